@@ -1,0 +1,83 @@
+"""Mint the golden fixtures by running the REFERENCE module classes (from /root/reference) on CPU fp32.
+
+Run in the build container only:   python -m tests.golden.make_golden
+Writes tests/golden/<case>.npz.  Weights and inputs are NOT stored: they are regenerated bit-identically
+from prismer_amd/synth.py (integer-hash generator), so a fixture holds only what the reference computed:
+
+  enc_eval      VisionTransformer.forward in eval mode (BN running stats)           [S,B,D]
+  logits_eval   RobertaForCausalLMModified logits (eval)                            [B,T,V] (strided for base)
+  loss_eval     per-sample loss [B]  (roberta.py:381-387)
+  enc_train / loss_train / total_train    same with the encoder in train() mode (BatchNorm batch statistics,
+                decoder dropout off) -- total = caption .mean() or VQA (weights*loss).mean()
+  bn.*          running_mean / running_var / num_batches_tracked of every BatchNorm after ONE train forward
+  gnorm.* gsamp.* gfull.*   gradients of `total_train` under the reference freeze rule 'freeze_vision'
+                (model/prismer.py:39-59 executed by the reference's own Prismer.prepare_to_train)
+  requires_grad names joined by '\n'
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from oracle import ref_harness as RH                     # noqa: E402
+from tests.golden import cases as C                      # noqa: E402
+
+
+def run_case(name):
+    case = C.Case(name)
+    d = case.dims
+    esd, dsd = case.weights()
+    x, ids, mask, labels, weights = case.inputs()
+    enc, dec = RH.build_reference(d, esd, dsd)
+    out = {}
+
+    def fwd():
+        random.seed(C.INSTANCE_SEED)
+        e = enc(x)
+        o = dec(ids, attention_mask=mask, encoder_hidden_states=e.permute(1, 0, 2), labels=labels, return_dict=True)
+        return e, o
+
+    with torch.no_grad():
+        e, o = fwd()
+    stride = C.LOGIT_STRIDE.get(name, 1)
+    out['enc_eval'] = e.numpy()
+    out['logits_eval'] = o.logits[..., ::stride].numpy()
+    out['loss_eval'] = o.loss.numpy()
+
+    holder = RH.reference_freeze(enc, dec, 'freeze_vision')
+    enc.train()          # BatchNorm batch statistics; the encoder has no dropout. dec stays eval (dropout off).
+    e, o = fwd()
+    total = (o.loss if weights is None else weights * o.loss).mean()
+    total.backward()
+    out['enc_train'] = e.detach().numpy()
+    out['loss_train'] = o.loss.detach().numpy()
+    out['total_train'] = total.detach().numpy()
+    for k, v in enc.state_dict().items():
+        if 'running_' in k or 'num_batches' in k:
+            out['bn.' + k] = v.numpy()
+    names = []
+    for n, p in holder.named_parameters():
+        if not p.requires_grad:
+            assert p.grad is None
+            continue
+        names.append(n)
+        g = p.grad.detach()
+        out['gnorm.' + n] = np.float64(g.double().norm().item())
+        out['gsamp.' + n] = g.flatten()[C.sample_idx(n, g.numel())].numpy()
+        if n in C.FULL_GRAD_KEYS:
+            out['gfull.' + n] = g.numpy()
+    out['requires_grad'] = np.array('\n'.join(names))
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f'{name}: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)  loss_eval={out["loss_eval"]}  '
+          f'total_train={out["total_train"]}  trainable={len(names)}')
+
+
+if __name__ == '__main__':
+    assert RH.available(), 'reference not mounted'
+    torch.set_num_threads(os.cpu_count())
+    for name in (sys.argv[1:] or list(C.CASES)):
+        run_case(name)

@@ -1,0 +1,133 @@
+"""CPU: the oracle restatement (oracle/prismer_oracle.py) against the committed reference outputs
+(tests/golden/*.npz, minted by tests/golden/make_golden.py from the reference module classes), and
+against the live reference when /root/reference is mounted."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import prismer_oracle as O
+from oracle import ref_harness as RH
+from tests.golden import cases as C
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+TOL = 2e-5          # fp32 vs fp32, different op order (packed MHA vs explicit matmul)
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name + '.npz'))
+
+
+def rel(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64); b = torch.as_tensor(b, dtype=torch.float64)
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def oracle_forward(case, train_bn, requires_grad=False):
+    d = case.dims
+    esd, dsd = case.weights()
+    x, ids, mask, labels, weights = case.inputs()
+    if requires_grad:
+        names = ['expert_encoder.' + k for k in esd] + ['text_decoder.' + k for k in dsd]
+        fm = O.freeze_mask(names, 'freeze_vision')
+        for k, v in esd.items():
+            if v.is_floating_point() and 'running' not in k:
+                v.requires_grad_(fm['expert_encoder.' + k])
+        seen = set()
+        for k, v in dsd.items():
+            if v.is_floating_point() and id(v) not in seen:
+                seen.add(id(v)); v.requires_grad_(fm['text_decoder.' + k])
+    tab = case.instance_table(x)
+    upd = {}
+    enc = O.vision_encoder(esd, x, d.patch_size, d.vit_heads, train_bn, tab, upd)
+    logits, loss = O.text_decoder(dsd, ids, mask, enc.transpose(0, 1), d.num_attention_heads, labels,
+                                  d.pad_token_id, d.label_smoothing)
+    total = (loss if weights is None else weights * loss).mean()
+    return esd, dsd, enc, logits, loss, total, upd
+
+
+@pytest.mark.parametrize('name', list(C.CASES))
+def test_oracle_matches_golden_eval(name):
+    g = load(name)
+    case = C.Case(name)
+    with torch.no_grad():
+        _, _, enc, logits, loss, _, _ = oracle_forward(case, False)
+    s = C.LOGIT_STRIDE.get(name, 1)
+    assert rel(enc, g['enc_eval']) < TOL
+    assert rel(logits[..., ::s], g['logits_eval']) < TOL
+    assert rel(loss, g['loss_eval']) < TOL
+
+
+@pytest.mark.parametrize('name', ['tiny_caption', 'tiny_vqa', 'tiny_bicubic', 'tiny_z'])
+def test_oracle_matches_golden_train_and_grads(name):
+    g = load(name)
+    case = C.Case(name)
+    esd, dsd, enc, logits, loss, total, upd = oracle_forward(case, True, requires_grad=True)
+    assert rel(enc.detach(), g['enc_train']) < TOL
+    assert rel(loss.detach(), g['loss_train']) < TOL
+    assert rel(total.detach(), g['total_train']) < TOL
+    for k, v in upd.items():                                   # BatchNorm running-stat update (App. C #7)
+        assert rel(v, g['bn.' + k]) < TOL, k
+    total.backward()
+    trainable = str(g['requires_grad']).split('\n')
+    got = {}
+    for k, v in esd.items():
+        if v.requires_grad:
+            got['expert_encoder.' + k] = v.grad
+    for k, v in dsd.items():
+        if v.requires_grad and not k.startswith('lm_head.decoder.'):
+            got['text_decoder.' + k] = v.grad
+    assert sorted(got) == sorted(trainable)
+    for n in trainable:
+        gr = got[n]
+        # fp32-vs-fp32 noise: gradients through train-mode BatchNorm of piecewise-constant label maps cancel
+        # heavily (1e-3 relative), attention key biases have an analytically ZERO gradient (pure round-off).
+        gn = float(g['gnorm.' + n])
+        assert abs(gr.double().norm().item() - gn) <= 1e-3 * gn + 1e-6, n
+        idx = C.sample_idx(n, gr.numel())
+        assert np.allclose(gr.flatten()[idx].numpy(), g['gsamp.' + n], rtol=2e-3, atol=1e-6 + 2e-3 * gn / gr.numel() ** 0.5), n
+        if 'gfull.' + n in g and gn > 1e-5:
+            assert rel(gr, g['gfull.' + n]) < 1e-3, n
+
+
+def test_freeze_rule_counts():
+    """trainable parameter counts under freeze_vision [probe]: 242.4 M of 327.5 M for BASE."""
+    from prismer_amd import config, synth
+    d = config.prismer_base()
+    names, numel = [], {}
+    for k, (shape, kind) in synth.encoder_spec(d).items():
+        if kind in ('bn_rm', 'bn_rv', 'i64zero'):
+            continue
+        names.append('expert_encoder.' + k); numel[names[-1]] = int(np.prod(shape))
+    for k, (shape, kind) in synth.decoder_spec(d).items():
+        if kind.startswith('alias') or kind == 'arange':
+            continue
+        names.append('text_decoder.' + k); numel[names[-1]] = int(np.prod(shape))
+    fm = O.freeze_mask(names, 'freeze_vision')
+    total = sum(numel.values()); train = sum(numel[n] for n in names if fm[n])
+    assert abs(total / 1e6 - 327.5) < 0.1 and abs(train / 1e6 - 242.4) < 0.1
+
+
+def test_position_ids_and_mask():
+    ids = torch.tensor([[0, 5, 6, 1, 1]])
+    assert O.position_ids_from_input_ids(ids, 1).tolist() == [[2, 3, 4, 1, 1]]       # App. C #12
+    m = O.extended_attention_mask(torch.tensor([[1, 1, 0]]), torch.float32)
+    keep = (m == 0)[0, 0].tolist()
+    assert keep == [[True, False, False], [True, True, False], [True, True, False]]
+
+
+@pytest.mark.skipif(not RH.available(), reason='reference not mounted (GPU box)')
+def test_oracle_matches_live_reference():
+    case = C.Case('tiny_caption')
+    d = case.dims
+    esd, dsd = case.weights()
+    x, ids, mask, labels, _ = case.inputs()
+    enc, dec = RH.build_reference(d, esd, dsd)
+    random.seed(C.INSTANCE_SEED)
+    with torch.no_grad():
+        e = enc(x)
+        o = dec(ids, attention_mask=mask, encoder_hidden_states=e.permute(1, 0, 2), labels=labels, return_dict=True)
+        _, _, enc_o, logits, loss, _, _ = oracle_forward(case, False)
+    assert rel(enc_o, e) < TOL and rel(logits, o.logits) < TOL and rel(loss, o.loss) < TOL
