@@ -1,0 +1,233 @@
+/* prismer_hip.h -- C ABI of libprismer_hip.so: the MI355X (gfx950) operator set behind the Prismer
+ * forward/backward hot path.
+ *
+ * The reference (NVlabs/prismer) has no plugin / FFI layer: its hot path is eager PyTorch
+ * (model/modules/{vit,resampler,roberta,utils}.py).  The seam this library plugs into is therefore the ATen
+ * operator level underneath those modules; each entry point names the reference call site(s) whose
+ * arithmetic it replaces (paths relative to the reference root).  See INTEGRATION.md for the ctypes binding
+ * and the nn.Module shells that keep the reference's parameter names.
+ *
+ * Conventions
+ *   - plain C: raw device pointers, ints, floats and a hipStream_t; no C++ / torch types cross the ABI.
+ *   - every function only ENQUEUES work on `stream`; it never allocates, frees or synchronises, keeps no
+ *     pointer past the call and is safe under hipGraph stream capture.
+ *   - activations / matrix weights are bf16 (row-major, contiguous unless a leading dimension is given);
+ *     vectors (biases, LayerNorm / BatchNorm affine), statistics, gradients of parameters, optimizer state
+ *     and losses are fp32.
+ *   - return value: PH_OK (0) or a negative PH_ERR_* code; ph_last_error() returns a thread-local message.
+ *     No exceptions, no abort().
+ */
+#ifndef PRISMER_HIP_H_
+#define PRISMER_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define PH_VERSION 100
+
+enum { PH_OK = 0, PH_ERR_BAD_ARG = -1, PH_ERR_UNSUPPORTED = -2, PH_ERR_LAUNCH = -3 };
+enum { PH_ACT_NONE = 0, PH_ACT_QUICKGELU = 1, PH_ACT_RELU2 = 2, PH_ACT_GELU = 3, PH_ACT_RELU = 4 };
+
+int ph_version(void);
+const char* ph_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM + fused epilogue.   C[M,N] = epi( alpha * sum_k opA[m,k] * opB[n,k] )
+ * Replaces: nn.Linear / F.linear everywhere (vit.py:41-47, resampler.py:18-24, utils.py:50-56,
+ * roberta.py:86-92,134,163,177,415-421), the packed in-projection of nn.MultiheadAttention (vit.py:53,
+ * resampler.py:31), convolutions after im2col (vit.py:86-120), and their autograd dgrad / wgrad.
+ *   trans_x == 0: operand stored [rows][K] (K contiguous);  trans_x == 1: stored [K][rows].
+ *   epilogue order: +bias -> (pre_out store) -> act | *act'(act_in) -> dropout -> +residual -> (+C) -> store
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* A; const void* B; void* C;
+  int M, N, K;
+  int lda, ldb, ldc;              /* in elements */
+  int trans_a, trans_b;
+  const float* bias;              /* [N] or NULL */
+  int act;                        /* PH_ACT_* */
+  void* pre_out;                  /* optional bf16 [M,N] (ld = ldc): value before the activation */
+  const void* act_in; int ld_act; /* optional bf16: C = acc * act'(act_in)   (backward through `act`) */
+  const void* residual; int ldr;  /* optional bf16 [M,N] added last */
+  float drop_p; const uint64_t* drop_seed; uint32_t drop_stream;   /* inverted dropout on the activation */
+  int out_f32;                    /* C is fp32 instead of bf16 */
+  int accumulate;                 /* C += result */
+  float alpha;
+  int split_k;                    /* 0 = auto (only out_f32 + accumulate GEMMs are ever split) */
+} ph_gemm_args;
+int ph_gemm_bf16(const ph_gemm_args* args, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm (fp32 math, eps inside the sqrt).  Replaces model/modules/utils.py:14-19 (F.layer_norm in
+ * fp32 + casts) at every call site: vit.py:50-59,130-131,169-171; resampler.py:26-36; utils.py:57-64;
+ * roberta.py:139,182,425.
+ * Row mapping: logical row r of a mapped tensor lives at physical row
+ *     (r / seg_in) * seg_out + seg_off + r % seg_in          (seg_in == 0 -> identity)
+ * which lets LN write straight into the [latents ; x] concatenation of the resampler (resampler.py:34).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { int seg_in, seg_out, seg_off; } ph_rowmap;
+typedef struct {
+  const void* x;                  /* bf16 [M,D] */
+  const float* gamma; const float* beta;
+  void* y; ph_rowmap y_map;       /* bf16 */
+  void* y2; ph_rowmap y2_map;     /* optional second copy of the output */
+  float* mean; float* rstd;       /* fp32 [M], optional */
+  int M, D; float eps;
+} ph_layernorm_fwd_args;
+int ph_layernorm_fwd(const ph_layernorm_fwd_args* args, hipStream_t stream);
+
+typedef struct {
+  const void* dy; ph_rowmap dy_map;      /* bf16 */
+  const void* dy2; ph_rowmap dy2_map;    /* optional second upstream gradient, summed with dy */
+  const void* x; const float* mean; const float* rstd; const float* gamma;
+  const void* dskip;              /* optional bf16 [M,D]: gradient arriving through the residual branch */
+  void* dx;                       /* bf16 [M,D] = LN'(dy) + dskip */
+  void* dx_drop;                  /* optional bf16 [M,D] = dx * dropout-mask / (1-p) (mask of the fwd GEMM epilogue) */
+  float drop_p; const uint64_t* drop_seed; uint32_t drop_stream;
+  float* dgamma; float* dbeta;    /* fp32 [D], ACCUMULATED (atomics); NULL when the affine is frozen */
+  int M, D;
+} ph_layernorm_bwd_args;
+int ph_layernorm_bwd(const ph_layernorm_bwd_args* args, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused multi-head attention (flash style: online softmax, scores never materialised).
+ * Replaces: nn.MultiheadAttention core (vit.py:53; resampler.py:31) and RobertaSelfAttention
+ * scores/mask/clamp/softmax/dropout/PV (roberta.py:101-126).
+ * Token (b, t), head h, channel c of q lives at  q + b*q_bs + t*q_ts + h*dh + c   (elements).
+ * key_mask[b*Sk + j] == 0 or (causal && j > i)  =>  score = finfo.min (finite, as roberta.py:113-115).
+ * lse[(b*H+h)*Sq + i] = log-sum-exp of the scaled, masked scores (saved for backward).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* q; const void* k; const void* v; void* o;
+  int64_t q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts;
+  int B, H, Sq, Sk, dh;
+  float scale;
+  const uint8_t* key_mask; int causal;
+  float drop_p; const uint64_t* drop_seed; uint32_t drop_stream;
+  float* lse;
+} ph_attn_fwd_args;
+int ph_attention_fwd(const ph_attn_fwd_args* args, hipStream_t stream);
+
+typedef struct {
+  ph_attn_fwd_args f;             /* same tensors as forward (o = forward output, lse filled) */
+  const void* d_o; int64_t do_bs, do_ts;
+  void* dq; void* dk; void* dv;   /* bf16, same strides as q / k / v */
+  int64_t dq_bs, dq_ts, dk_bs, dk_ts, dv_bs, dv_ts;
+  float* delta;                   /* workspace fp32 [B*H*Sq] */
+} ph_attn_bwd_args;
+int ph_attention_bwd(const ph_attn_bwd_args* args, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Encoder front end (vit.py:86-160).
+ * ---------------------------------------------------------------------------------------------- */
+/* fp32 NCHW image -> bf16 patch matrix [B*g*g, Kp], column order (c, py, px) = Conv2d weight [D,3,p,p]
+ * flattened (vit.py:86,138), zero-padded to Kp. */
+int ph_patchify(const float* img, void* col, int B, int C, int R, int p, int Kp, hipStream_t stream);
+/* nn.UpsamplingBilinear2d (align_corners=True, vit.py:89,106) fused with NCHW fp32 -> NHWC bf16. */
+int ph_resize_bilinear_nchw_to_nhwc(const float* x, void* y, int B, int C, int Hin, int Win, int Hout, int Wout,
+                                    hipStream_t stream);
+/* 3x3 (pad 1) or 1x1 (pad 0) window gather from an NHWC bf16 map into col[B*Ho*Wo, Kp] with column order
+ * (ky, kx, c); optionally applies BatchNorm(scale, shift per channel) + ReLU to every gathered element
+ * (vit.py:90-103: conv -> BN -> ReLU -> conv, the normalised map is never written on its own). */
+int ph_im2col_nhwc(const void* x, void* col, int B, int H, int W, int C, int ksize, int stride, int Kp,
+                   const float* bn_scale, const float* bn_shift, hipStream_t stream);
+/* adjoint of ph_im2col_nhwc: dx[b,y,x,c] = sum of dcol entries that read it (gather form, deterministic). */
+int ph_col2im_nhwc(const void* dcol, void* dx, int B, int H, int W, int C, int ksize, int stride, int Kp,
+                   hipStream_t stream);
+/* BatchNorm2d training statistics over the rows of y[M,C] (vit.py:91-101): biased variance for normalisation,
+ * running_mean/var update with momentum and UNBIASED variance, scale = gamma*rstd, shift = beta - mean*scale.
+ * training == 0: scale/shift from the running statistics, nothing updated. */
+int ph_bn_stats(const void* y, int M, int C, const float* gamma, const float* beta, float* running_mean,
+                float* running_var, float momentum, float eps, int training, float* mean, float* rstd,
+                float* scale, float* shift, hipStream_t stream);
+/* BatchNorm + ReLU backward.  da = gradient w.r.t. relu(bn(y)).  Two kernels inside:
+ * (1) dgamma += sum g*xhat, dbeta += sum g with g = da * [bn(y) > 0];  (2) dy = gamma*rstd*(g - dbeta/M - xhat*dgamma/M).
+ * sums: fp32 workspace [2*C] (zeroed by the call). */
+int ph_bn_relu_bwd(const void* da, const void* y, void* dy, int M, int C, const float* gamma, const float* beta,
+                   const float* mean, const float* rstd, float* dgamma, float* dbeta, float* sums,
+                   hipStream_t stream);
+/* tokens[b, off + t, :] = feat[b*G + t, :] + pos[t, :] (+ inst_emb[table[inst[b, nearest(t)]], :])
+ * (vit.py:141-159).  inst: int64 [B, E, E] instance map (nearest down-sampling to g x g), table: int32[256]. */
+int ph_tokens_finalize(const void* feat, const float* pos, void* tokens, int B, int G, int D, int tok_per_batch,
+                       int tok_off, const int64_t* inst, int E, int g, const int32_t* table, const float* inst_emb,
+                       hipStream_t stream);
+/* backward of the above: dfeat (bf16 [B*G, D]) = dtokens slice; dpos[t,:] += sum_b; dinst_emb[row,:] += ... */
+int ph_tokens_finalize_bwd(const void* dtokens, void* dfeat, float* dpos, int B, int G, int D, int tok_per_batch,
+                           int tok_off, const int64_t* inst, int E, int g, const int32_t* table, float* dinst_emb,
+                           hipStream_t stream);
+/* out[i,:] = sum_t w[i,t] * in[idx[i,t],:]  (bicubic positional-embedding re-grid, utils.py:34-44) and adjoint */
+int ph_gather_taps(const float* in, float* out, const int32_t* idx, const float* w, int n_out, int taps, int D,
+                   hipStream_t stream);
+int ph_scatter_taps(const float* dout, float* din, const int32_t* idx, const float* w, int n_out, int taps, int D,
+                    hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Decoder embeddings (roberta.py:38-45,66-76): position ids = cumsum(ids != pad)*(ids != pad) + pad,
+ * word + token_type[0] + position -> LayerNorm -> dropout.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const int64_t* ids; int B, T, H; int pad_id;
+  const float* word; const float* pos; const float* type;     /* fp32 master tables */
+  const float* gamma; const float* beta; float eps;
+  void* out;                      /* bf16 [B*T, H] */
+  void* xhat;                     /* bf16 [B*T, H] normalised pre-affine value, saved for backward */
+  float* rstd;                    /* fp32 [B*T] */
+  float drop_p; const uint64_t* drop_seed; uint32_t drop_stream;
+} ph_embed_fwd_args;
+int ph_embed_fwd(const ph_embed_fwd_args* args, hipStream_t stream);
+typedef struct {
+  ph_embed_fwd_args f;
+  const void* dout;               /* bf16 [B*T, H] */
+  float* dword; float* dpos; float* dtype; float* dgamma; float* dbeta;   /* fp32, accumulated with atomics */
+} ph_embed_bwd_args;
+int ph_embed_bwd(const ph_embed_bwd_args* args, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Shifted label-smoothed cross entropy over bf16 logits (roberta.py:381-387):
+ * token (b,t) for t < T-1 is scored against labels[b,t+1]; ignore_index -100;
+ * loss[b] = sum_t (1-eps)*nll + eps*mean_c(-log p_c).   Backward overwrites `logits` with dlogits (bf16):
+ * dloss[b] * (softmax - (1-eps)*onehot - eps/V) for scored tokens, 0 elsewhere (incl. row T-1 and pad columns).
+ * ---------------------------------------------------------------------------------------------- */
+int ph_ce_fwd(const void* logits, int ld, const int64_t* labels, int B, int T, int V, float eps, float* loss,
+              float* row_lse, hipStream_t stream);
+int ph_ce_bwd(void* logits, int ld, const int64_t* labels, int B, int T, int V, int Vpad, float eps,
+              const float* row_lse, const float* dloss, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer and small utilities.
+ * ---------------------------------------------------------------------------------------------- */
+/* torch.optim.AdamW step (train_caption.py:111-112,133) over a flat fp32 range; also refreshes the bf16 shadow.
+ * lr and step are read from device memory (hipGraph replays see new values): hyper[0] = lr, hyper[1] = bias
+ * correction1 = 1-b1^t, hyper[2] = bias correction2 = 1-b2^t. grad_scale multiplies g first (1/world). */
+int ph_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const float* hyper, float beta1,
+             float beta2, float eps, float weight_decay, float grad_scale, hipStream_t stream);
+int ph_cast_f32_to_bf16(const float* x, void* y, int64_t n, hipStream_t stream);
+int ph_cast_bf16_to_f32(const void* x, float* y, int64_t n, hipStream_t stream);
+/* out[n] += sum_m x[m,n]  (bias gradients) */
+int ph_colsum_bf16(const void* x, int M, int N, int ld, float* out, hipStream_t stream);
+/* y = a + b (bf16, n elements) */
+int ph_add_bf16(const void* a, const void* b, void* y, int64_t n, hipStream_t stream);
+/* generic 2-D strided copy of bf16 rows: dst[r*ldd + c] = src[map(r)*lds + c], c < cols */
+int ph_copy_rows_bf16(const void* src, int lds, ph_rowmap src_map, void* dst, int ldd, ph_rowmap dst_map, int rows,
+                      int cols, int accumulate, hipStream_t stream);
+/* conv weight layout changes: w[Cout,Cin,kh,kw] fp32 -> shadow bf16 [Cout, Kp] with column order (ky,kx,c) */
+int ph_conv_weight_to_shadow(const float* w, void* shadow, int Cout, int Cin, int ks, int Kp, hipStream_t stream);
+/* and the adjoint for gradients: dshadow fp32 [Cout,Kp] (ky,kx,c) -> dw[Cout,Cin,kh,kw] += */
+int ph_conv_grad_from_shadow(const float* dshadow, float* dw, int Cout, int Cin, int ks, int Kp, hipStream_t stream);
+/* advance the dropout seed (device-side, graph-replay safe): seed[0] = splitmix(seed[0]) */
+int ph_advance_seed(uint64_t* seed, hipStream_t stream);
+
+/* unit-test probe: exercises ds_read_b64_tr_b16 / MFMA lane layouts on the device (tests/test_kernels_gpu.py) */
+int ph_probe_layouts(const void* in_bf16, float* out, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRISMER_HIP_H_ */

@@ -1,0 +1,59 @@
+"""Builds libprismer_hip.so (gfx950) in-tree with hipcc.  `python -m prismer_amd.build [--force]`.
+
+The .so lands in prismer_amd/lib/ (git-ignored, but shipped to the GPU box by gpurun).  No torch involved:
+the library is plain HIP behind a C ABI (include/prismer_hip.h).
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, 'lib')
+LIB = os.path.join(LIBDIR, 'libprismer_hip.so')
+SOURCES = ['core.hip', 'gemm.hip', 'norm.hip', 'attention.hip', 'frontend.hip', 'embed_loss.hip', 'optim.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-pass-failed']
+
+
+def _digest():
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)) + ['../../include/prismer_hip.h']:
+        p = os.path.join(CSRC, f)
+        if os.path.isfile(p):
+            h.update(f.encode()); h.update(open(p, 'rb').read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    stamp = os.path.join(LIBDIR, 'build.stamp')
+    dig = _digest()
+    if not force and os.path.isfile(LIB) and os.path.isfile(stamp) and open(stamp).read() == dig:
+        return LIB
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objs = []
+
+    def cc(src):
+        obj = os.path.join(LIBDIR, src.replace('.hip', '.o'))
+        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc failed on {src}:\n{r.stderr[-4000:]}')
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(cc, SOURCES))
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('link failed:\n' + r.stderr[-4000:])
+    open(stamp, 'w').write(dig)
+    if verbose:
+        print(f'built {LIB} ({os.path.getsize(LIB) / 1e6:.1f} MB)')
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

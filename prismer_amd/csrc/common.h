@@ -1,0 +1,111 @@
+// Common device/host helpers for the prismer_hip library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/prismer_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define PH_WAVE 64
+
+// ---- error plumbing -----------------------------------------------------------------------------
+void ph_set_error(const std::string& msg);
+int ph_fail(int code, const char* fmt, ...);
+#define PH_CHECK_ARG(cond, ...)                                   \
+  do {                                                            \
+    if (!(cond)) return ph_fail(PH_ERR_BAD_ARG, __VA_ARGS__);     \
+  } while (0)
+#define PH_LAUNCH_CHECK(name)                                                          \
+  do {                                                                                 \
+    hipError_t e__ = hipGetLastError();                                                \
+    if (e__ != hipSuccess) return ph_fail(PH_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- bf16 <-> f32 -------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+__device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }   // v_cvt_pk_bf16_f32: RNE
+
+// ---- wave reductions (64 lanes) -----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- activations --------------------------------------------------------------------------------
+// reference: QuickGELU utils.py:23-25, SquaredReLU utils.py:28-30, erf-GELU roberta.py:164,423
+__device__ __forceinline__ float act_fwd(int act, float x) {
+  switch (act) {
+    case PH_ACT_QUICKGELU: return x / (1.0f + __expf(-1.702f * x));
+    case PH_ACT_RELU2: { float r = fmaxf(x, 0.0f); return r * r; }
+    case PH_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    case PH_ACT_RELU: return fmaxf(x, 0.0f);
+    default: return x;
+  }
+}
+__device__ __forceinline__ float act_grad(int act, float x) {
+  switch (act) {
+    case PH_ACT_QUICKGELU: {
+      float s = 1.0f / (1.0f + __expf(-1.702f * x));
+      return s * (1.0f + 1.702f * x * (1.0f - s));
+    }
+    case PH_ACT_RELU2: return 2.0f * fmaxf(x, 0.0f);
+    case PH_ACT_GELU: {
+      float c = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+      return c + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    }
+    case PH_ACT_RELU: return x > 0.0f ? 1.0f : 0.0f;
+    default: return 1.0f;
+  }
+}
+
+// ---- Philox4x32-10 (dropout masks are a pure function of (seed, stream, element index)) -------------
+__device__ __forceinline__ u32x4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  u32x4 o = {c0, c1, c2, c3};
+  return o;
+}
+// keep-mask for 4 consecutive elements whose first linear index is idx (idx % 4 == 0).
+// keep[i] <=> u_i >= p  with u_i = top 24 bits / 2^24.
+struct DropCtx {
+  uint32_t k0, k1, stream, thr;   // thr = p * 2^24
+  float scale;                    // 1/(1-p)
+};
+__device__ __forceinline__ DropCtx make_drop(const uint64_t* seed_ptr, uint32_t stream, float p) {
+  DropCtx d;
+  uint64_t s = seed_ptr ? *seed_ptr : 0ull;
+  d.k0 = (uint32_t)s; d.k1 = (uint32_t)(s >> 32); d.stream = stream;
+  d.thr = (uint32_t)(p * 16777216.0f);
+  d.scale = 1.0f / (1.0f - p);
+  return d;
+}
+__device__ __forceinline__ u32x4 drop_rand4(const DropCtx& d, uint64_t idx4) {   // idx4 = element index / 4
+  return philox4x32((uint32_t)idx4, (uint32_t)(idx4 >> 32), d.stream, 0x5eedu, d.k0, d.k1);
+}
+__device__ __forceinline__ float drop_apply(const DropCtx& d, uint32_t r, float v) {
+  return ((r >> 8) >= d.thr) ? v * d.scale : 0.0f;
+}

@@ -1,0 +1,471 @@
+// Encoder front end for gfx950: patchify, expert-stem data movement (bilinear resize, im2col / col2im),
+// train-mode BatchNorm statistics + backward, token assembly (pos / instance embeddings).
+// Replaces the non-GEMM parts of model/modules/vit.py:86-160.  All of these are HBM-bound byte movers:
+// every thread moves 16-B vectors along the channel (innermost NHWC) dimension.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ patchify
+// vit.py:86,138: Conv2d(3, D, kernel=p, stride=p, bias=False) == GEMM over non-overlapping patches.
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, bf16* __restrict__ col, int B, int C,
+                                                       int R, int p, int Kp) {
+  int g = R / p;
+  int64_t total = (int64_t)B * g * g * (Kp / 2);
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    int k2 = (int)(id % (Kp / 2));
+    int64_t m = id / (Kp / 2);
+    int gx = (int)(m % g), gy = (int)((m / g) % g), b = (int)(m / ((int64_t)g * g));
+    bf16x2 o;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      int k = k2 * 2 + e;
+      float v = 0.f;
+      if (k < C * p * p) {
+        int c = k / (p * p), rem = k % (p * p), py = rem / p, px = rem % p;
+        v = img[(((int64_t)b * C + c) * R + gy * p + py) * R + gx * p + px];
+      }
+      o[e] = f2bf(v);
+    }
+    *reinterpret_cast<bf16x2*>(col + m * Kp + k2 * 2) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ resize
+// nn.UpsamplingBilinear2d == F.interpolate(mode='bilinear', align_corners=True) (vit.py:89,106), fused with the
+// NCHW fp32 -> NHWC bf16 layout change.  One block per (b, out row, group of 8 channels): consecutive lanes walk
+// consecutive x of one channel plane (coalesced source rows), the 8-channel pixel vectors are assembled in LDS
+// and stored as 16-B pieces.
+__global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ x, bf16* __restrict__ y, int B, int C, int Hin,
+                                                     int Win, int Hout, int Wout) {
+  __shared__ bf16 tile[1024 * 8];
+  int cgroups = (C + 7) / 8;
+  int cg = blockIdx.x % cgroups;
+  int oy = (blockIdx.x / cgroups) % Hout;
+  int b = blockIdx.x / (cgroups * Hout);
+  int c0 = cg * 8, nc = min(8, C - c0);
+  float sy = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f;
+  float sx = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
+  float fy = oy * sy;
+  int y0 = min((int)fy, Hin - 1), y1 = min(y0 + 1, Hin - 1);
+  float wy = fy - (float)y0;
+  for (int xb = 0; xb < Wout; xb += 1024) {
+    int wchunk = min(1024, Wout - xb);
+    for (int id = threadIdx.x; id < wchunk * nc; id += 256) {
+      int cc = id / wchunk, ox = xb + id % wchunk;
+      float fx = ox * sx;
+      int x0 = min((int)fx, Win - 1), x1 = min(x0 + 1, Win - 1);
+      float wx = fx - (float)x0;
+      const float* pl = x + ((int64_t)b * C + c0 + cc) * Hin * Win;
+      float v00 = pl[(int64_t)y0 * Win + x0], v01 = pl[(int64_t)y0 * Win + x1];
+      float v10 = pl[(int64_t)y1 * Win + x0], v11 = pl[(int64_t)y1 * Win + x1];
+      float v = (1.f - wy) * ((1.f - wx) * v00 + wx * v01) + wy * ((1.f - wx) * v10 + wx * v11);
+      tile[(ox - xb) * 8 + cc] = f2bf(v);
+    }
+    __syncthreads();
+    bf16* orow = y + (((int64_t)b * Hout + oy) * Wout + xb) * C + c0;
+    if (nc == 8 && (C % 8) == 0) {
+      for (int ox = threadIdx.x; ox < wchunk; ox += 256)
+        *reinterpret_cast<u32x4*>(orow + (int64_t)ox * C) = *reinterpret_cast<const u32x4*>(tile + ox * 8);
+    } else {
+      for (int id = threadIdx.x; id < wchunk * nc; id += 256) {
+        int ox = id / nc, cc = id % nc;
+        orow[(int64_t)ox * C + cc] = tile[ox * 8 + cc];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ im2col
+// col[m][(ky*ks+kx)*C + c] = act(x[b][oy*s - pad + ky][ox*s - pad + kx][c]), zero outside / beyond K.
+// act = BN(scale, shift) + ReLU when bn_scale != NULL (the conv of vit.py:92-103 consumes relu(bn(prev))).
+template <bool VEC>
+__global__ __launch_bounds__(256) void im2col_kernel(const bf16* __restrict__ x, bf16* __restrict__ col, int B, int H, int W, int C,
+                                                     int ks, int stride, int Kp, int Ho, int Wo,
+                                                     const float* __restrict__ sc, const float* __restrict__ sh) {
+  const int pad = ks / 2;
+  const int K = ks * ks * C;
+  if (VEC) {   // C % 8 == 0: one thread per 16-B chunk
+    const int cpr = Kp / 8;
+    int64_t total = (int64_t)B * Ho * Wo * cpr;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+      int ch = (int)(id % cpr);
+      int64_t m = id / cpr;
+      int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho), b = (int)(m / ((int64_t)Wo * Ho));
+      int k = ch * 8;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (k < K) {
+        int tap = k / C, c = k % C, ky = tap / ks, kx = tap % ks;
+        int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+          v = *reinterpret_cast<const u32x4*>(x + (((int64_t)b * H + iy) * W + ix) * C + c);
+          if (sc) {
+            bf16x8 t = *reinterpret_cast<bf16x8*>(&v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = f2bf(fmaxf(bf2f(t[e]) * sc[c + e] + sh[c + e], 0.f));
+            v = *reinterpret_cast<u32x4*>(&t);
+          }
+        }
+      }
+      *reinterpret_cast<u32x4*>(col + m * Kp + k) = v;
+    }
+  } else {     // small C (1 or 3): one thread per element
+    int64_t total = (int64_t)B * Ho * Wo * Kp;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+      int k = (int)(id % Kp);
+      int64_t m = id / Kp;
+      int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho), b = (int)(m / ((int64_t)Wo * Ho));
+      float v = 0.f;
+      if (k < K) {
+        int tap = k / C, c = k % C, ky = tap / ks, kx = tap % ks;
+        int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+          v = bf2f(x[(((int64_t)b * H + iy) * W + ix) * C + c]);
+          if (sc) v = fmaxf(v * sc[c] + sh[c], 0.f);
+        }
+      }
+      col[id] = f2bf(v);
+    }
+  }
+}
+
+// adjoint (gather form): dx[b][y][x][c] = sum over taps (ky,kx) with (y + pad - ky) % s == 0 of dcol[m][tap*C + c]
+__global__ __launch_bounds__(256) void col2im_kernel(const bf16* __restrict__ dcol, bf16* __restrict__ dx, int B, int H, int W, int C,
+                                                     int ks, int stride, int Kp, int Ho, int Wo) {
+  const int pad = ks / 2;
+  const int cpr = C / 8;
+  int64_t total = (int64_t)B * H * W * cpr;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    int c = (int)(id % cpr) * 8;
+    int64_t pix = id / cpr;
+    int ix = (int)(pix % W), iy = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int ky = 0; ky < ks; ++ky) {
+      int ty = iy + pad - ky;
+      if (ty < 0 || (ty % stride) != 0) continue;
+      int oy = ty / stride;
+      if (oy >= Ho) continue;
+      for (int kx = 0; kx < ks; ++kx) {
+        int tx = ix + pad - kx;
+        if (tx < 0 || (tx % stride) != 0) continue;
+        int ox = tx / stride;
+        if (ox >= Wo) continue;
+        int64_t m = ((int64_t)b * Ho + oy) * Wo + ox;
+        bf16x8 t = *reinterpret_cast<const bf16x8*>(dcol + m * Kp + (ky * ks + kx) * C + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += bf2f(t[e]);
+      }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[e]);
+    *reinterpret_cast<bf16x8*>(dx + pix * C + c) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm
+// column reduction helper: rows x C (C % 8 == 0), each thread owns one 8-channel chunk of a row strip.
+// MODE 0: sums[c] += x, sums[C+c] += x*x.          (forward statistics)
+// MODE 1: g = da * [scale*y+shift > 0]; sums[c] += g, sums[C+c] += g * xhat   (backward sums)
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const bf16* __restrict__ y, const bf16* __restrict__ da, int M, int C,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ sums) {
+  extern __shared__ float red[];   // [2][C]
+  const int tpr = C / 8;
+  const int rpp = 256 / tpr;       // rows per pass
+  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
+  __syncthreads();
+  float a0[8], a1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+  const int r_in = threadIdx.x / tpr, cc = threadIdx.x % tpr;
+  float mu[8], rs[8], gm[8], bt[8];
+  if (MODE == 1 && r_in < rpp) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { mu[e] = mean[cc * 8 + e]; rs[e] = rstd[cc * 8 + e]; gm[e] = gamma[cc * 8 + e]; bt[e] = beta[cc * 8 + e]; }
+  }
+  if (r_in < rpp) {
+    for (int64_t r = (int64_t)blockIdx.x * rpp + r_in; r < M; r += (int64_t)gridDim.x * rpp) {
+      bf16x8 t = *reinterpret_cast<const bf16x8*>(y + r * C + cc * 8);
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { float v = bf2f(t[e]); a0[e] += v; a1[e] += v * v; }
+      } else {
+        bf16x8 d = *reinterpret_cast<const bf16x8*>(da + r * C + cc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float xh = (bf2f(t[e]) - mu[e]) * rs[e];
+          float g = (xh * gm[e] + bt[e] > 0.f) ? bf2f(d[e]) : 0.f;
+          a0[e] += g; a1[e] += g * xh;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { atomicAdd(&red[cc * 8 + e], a0[e]); atomicAdd(&red[C + cc * 8 + e], a1[e]); }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&sums[i], red[i]);
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, int M, int C, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, float momentum, float eps, int training,
+                                   float* mean, float* rstd, float* scale, float* shift) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mu, var;
+  if (training) {
+    mu = sums[c] / (float)M;
+    var = fmaxf(sums[C + c] / (float)M - mu * mu, 0.f);
+    float unb = M > 1 ? var * (float)M / (float)(M - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+  } else {
+    mu = running_mean[c];
+    var = running_var[c];
+  }
+  float r = rsqrtf(var + eps);
+  mean[c] = mu; rstd[c] = r;
+  float s = gamma[c] * r;
+  scale[c] = s; shift[c] = beta[c] - mu * s;
+}
+
+// dy = gamma*rstd*(g - dbeta/M - xhat*dgamma/M); block 0 also accumulates dgamma/dbeta into the parameter grads.
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restrict__ da, const bf16* __restrict__ y, bf16* __restrict__ dy,
+                                                           int64_t M, int C, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ sums,
+                                                           float* dgamma, float* dbeta) {
+  const int cpr = C / 8;
+  int64_t total = M * cpr;
+  float invM = 1.f / (float)M;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    int c = (int)(id % cpr) * 8;
+    int64_t r = id / cpr;
+    bf16x8 t = *reinterpret_cast<const bf16x8*>(y + r * C + c);
+    bf16x8 d = *reinterpret_cast<const bf16x8*>(da + r * C + c);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float xh = (bf2f(t[e]) - mean[c + e]) * rstd[c + e];
+      float g = (xh * gamma[c + e] + beta[c + e] > 0.f) ? bf2f(d[e]) : 0.f;
+      o[e] = f2bf(gamma[c + e] * rstd[c + e] * (g - sums[c + e] * invM - xh * sums[C + c + e] * invM));
+    }
+    *reinterpret_cast<bf16x8*>(dy + r * C + c) = o;
+  }
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      if (dbeta) atomicAdd(dbeta + c, sums[c]);
+      if (dgamma) atomicAdd(dgamma + c, sums[C + c]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ tokens
+__device__ __forceinline__ int nearest_src(int dst, int in, int out) {   // F.interpolate(mode='nearest'), vit.py:142
+  float scale = (float)in / (float)out;
+  return min((int)floorf((float)dst * scale), in - 1);
+}
+
+__global__ __launch_bounds__(256) void tokens_kernel(const bf16* __restrict__ feat, const float* __restrict__ pos, bf16* __restrict__ tokens,
+                                                     int B, int G, int D, int tpb, int off, const int64_t* __restrict__ inst, int E,
+                                                     int g, const int32_t* __restrict__ table, const float* __restrict__ inst_emb) {
+  const int cpr = D / 4;
+  int64_t total = (int64_t)B * G * cpr;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    int c = (int)(id % cpr) * 4;
+    int64_t bt = id / cpr;
+    int t = (int)(bt % G), b = (int)(bt / G);
+    bf16x4 f = *reinterpret_cast<const bf16x4*>(feat + bt * D + c);
+    f32x4 p = *reinterpret_cast<const f32x4*>(pos + (int64_t)t * D + c);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = bf2f(f[e]) + p[e];
+    if (inst) {
+      int ty = t / g, tx = t % g;
+      int64_t lab = inst[((int64_t)b * E + nearest_src(ty, E, g)) * E + nearest_src(tx, E, g)];
+      int row = table[(int)(lab & 255)];
+      f32x4 ie = *reinterpret_cast<const f32x4*>(inst_emb + (int64_t)row * D + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += ie[e];
+    }
+    bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+    *reinterpret_cast<bf16x4*>(tokens + ((int64_t)b * tpb + off + t) * D + c) = o;
+  }
+}
+
+// one thread per (t, 4 channels): loops over the batch -> deterministic dpos; dinst_emb via atomics.
+__global__ __launch_bounds__(256) void tokens_bwd_kernel(const bf16* __restrict__ dtok, bf16* __restrict__ dfeat, float* __restrict__ dpos,
+                                                         int B, int G, int D, int tpb, int off, const int64_t* __restrict__ inst,
+                                                         int E, int g, const int32_t* __restrict__ table, float* __restrict__ dinst) {
+  const int cpr = D / 4;
+  int total = G * cpr;
+  int id = blockIdx.x * 256 + threadIdx.x;
+  if (id >= total) return;
+  int c = (id % cpr) * 4, t = id / cpr;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < B; ++b) {
+    bf16x4 d = *reinterpret_cast<const bf16x4*>(dtok + ((int64_t)b * tpb + off + t) * D + c);
+    if (dfeat) *reinterpret_cast<bf16x4*>(dfeat + ((int64_t)b * G + t) * D + c) = d;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += bf2f(d[e]);
+    if (inst && dinst) {
+      int ty = t / g, tx = t % g;
+      int64_t lab = inst[((int64_t)b * E + nearest_src(ty, E, g)) * E + nearest_src(tx, E, g)];
+      int row = table[(int)(lab & 255)];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(dinst + (int64_t)row * D + c + e, bf2f(d[e]));
+    }
+  }
+  if (dpos) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(dpos + (int64_t)t * D + c + e, acc[e]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ taps
+__global__ void gather_taps_kernel(const float* __restrict__ in, float* __restrict__ out, const int32_t* __restrict__ idx,
+                                   const float* __restrict__ w, int n_out, int taps, int D) {
+  int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (int64_t)n_out * D) return;
+  int d = (int)(id % D), i = (int)(id / D);
+  float s = 0.f;
+  for (int t = 0; t < taps; ++t) s += w[i * taps + t] * in[(int64_t)idx[i * taps + t] * D + d];
+  out[id] = s;
+}
+__global__ void scatter_taps_kernel(const float* __restrict__ dout, float* __restrict__ din, const int32_t* __restrict__ idx,
+                                    const float* __restrict__ w, int n_out, int taps, int D) {
+  int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (int64_t)n_out * D) return;
+  int d = (int)(id % D), i = (int)(id / D);
+  float g = dout[id];
+  for (int t = 0; t < taps; ++t) atomicAdd(din + (int64_t)idx[i * taps + t] * D + d, w[i * taps + t] * g);
+}
+
+inline int grid_for(int64_t work_items) { return (int)std::min<int64_t>(ceil_div64(work_items, 256), 256 * 16); }
+
+}  // namespace
+
+extern "C" int ph_patchify(const float* img, void* col, int B, int C, int R, int p, int Kp, hipStream_t stream) {
+  PH_CHECK_ARG(img && col && B > 0 && R % p == 0 && Kp >= C * p * p && Kp % 8 == 0, "ph_patchify: bad args");
+  int g = R / p;
+  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((int64_t)B * g * g * (Kp / 2))), dim3(256), 0, stream, img, (bf16*)col, B, C, R, p, Kp);
+  PH_LAUNCH_CHECK("patchify_kernel");
+  return PH_OK;
+}
+
+extern "C" int ph_resize_bilinear_nchw_to_nhwc(const float* x, void* y, int B, int C, int Hin, int Win, int Hout, int Wout,
+                                               hipStream_t stream) {
+  PH_CHECK_ARG(x && y && B > 0 && C > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "ph_resize_bilinear: bad args");
+  int64_t blocks = (int64_t)B * Hout * ((C + 7) / 8);
+  PH_CHECK_ARG(blocks < (1ll << 31), "ph_resize_bilinear: grid too large");
+  hipLaunchKernelGGL(resize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, (bf16*)y, B, C, Hin, Win, Hout, Wout);
+  PH_LAUNCH_CHECK("resize_kernel");
+  return PH_OK;
+}
+
+extern "C" int ph_im2col_nhwc(const void* x, void* col, int B, int H, int W, int C, int ksize, int stride, int Kp,
+                              const float* bn_scale, const float* bn_shift, hipStream_t stream) {
+  PH_CHECK_ARG(x && col && (ksize == 1 || ksize == 3) && stride >= 1 && Kp >= ksize * ksize * C && Kp % 8 == 0, "ph_im2col_nhwc: bad args");
+  PH_CHECK_ARG((bn_scale == nullptr) == (bn_shift == nullptr), "ph_im2col_nhwc: scale/shift must come together");
+  int pad = ksize / 2;
+  int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+  if (C % 8 == 0) {
+    hipLaunchKernelGGL(im2col_kernel<true>, dim3(grid_for((int64_t)B * Ho * Wo * (Kp / 8))), dim3(256), 0, stream, (const bf16*)x,
+                       (bf16*)col, B, H, W, C, ksize, stride, Kp, Ho, Wo, bn_scale, bn_shift);
+  } else {
+    hipLaunchKernelGGL(im2col_kernel<false>, dim3(grid_for((int64_t)B * Ho * Wo * Kp)), dim3(256), 0, stream, (const bf16*)x,
+                       (bf16*)col, B, H, W, C, ksize, stride, Kp, Ho, Wo, bn_scale, bn_shift);
+  }
+  PH_LAUNCH_CHECK("im2col_kernel");
+  return PH_OK;
+}
+
+extern "C" int ph_col2im_nhwc(const void* dcol, void* dx, int B, int H, int W, int C, int ksize, int stride, int Kp,
+                              hipStream_t stream) {
+  PH_CHECK_ARG(dcol && dx && (ksize == 1 || ksize == 3) && C % 8 == 0 && Kp >= ksize * ksize * C, "ph_col2im_nhwc: bad args");
+  int pad = ksize / 2;
+  int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
+  hipLaunchKernelGGL(col2im_kernel, dim3(grid_for((int64_t)B * H * W * (C / 8))), dim3(256), 0, stream, (const bf16*)dcol, (bf16*)dx, B,
+                     H, W, C, ksize, stride, Kp, Ho, Wo);
+  PH_LAUNCH_CHECK("col2im_kernel");
+  return PH_OK;
+}
+
+extern "C" int ph_bn_stats(const void* y, int M, int C, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float momentum, float eps, int training, float* mean, float* rstd, float* scale,
+                           float* shift, hipStream_t stream) {
+  PH_CHECK_ARG(gamma && beta && running_mean && running_var && mean && rstd && scale && shift, "ph_bn_stats: null pointer");
+  PH_CHECK_ARG(C % 8 == 0 && C <= 2048 && M > 0, "ph_bn_stats: C=%d unsupported", C);
+  float* sums = scale;   // scale/shift double as the [2*C] reduction scratch when they are contiguous; otherwise use mean/rstd
+  // we need 2*C contiguous floats: require shift == scale + C (the host allocates the four vectors as one block)
+  PH_CHECK_ARG(shift == scale + C, "ph_bn_stats: scale/shift must be one contiguous [2*C] block");
+  if (training) {
+    PH_CHECK_ARG(y, "ph_bn_stats: null y");
+    (void)hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, stream);
+    int rpp = 256 / (C / 8);
+    int grid = (int)std::min<int64_t>(ceil_div64(M, (int64_t)rpp * 8), 1024);
+    hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(grid), dim3(256), sizeof(float) * 2 * C, stream, (const bf16*)y, (const bf16*)nullptr, M,
+                       C, nullptr, nullptr, nullptr, nullptr, sums);
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, stream, sums, M, C, gamma, beta, running_mean, running_var,
+                     momentum, eps, training, mean, rstd, scale, shift);
+  PH_LAUNCH_CHECK("bn_stats kernels");
+  return PH_OK;
+}
+
+extern "C" int ph_bn_relu_bwd(const void* da, const void* y, void* dy, int M, int C, const float* gamma, const float* beta,
+                              const float* mean, const float* rstd, float* dgamma, float* dbeta, float* sums,
+                              hipStream_t stream) {
+  PH_CHECK_ARG(da && y && dy && gamma && beta && mean && rstd && sums, "ph_bn_relu_bwd: null pointer");
+  PH_CHECK_ARG(C % 8 == 0 && C <= 2048 && M > 0, "ph_bn_relu_bwd: C=%d unsupported", C);
+  (void)hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, stream);
+  int rpp = 256 / (C / 8);
+  int grid = (int)std::min<int64_t>(ceil_div64(M, (int64_t)rpp * 8), 1024);
+  hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(grid), dim3(256), sizeof(float) * 2 * C, stream, (const bf16*)y, (const bf16*)da, M, C, mean,
+                     rstd, gamma, beta, sums);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((int64_t)M * (C / 8))), dim3(256), 0, stream, (const bf16*)da, (const bf16*)y,
+                     (bf16*)dy, (int64_t)M, C, gamma, beta, mean, rstd, sums, dgamma, dbeta);
+  PH_LAUNCH_CHECK("bn_relu_bwd kernels");
+  return PH_OK;
+}
+
+extern "C" int ph_tokens_finalize(const void* feat, const float* pos, void* tokens, int B, int G, int D, int tok_per_batch,
+                                  int tok_off, const int64_t* inst, int E, int g, const int32_t* table, const float* inst_emb,
+                                  hipStream_t stream) {
+  PH_CHECK_ARG(feat && pos && tokens && D % 4 == 0 && g * g == G, "ph_tokens_finalize: bad args");
+  PH_CHECK_ARG(!inst || (table && inst_emb && E > 0), "ph_tokens_finalize: instance inputs incomplete");
+  hipLaunchKernelGGL(tokens_kernel, dim3(grid_for((int64_t)B * G * (D / 4))), dim3(256), 0, stream, (const bf16*)feat, pos, (bf16*)tokens, B,
+                     G, D, tok_per_batch, tok_off, inst, E, g, table, inst_emb);
+  PH_LAUNCH_CHECK("tokens_kernel");
+  return PH_OK;
+}
+
+extern "C" int ph_tokens_finalize_bwd(const void* dtokens, void* dfeat, float* dpos, int B, int G, int D, int tok_per_batch,
+                                      int tok_off, const int64_t* inst, int E, int g, const int32_t* table, float* dinst_emb,
+                                      hipStream_t stream) {
+  PH_CHECK_ARG(dtokens && D % 4 == 0 && g * g == G, "ph_tokens_finalize_bwd: bad args");
+  hipLaunchKernelGGL(tokens_bwd_kernel, dim3(ceil_div(G * (D / 4), 256)), dim3(256), 0, stream, (const bf16*)dtokens, (bf16*)dfeat, dpos, B, G,
+                     D, tok_per_batch, tok_off, inst, E, g, table, dinst_emb);
+  PH_LAUNCH_CHECK("tokens_bwd_kernel");
+  return PH_OK;
+}
+
+extern "C" int ph_gather_taps(const float* in, float* out, const int32_t* idx, const float* w, int n_out, int taps, int D,
+                              hipStream_t stream) {
+  PH_CHECK_ARG(in && out && idx && w, "ph_gather_taps: null pointer");
+  hipLaunchKernelGGL(gather_taps_kernel, dim3((unsigned)ceil_div64((int64_t)n_out * D, 256)), dim3(256), 0, stream, in, out, idx, w, n_out, taps, D);
+  PH_LAUNCH_CHECK("gather_taps_kernel");
+  return PH_OK;
+}
+extern "C" int ph_scatter_taps(const float* dout, float* din, const int32_t* idx, const float* w, int n_out, int taps, int D,
+                               hipStream_t stream) {
+  PH_CHECK_ARG(dout && din && idx && w, "ph_scatter_taps: null pointer");
+  hipLaunchKernelGGL(scatter_taps_kernel, dim3((unsigned)ceil_div64((int64_t)n_out * D, 256)), dim3(256), 0, stream, dout, din, idx, w, n_out, taps, D);
+  PH_LAUNCH_CHECK("scatter_taps_kernel");
+  return PH_OK;
+}

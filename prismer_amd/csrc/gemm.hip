@@ -1,0 +1,350 @@
+// bf16 MFMA GEMM with fused epilogue for gfx950 (CDNA4).
+//
+//   C[M,N] = epilogue( alpha * sum_k opA[m,k] * opB[n,k] )
+//
+// Replaces every nn.Linear / conv-as-GEMM contraction on the Prismer hot path:
+//   forward   x[M,K] . W[N,K]^T            (both K-contiguous)               -> trans_a=0, trans_b=0
+//   dgrad     dY[M,N'] . W[N',K']          (W stored [red][out])             -> trans_a=0, trans_b=1
+//   wgrad     dY[M',N]^T . X[M',K]         (both stored [red][out])          -> trans_a=1, trans_b=1
+// reference call sites: vit.py:41-47,53 (ViT), resampler.py:18-24, utils.py:50-56 (Adaptor),
+// roberta.py:86-92,134,163,177,415-421 (decoder), vit.py:86-120 (convs lowered to im2col GEMMs).
+//
+// Design (wave64, MFMA 32x32x16 bf16, fp32 accumulate):
+//   * block = 256 threads = 4 waves in a 2x2 grid; block tile BMxBN (128x128 or 64x64), BK = 64.
+//   * operands are staged global -> VGPR -> LDS, double-buffered: the loads of k-tile t+1 are issued before
+//     the MFMAs of tile t and written to the other LDS buffer after them (one barrier per k-tile).
+//   * K-contiguous operand: LDS image [rows][64] bf16 (128 B rows), 16-B chunk index XOR-swizzled with
+//     (row>>1)&7 so that the ds_read_b128 fragment reads of a 16-lane group hit 16 distinct 16-B slots.
+//   * K-strided operand (stored [K][rows]): LDS image [64][rows] with a 64-B row pad, fragments fetched with
+//     the gfx950 transposing LDS read ds_read_b64_tr_b16 (two per 8-element fragment).
+//   * the MFMA is issued as D = W_frag x X_frag so each lane ends with 4 CONSECUTIVE n for one m:
+//     epilogue stores are 8-B (bf16) / 16-B (fp32) vectors along n.
+//   * split-K (grid.z) with fp32 atomics for the tall-skinny weight-gradient GEMMs.
+//   * block ids are remapped so that consecutive tiles along N share an XCD (and its L2 copy of the A panel).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int KC_ROW_BYTES = BK * 2;   // K-contiguous image: 128 B per row
+
+template <int R>
+struct TileBytes {
+  static constexpr int kc = R * KC_ROW_BYTES;          // K-contiguous image
+  static constexpr int ks_stride = R * 2 + 64;         // K-strided image: bytes per k-row (64-B pad)
+  static constexpr int ks = BK * ks_stride;
+  static constexpr int max = ks > kc ? ks : kc;
+};
+
+struct GemmParams {
+  const bf16* A; const bf16* B; void* C;
+  int M, N, K, lda, ldb, ldc;
+  const float* bias;
+  bf16* pre_out;
+  const bf16* act_in; int ld_act;
+  const bf16* residual; int ldr;
+  float drop_p; const uint64_t* drop_seed; uint32_t drop_stream;
+  int act, out_f32, accumulate;
+  float alpha;
+  int k_tiles_per_split;   // in units of BK
+  int tiles_m, tiles_n;
+};
+
+// ---- global -> register staging ------------------------------------------------------------------------
+// K-contiguous operand: tile = R rows x 64 k. chunk id -> (row = id/8, c = id%8), 16 B each.
+template <int R>
+__device__ __forceinline__ void load_kc(const bf16* __restrict__ base, int ld, int row0, int rows, int k0, int K,
+                                        u32x4 (&regs)[R * 8 / 256]) {
+#pragma unroll
+  for (int i = 0; i < R * 8 / 256; ++i) {
+    int id = threadIdx.x + 256 * i;
+    int r = id >> 3, c = id & 7;
+    int row = row0 + r;
+    row = row < rows ? row : rows - 1;          // clamp: out-of-range rows only feed out-of-range outputs
+    int k = k0 + c * 8;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (k < K) v = *reinterpret_cast<const u32x4*>(base + (size_t)row * ld + k);
+    regs[i] = v;
+  }
+}
+template <int R>
+__device__ __forceinline__ void store_kc(char* lds, const u32x4 (&regs)[R * 8 / 256]) {
+#pragma unroll
+  for (int i = 0; i < R * 8 / 256; ++i) {
+    int id = threadIdx.x + 256 * i;
+    int r = id >> 3, c = id & 7;
+    int cs = c ^ ((r >> 1) & 7);
+    *reinterpret_cast<u32x4*>(lds + r * KC_ROW_BYTES + cs * 16) = regs[i];
+  }
+}
+// K-strided operand: memory [K][rows] (rows contiguous). tile = 64 k-rows x R. chunk id -> (kr = id/(R/8), c = id%(R/8)).
+template <int R>
+__device__ __forceinline__ void load_ks(const bf16* __restrict__ base, int ld, int row0, int rows, int k0, int K,
+                                        u32x4 (&regs)[R * 8 / 256]) {
+  constexpr int CPR = R / 8;
+#pragma unroll
+  for (int i = 0; i < R * 8 / 256; ++i) {
+    int id = threadIdx.x + 256 * i;
+    int kr = id / CPR, c = id % CPR;
+    int k = k0 + kr;
+    int r = row0 + c * 8;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (k < K && r < rows) v = *reinterpret_cast<const u32x4*>(base + (size_t)k * ld + r);
+    regs[i] = v;
+  }
+}
+template <int R>
+__device__ __forceinline__ void store_ks(char* lds, const u32x4 (&regs)[R * 8 / 256]) {
+  constexpr int CPR = R / 8;
+#pragma unroll
+  for (int i = 0; i < R * 8 / 256; ++i) {
+    int id = threadIdx.x + 256 * i;
+    int kr = id / CPR, c = id % CPR;
+    *reinterpret_cast<u32x4*>(lds + kr * TileBytes<R>::ks_stride + c * 16) = regs[i];
+  }
+}
+
+// ---- LDS -> MFMA fragment ------------------------------------------------------------------------------
+// 32x32x16 operand fragment: lane l holds 8 consecutive k for row (l & 31), k-half (l >> 5).
+__device__ __forceinline__ bf16x8 frag_kc(const char* lds, int rbase, int kk, int lane) {
+  int r = rbase + (lane & 31);
+  int c = kk * 2 + (lane >> 5);
+  int cs = c ^ ((r >> 1) & 7);
+  return *reinterpret_cast<const bf16x8*>(lds + r * KC_ROW_BYTES + cs * 16);
+}
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+template <int R>
+__device__ __forceinline__ bf16x8 frag_ks(const char* lds, int rbase, int kk, int lane) {
+  // ds_read_b64_tr_b16: within a 16-lane group, source lane (4j+q) supplies 4 consecutive row-elements of
+  // k-row j; result lane c receives element j = T[k_j][rows 4*(c/4).. + c%4] i.e. column c of the 4x16 block.
+  int g = lane >> 4, i = lane & 15, j = i >> 2, q = i & 3;
+  int k = kk * 16 + (g >> 1) * 8 + j;
+  int r = rbase + (g & 1) * 16 + q * 4;
+  const char* p = lds + k * TileBytes<R>::ks_stride + r * 2;
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * TileBytes<R>::ks_stride));
+  bf16x8 o;
+  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+  o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+  return o;
+}
+
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+  constexpr int WM = BM / 2, WN = BN / 2;   // wave tile
+  constexpr int TM = WM / 32, TN = WN / 32; // 32x32 MFMA tiles per wave
+  constexpr int A_BYTES = TA ? TileBytes<BM>::ks : TileBytes<BM>::kc;
+  constexpr int B_BYTES = TB ? TileBytes<BN>::ks : TileBytes<BN>::kc;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = A_BYTES + B_BYTES;   // stage s: A image at smem + s*STAGE, B image right behind it
+
+  // XCD-aware tile mapping: hardware places block b on XCD b % 8; give each XCD a contiguous run of tiles.
+  int nt = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    int q = nt / 8, r = nt % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tm = bid / p.tiles_n, tn = bid % p.tiles_n;
+  int m0 = tm * BM, n0 = tn * BN;
+  int kt_begin = blockIdx.z * p.k_tiles_per_split;
+  int kt_total = (p.K + BK - 1) / BK;
+  int kt_end = min(kt_begin + p.k_tiles_per_split, kt_total);
+  if (kt_begin >= kt_end) return;
+
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int wm = wave >> 1, wn = wave & 1;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  u32x4 ra[BM * 8 / 256], rb[BN * 8 / 256];
+  auto gload = [&](int kt) {
+    int k0 = kt * BK;
+    if (TA) load_ks<BM>(p.A, p.lda, m0, p.M, k0, p.K, ra); else load_kc<BM>(p.A, p.lda, m0, p.M, k0, p.K, ra);
+    if (TB) load_ks<BN>(p.B, p.ldb, n0, p.N, k0, p.K, rb); else load_kc<BN>(p.B, p.ldb, n0, p.N, k0, p.K, rb);
+  };
+  auto lstore = [&](int buf) {
+    char* sa = smem + buf * STAGE;
+    char* sb = sa + A_BYTES;
+    if (TA) store_ks<BM>(sa, ra); else store_kc<BM>(sa, ra);
+    if (TB) store_ks<BN>(sb, rb); else store_kc<BN>(sb, rb);
+  };
+
+  gload(kt_begin);
+  lstore(0);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    bool more = kt + 1 < kt_end;
+    if (more) gload(kt + 1);
+    const char* la = smem + cur * STAGE;
+    const char* lb = la + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8 fx[TM], fw[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fx[i] = TA ? frag_ks<BM>(la, wm * WM + i * 32, kk, lane) : frag_kc(la, wm * WM + i * 32, kk, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fw[j] = TB ? frag_ks<BN>(lb, wn * WN + j * 32, kk, lane) : frag_kc(lb, wn * WN + j * 32, kk, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fx[i], acc[i][j], 0, 0, 0);
+    }
+    if (more) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: lane holds, for tile (i,j): m = l&31 ; n = 8*(r>>2) + 4*(l>>5) + (r&3) -------------------
+  const bool splitk = gridDim.z > 1;
+  DropCtx dc;
+  const bool drop = p.drop_p > 0.0f;
+  if (drop) dc = make_drop(p.drop_seed, p.drop_stream, p.drop_p);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    int m = m0 + wm * WM + i * 32 + (lane & 31);
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        int n = n0 + wn * WN + j * 32 + g * 8 + (lane >> 5) * 4;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e] * p.alpha;
+        bool full = (n + 4 <= p.N);
+        if (splitk) {   // raw fp32 atomics; bias / activation are not allowed with split-K (checked on host)
+          float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) atomicAdd(c + e, v[e]);
+          continue;
+        }
+        if (p.bias) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += p.bias[min(n + e, p.N - 1)];
+        }
+        if (p.pre_out) {
+          bf16* q = p.pre_out + (size_t)m * p.ldc + n;
+          if (full) { bf16x4 t = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *reinterpret_cast<bf16x4*>(q) = t; }
+          else { for (int e = 0; e < 4; ++e) if (n + e < p.N) q[e] = f2bf(v[e]); }
+        }
+        if (p.act_in) {       // backward through an activation: multiply by act'(saved pre-activation)
+          const bf16* q = p.act_in + (size_t)m * p.ld_act + n;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= act_grad(p.act, bf2f(q[min(e, p.N - 1 - n)]));
+        } else if (p.act != PH_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = act_fwd(p.act, v[e]);
+        }
+        if (drop) {           // element index m*N+n ; N % 4 == 0 is required with dropout (checked on host)
+          u32x4 r = drop_rand4(dc, ((uint64_t)m * (uint64_t)p.N + (uint64_t)n) >> 2);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = drop_apply(dc, r[e], v[e]);
+        }
+        if (p.residual) {
+          const bf16* q = p.residual + (size_t)m * p.ldr + n;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bf2f(q[min(e, p.N - 1 - n)]);
+        }
+        if (p.out_f32) {
+          float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+          if (p.accumulate) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += c[e];
+          }
+          if (full && ((p.ldc & 3) == 0)) { f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(c) = t; }
+          else { for (int e = 0; e < 4; ++e) if (n + e < p.N) c[e] = v[e]; }
+        } else {
+          bf16* c = reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n;
+          if (p.accumulate) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += bf2f(c[e]);
+          }
+          if (full && ((p.ldc & 3) == 0)) { bf16x4 t = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *reinterpret_cast<bf16x4*>(c) = t; }
+          else { for (int e = 0; e < 4; ++e) if (n + e < p.N) c[e] = f2bf(v[e]); }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, bool TA, bool TB>
+int launch(const GemmParams& p, int splits, hipStream_t s) {
+  constexpr int smem = 2 * ((TA ? TileBytes<BM>::ks : TileBytes<BM>::kc) + (TB ? TileBytes<BN>::ks : TileBytes<BN>::kc));
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, TA, TB>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, TA, TB>), grid, dim3(256), smem, s, p);
+  PH_LAUNCH_CHECK("gemm_kernel");
+  return PH_OK;
+}
+
+template <int BM, int BN>
+int dispatch_layout(const GemmParams& p, int ta, int tb, int splits, hipStream_t s) {
+  if (!ta && !tb) return launch<BM, BN, false, false>(p, splits, s);
+  if (!ta && tb) return launch<BM, BN, false, true>(p, splits, s);
+  if (ta && tb) return launch<BM, BN, true, true>(p, splits, s);
+  return launch<BM, BN, true, false>(p, splits, s);
+}
+
+}  // namespace
+
+extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
+  PH_CHECK_ARG(a && a->A && a->B && a->C, "ph_gemm_bf16: null pointer");
+  PH_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "ph_gemm_bf16: bad dims M=%d N=%d K=%d", a->M, a->N, a->K);
+  PH_CHECK_ARG((a->lda % 8) == 0 && (a->ldb % 8) == 0, "ph_gemm_bf16: lda/ldb must be multiples of 8 (16-B rows)");
+  PH_CHECK_ARG((((uintptr_t)a->A | (uintptr_t)a->B) & 15) == 0, "ph_gemm_bf16: A/B must be 16-B aligned");
+  PH_CHECK_ARG(a->trans_a || a->trans_b || (a->K % 8) == 0, "ph_gemm_bf16: K %% 8 != 0 needs a K-strided operand");
+  PH_CHECK_ARG(a->lda >= (a->trans_a ? a->M : a->K) && a->ldb >= (a->trans_b ? a->N : a->K) && a->ldc >= a->N,
+               "ph_gemm_bf16: leading dimension too small");
+  PH_CHECK_ARG(!(a->drop_p > 0.0f) || ((a->N % 4) == 0 && a->drop_seed), "ph_gemm_bf16: dropout needs N %% 4 == 0 and a seed");
+  PH_CHECK_ARG(a->drop_p >= 0.0f && a->drop_p < 1.0f, "ph_gemm_bf16: bad dropout p");
+
+  GemmParams p;
+  p.A = (const bf16*)a->A; p.B = (const bf16*)a->B; p.C = a->C;
+  p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc;
+  p.bias = a->bias; p.pre_out = (bf16*)a->pre_out; p.act_in = (const bf16*)a->act_in; p.ld_act = a->ld_act;
+  p.residual = (const bf16*)a->residual; p.ldr = a->ldr;
+  p.drop_p = a->drop_p; p.drop_seed = a->drop_seed; p.drop_stream = a->drop_stream;
+  p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.alpha = a->alpha;
+
+  bool small = ((int64_t)ceil_div(a->M, 128) * ceil_div(a->N, 128) < 128) || a->M <= 64 || a->N <= 64;
+  int BM = small ? 64 : 128;
+  p.tiles_m = ceil_div(a->M, BM); p.tiles_n = ceil_div(a->N, BM);
+  int kt = ceil_div(a->K, BK);
+  int splits = a->split_k;
+  int tiles = p.tiles_m * p.tiles_n;
+  bool plain = !a->bias && !a->pre_out && !a->act_in && a->act == PH_ACT_NONE && !a->residual && !(a->drop_p > 0.0f) &&
+               a->out_f32 && a->accumulate;
+  if (splits <= 0) {   // auto: split only accumulate-into-fp32 GEMMs (weight gradients) that under-fill the chip
+    splits = 1;
+    if (plain && tiles < 256 && kt >= 8) {
+      splits = min(min(ceil_div(512, tiles), kt / 4), 32);
+      if (splits < 1) splits = 1;
+    }
+  }
+  PH_CHECK_ARG(splits == 1 || plain, "ph_gemm_bf16: split_k > 1 needs out_f32 + accumulate and no fused epilogue");
+  p.k_tiles_per_split = ceil_div(kt, splits);
+  splits = ceil_div(kt, p.k_tiles_per_split);
+  if (small) return dispatch_layout<64, 64>(p, a->trans_a, a->trans_b, splits, stream);
+  return dispatch_layout<128, 128>(p, a->trans_a, a->trans_b, splits, stream);
+}

@@ -1,0 +1,184 @@
+// LayerNorm forward / backward (fp32 math on bf16 rows) for gfx950.
+// Replaces model/modules/utils.py:14-19 (fp32 F.layer_norm + casts) and its autograd.
+// One 64-lane wave owns one row: the row lives in registers (8-B bf16x4 loads, D/4 chunks spread over the
+// lanes), mean / variance are two wave-shuffle reductions, nothing goes through LDS.  HBM-bound:
+// algorithmic bytes per row = 2*D (read) + 2*D (write) forward.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_CH = 8;   // chunks of 4 elements per lane -> D <= 2048
+
+__device__ __forceinline__ int map_row(const ph_rowmap& m, int r) {
+  return m.seg_in ? (r / m.seg_in) * m.seg_out + m.seg_off + (r % m.seg_in) : r;
+}
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(ph_layernorm_fwd_args a) {
+  int lane = threadIdx.x & 63;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.M) return;
+  const int nch = a.D >> 2;
+  const bf16* x = reinterpret_cast<const bf16*>(a.x) + (size_t)row * a.D;
+  float v[MAX_CH][4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAX_CH; ++i) {
+    int c = lane + 64 * i;
+    if (c < nch) {
+      bf16x4 t = *reinterpret_cast<const bf16x4*>(x + c * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[i][e] = bf2f(t[e]); s += v[i][e]; }
+    }
+  }
+  float mean = wave_sum(s) / (float)a.D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAX_CH; ++i) {
+    int c = lane + 64 * i;
+    if (c < nch) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { float d = v[i][e] - mean; q += d * d; }
+    }
+  }
+  float rstd = rsqrtf(wave_sum(q) / (float)a.D + a.eps);
+  if (lane == 0) {
+    if (a.mean) a.mean[row] = mean;
+    if (a.rstd) a.rstd[row] = rstd;
+  }
+  bf16* y = reinterpret_cast<bf16*>(a.y) + (size_t)map_row(a.y_map, row) * a.D;
+  bf16* y2 = a.y2 ? reinterpret_cast<bf16*>(a.y2) + (size_t)map_row(a.y2_map, row) * a.D : nullptr;
+#pragma unroll
+  for (int i = 0; i < MAX_CH; ++i) {
+    int c = lane + 64 * i;
+    if (c < nch) {
+      f32x4 g = *reinterpret_cast<const f32x4*>(a.gamma + c * 4);
+      f32x4 b = *reinterpret_cast<const f32x4*>(a.beta + c * 4);
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = f2bf((v[i][e] - mean) * rstd * g[e] + b[e]);
+      *reinterpret_cast<bf16x4*>(y + c * 4) = o;
+      if (y2) *reinterpret_cast<bf16x4*>(y2 + c * 4) = o;
+    }
+  }
+}
+
+// Backward.  Each wave walks rows (grid-stride) keeping its dgamma / dbeta partials in registers; the block
+// folds its 4 waves through LDS and issues one fp32 atomic per column.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(ph_layernorm_bwd_args a) {
+  __shared__ float red_flat[2 * 4 * 512];   // [dgamma|dbeta][wave][512 columns]: 16 KB, D is folded in passes of 512
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = a.D >> 2;
+  float dg[MAX_CH][4], db[MAX_CH][4];
+#pragma unroll
+  for (int i = 0; i < MAX_CH; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
+  DropCtx dc;
+  const bool drop = a.dx_drop && a.drop_p > 0.f;
+  if (drop) dc = make_drop(a.drop_seed, a.drop_stream, a.drop_p);
+
+  for (int row = blockIdx.x * 4 + wave; row < a.M; row += gridDim.x * 4) {
+    const bf16* x = reinterpret_cast<const bf16*>(a.x) + (size_t)row * a.D;
+    const bf16* dy = reinterpret_cast<const bf16*>(a.dy) + (size_t)map_row(a.dy_map, row) * a.D;
+    const bf16* dy2 = a.dy2 ? reinterpret_cast<const bf16*>(a.dy2) + (size_t)map_row(a.dy2_map, row) * a.D : nullptr;
+    float mean = a.mean[row], rstd = a.rstd[row];
+    float xh[MAX_CH][4], g[MAX_CH][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_CH; ++i) {
+      int c = lane + 64 * i;
+      if (c < nch) {
+        bf16x4 tx = *reinterpret_cast<const bf16x4*>(x + c * 4);
+        bf16x4 td = *reinterpret_cast<const bf16x4*>(dy + c * 4);
+        f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + c * 4);
+        bf16x4 td2;
+        if (dy2) td2 = *reinterpret_cast<const bf16x4*>(dy2 + c * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float d = bf2f(td[e]);
+          if (dy2) d += bf2f(td2[e]);
+          xh[i][e] = (bf2f(tx[e]) - mean) * rstd;
+          dg[i][e] += d * xh[i][e];
+          db[i][e] += d;
+          g[i][e] = d * gm[e];
+          s1 += g[i][e];
+          s2 += g[i][e] * xh[i][e];
+        }
+      }
+    }
+    float m1 = wave_sum(s1) / (float)a.D, m2 = wave_sum(s2) / (float)a.D;
+    bf16* dx = reinterpret_cast<bf16*>(a.dx) + (size_t)row * a.D;
+    const bf16* dsk = a.dskip ? reinterpret_cast<const bf16*>(a.dskip) + (size_t)row * a.D : nullptr;
+    bf16* dxd = drop ? reinterpret_cast<bf16*>(a.dx_drop) + (size_t)row * a.D : nullptr;
+#pragma unroll
+    for (int i = 0; i < MAX_CH; ++i) {
+      int c = lane + 64 * i;
+      if (c < nch) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rstd * (g[i][e] - m1 - xh[i][e] * m2);
+        if (dsk) {
+          bf16x4 t = *reinterpret_cast<const bf16x4*>(dsk + c * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] += bf2f(t[e]);
+        }
+        bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+        *reinterpret_cast<bf16x4*>(dx + c * 4) = ob;
+        if (drop) {
+          u32x4 r = drop_rand4(dc, ((uint64_t)row * (uint64_t)a.D + (uint64_t)c * 4) >> 2);
+          bf16x4 od = {f2bf(drop_apply(dc, r[0], o[0])), f2bf(drop_apply(dc, r[1], o[1])),
+                       f2bf(drop_apply(dc, r[2], o[2])), f2bf(drop_apply(dc, r[3], o[3]))};
+          *reinterpret_cast<bf16x4*>(dxd + c * 4) = od;
+        }
+      }
+    }
+  }
+  if (!a.dgamma && !a.dbeta) return;
+  // fold the 4 waves: column passes of 512 columns (128 chunks) to keep LDS at 16 KB
+  for (int pass = 0; pass < (a.D + 511) / 512; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MAX_CH; ++i) {
+      int c = lane + 64 * i;
+      int cl = c - pass * 128;
+      if (c < nch && cl >= 0 && cl < 128) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          red_flat[(0 * 4 + wave) * 512 + cl * 4 + e] = dg[i][e];
+          red_flat[(1 * 4 + wave) * 512 + cl * 4 + e] = db[i][e];
+        }
+      }
+    }
+    __syncthreads();
+    for (int col = threadIdx.x; col < 512; col += 256) {
+      int gc = pass * 512 + col;
+      if (gc < a.D) {
+        float sg = 0.f, sb = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { sg += red_flat[(0 * 4 + w) * 512 + col]; sb += red_flat[(1 * 4 + w) * 512 + col]; }
+        if (a.dgamma) atomicAdd(a.dgamma + gc, sg);
+        if (a.dbeta) atomicAdd(a.dbeta + gc, sb);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int ph_layernorm_fwd(const ph_layernorm_fwd_args* a, hipStream_t stream) {
+  PH_CHECK_ARG(a && a->x && a->y && a->gamma && a->beta, "ph_layernorm_fwd: null pointer");
+  PH_CHECK_ARG(a->M > 0 && a->D > 0 && (a->D % 4) == 0 && a->D <= MAX_CH * 256, "ph_layernorm_fwd: D=%d unsupported (need D%%4==0, D<=%d)", a->D, MAX_CH * 256);
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(a->M, 4)), dim3(256), 0, stream, *a);
+  PH_LAUNCH_CHECK("ln_fwd_kernel");
+  return PH_OK;
+}
+
+extern "C" int ph_layernorm_bwd(const ph_layernorm_bwd_args* a, hipStream_t stream) {
+  PH_CHECK_ARG(a && a->dy && a->x && a->mean && a->rstd && a->gamma && a->dx, "ph_layernorm_bwd: null pointer");
+  PH_CHECK_ARG(a->M > 0 && a->D > 0 && (a->D % 4) == 0 && a->D <= MAX_CH * 256, "ph_layernorm_bwd: D=%d unsupported", a->D);
+  PH_CHECK_ARG(!a->dx_drop || !(a->drop_p > 0.f) || a->drop_seed, "ph_layernorm_bwd: dropout needs a seed");
+  int grid = min(ceil_div(a->M, 4), 512);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, stream, *a);
+  PH_LAUNCH_CHECK("ln_bwd_kernel");
+  return PH_OK;
+}

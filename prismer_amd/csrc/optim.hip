@@ -1,0 +1,249 @@
+// Optimizer + small HBM-bound utilities for gfx950.
+// AdamW replaces torch.optim.AdamW (reference: train_caption.py:111-112,133); the rest are the glue kernels of
+// the layer programs (bias gradients, casts, strided row copies, conv-weight layout changes).
+#include "common.h"
+
+namespace {
+
+// torch.optim.AdamW:  p *= 1 - lr*wd ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+//                     p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+// HBM-bound: 16 B read + 14 B written per parameter.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16* __restrict__ pb, int64_t n, const float* __restrict__ hyper,
+                                                    float b1, float b2, float eps, float wd, float gscale) {
+  const float lr = hyper[0], bc1 = hyper[1], bc2 = hyper[2];
+  const float step = lr / bc1, rbc2 = rsqrtf(bc2), decay = 1.f - lr * wd;
+  int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 tp = reinterpret_cast<f32x4*>(p)[i], tg = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 tm = reinterpret_cast<f32x4*>(m)[i], tv = reinterpret_cast<f32x4*>(v)[i];
+    bf16x4 ob;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gg = tg[e] * gscale;
+      float pp = tp[e] * decay;
+      tm[e] = b1 * tm[e] + (1.f - b1) * gg;
+      tv[e] = b2 * tv[e] + (1.f - b2) * gg * gg;
+      pp -= step * tm[e] / (sqrtf(tv[e]) * rbc2 + eps);
+      tp[e] = pp;
+      ob[e] = f2bf(pp);
+    }
+    reinterpret_cast<f32x4*>(p)[i] = tp;
+    reinterpret_cast<f32x4*>(m)[i] = tm;
+    reinterpret_cast<f32x4*>(v)[i] = tv;
+    if (pb) reinterpret_cast<bf16x4*>(pb)[i] = ob;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    int64_t i = (n4 << 2) + threadIdx.x;
+    float gg = g[i] * gscale, pp = p[i] * decay;
+    float mm = b1 * m[i] + (1.f - b1) * gg, vv = b2 * v[i] + (1.f - b2) * gg * gg;
+    pp -= step * mm / (sqrtf(vv) * rbc2 + eps);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+    if (pb) pb[i] = f2bf(pp);
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_f2b_kernel(const float* __restrict__ x, bf16* __restrict__ y, int64_t n) {
+  int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 t = reinterpret_cast<const f32x4*>(x)[i];
+    bf16x4 o = {f2bf(t[0]), f2bf(t[1]), f2bf(t[2]), f2bf(t[3])};
+    reinterpret_cast<bf16x4*>(y)[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { int64_t i = (n4 << 2) + threadIdx.x; y[i] = f2bf(x[i]); }
+}
+__global__ __launch_bounds__(256) void cast_b2f_kernel(const bf16* __restrict__ x, float* __restrict__ y, int64_t n) {
+  int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    bf16x4 t = reinterpret_cast<const bf16x4*>(x)[i];
+    f32x4 o = {bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
+    reinterpret_cast<f32x4*>(y)[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { int64_t i = (n4 << 2) + threadIdx.x; y[i] = bf2f(x[i]); }
+}
+__global__ __launch_bounds__(256) void add_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ y, int64_t n) {
+  int64_t n8 = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    bf16x8 ta = reinterpret_cast<const bf16x8*>(a)[i], tb = reinterpret_cast<const bf16x8*>(b)[i], o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(ta[e]) + bf2f(tb[e]));
+    reinterpret_cast<bf16x8*>(y)[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) { int64_t i = (n8 << 3) + threadIdx.x; y[i] = f2bf(bf2f(a[i]) + bf2f(b[i])); }
+}
+
+// out[n] += sum_m x[m][n] : each block owns a 64-row strip, thread t owns columns {t*8 .. t*8+7} mod pass.
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, int M, int N, int ld, float* __restrict__ out) {
+  const int nch = N / 8;
+  for (int c = threadIdx.x; c < nch; c += 256) {
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int r = blockIdx.x; r < M; r += gridDim.x) {
+      bf16x8 t = *reinterpret_cast<const bf16x8*>(x + (int64_t)r * ld + c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += bf2f(t[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(out + c * 8 + e, acc[e]);
+  }
+  for (int n = nch * 8 + threadIdx.x; n < N; n += 256) {   // ragged tail columns
+    float acc = 0.f;
+    for (int r = blockIdx.x; r < M; r += gridDim.x) acc += bf2f(x[(int64_t)r * ld + n]);
+    atomicAdd(out + n, acc);
+  }
+}
+
+__device__ __forceinline__ int map_row(const ph_rowmap& m, int r) {
+  return m.seg_in ? (r / m.seg_in) * m.seg_out + m.seg_off + (r % m.seg_in) : r;
+}
+__global__ __launch_bounds__(256) void copy_rows_kernel(const bf16* __restrict__ src, int lds_, ph_rowmap smap, bf16* __restrict__ dst, int ldd,
+                                                        ph_rowmap dmap, int rows, int cols, int accumulate) {
+  const int cpr = cols / 8;
+  int64_t total = (int64_t)rows * cpr;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    int c = (int)(id % cpr) * 8, r = (int)(id / cpr);
+    bf16x8 t = *reinterpret_cast<const bf16x8*>(src + (int64_t)map_row(smap, r) * lds_ + c);
+    bf16* d = dst + (int64_t)map_row(dmap, r) * ldd + c;
+    if (accumulate) {
+      bf16x8 o = *reinterpret_cast<const bf16x8*>(d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = f2bf(bf2f(t[e]) + bf2f(o[e]));
+    }
+    *reinterpret_cast<bf16x8*>(d) = t;
+  }
+}
+
+// w[Cout][Cin][ks][ks] fp32  ->  shadow[Cout][Kp] bf16 with column (ky*ks+kx)*Cin + c (zero padded)
+__global__ void conv_w_shadow_kernel(const float* __restrict__ w, bf16* __restrict__ s, int Cout, int Cin, int ks, int Kp) {
+  int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (int64_t)Cout * Kp) return;
+  int k = (int)(id % Kp), o = (int)(id / Kp);
+  float v = 0.f;
+  if (k < ks * ks * Cin) {
+    int tap = k / Cin, c = k % Cin;
+    v = w[((int64_t)o * Cin + c) * ks * ks + tap];
+  }
+  s[id] = f2bf(v);
+}
+__global__ void conv_g_shadow_kernel(const float* __restrict__ ds, float* __restrict__ dw, int Cout, int Cin, int ks, int Kp) {
+  int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int K = ks * ks * Cin;
+  if (id >= (int64_t)Cout * K) return;
+  int k = (int)(id % K), o = (int)(id / K);
+  int tap = k / Cin, c = k % Cin;
+  dw[((int64_t)o * Cin + c) * ks * ks + tap] += ds[(int64_t)o * Kp + k];
+}
+
+__global__ void advance_seed_kernel(uint64_t* seed) {
+  uint64_t z = seed[0] + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  seed[0] = z ^ (z >> 31);
+}
+
+// ---- layout probe: (1) ds_read_b64_tr_b16 semantics, (2) MFMA 16x16x32 and 32x32x16 C layouts -----------
+// in : bf16[64*16] filled by the host with value = index.
+// out[0..255]      : lane l, element j of ONE tr-read with lane-linear addresses (lane l -> element 4*l)
+// out[256..511]    : C of mfma_16x16x32(A=I-like, B) ... see tests/test_kernels_gpu.py for the expectation
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+__global__ void probe_kernel(const bf16* __restrict__ in, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) bf16 lds[1024];
+  int l = threadIdx.x;
+  for (int i = l; i < 1024; i += 64) lds[i] = in[i];
+  __syncthreads();
+  bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(lds + 4 * l));
+  for (int j = 0; j < 4; ++j) out[l * 4 + j] = bf2f(t[j]);
+  // MFMA 16x16x32: A[i][k] = (i == k ? 1 : 0) for k < 16 ; B[k][j] = in[k*16 + j] -> C[i][j] = B[i][j] (i < 16)
+  bf16x8 a, b;
+  for (int j = 0; j < 8; ++j) {
+    int k = (l >> 4) * 8 + j;
+    a[j] = f2bf(((l & 15) == k) ? 1.f : 0.f);
+    b[j] = (k < 16) ? in[k * 16 + (l & 15)] : f2bf(0.f);
+  }
+  f32x4 c = {0.f, 0.f, 0.f, 0.f};
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) out[256 + l * 4 + r] = c[r];
+  // MFMA 32x32x16: A[i][k] = (i == k) (k < 16), B[k][j] = in[k*32 + j]  -> C[i][j] = in[i*32 + j] for i < 16, 0 otherwise
+  bf16x8 a2, b2;
+  for (int j = 0; j < 8; ++j) {
+    int k = (l >> 5) * 8 + j;
+    a2[j] = f2bf(((l & 31) == k) ? 1.f : 0.f);
+    b2[j] = in[k * 32 + (l & 31)];
+  }
+  f32x16 c2;
+  for (int r = 0; r < 16; ++r) c2[r] = 0.f;
+  c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, c2, 0, 0, 0);
+  for (int r = 0; r < 16; ++r) out[512 + l * 16 + r] = c2[r];
+}
+
+inline int grid_for(int64_t work_items) { return (int)std::min<int64_t>(ceil_div64(work_items, 256), 256 * 16); }
+
+}  // namespace
+
+extern "C" int ph_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const float* hyper, float beta1,
+                        float beta2, float eps, float weight_decay, float grad_scale, hipStream_t stream) {
+  PH_CHECK_ARG(p && g && m && v && hyper && n > 0, "ph_adamw: bad args");
+  PH_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && (((uintptr_t)p_bf16) & 7) == 0, "ph_adamw: misaligned");
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, stream, p, g, m, v, (bf16*)p_bf16, n, hyper, beta1, beta2, eps,
+                     weight_decay, grad_scale);
+  PH_LAUNCH_CHECK("adamw_kernel");
+  return PH_OK;
+}
+extern "C" int ph_cast_f32_to_bf16(const float* x, void* y, int64_t n, hipStream_t stream) {
+  PH_CHECK_ARG(x && y && n > 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 7) == 0, "ph_cast_f32_to_bf16: bad args");
+  hipLaunchKernelGGL(cast_f2b_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, stream, x, (bf16*)y, n);
+  PH_LAUNCH_CHECK("cast_f2b_kernel");
+  return PH_OK;
+}
+extern "C" int ph_cast_bf16_to_f32(const void* x, float* y, int64_t n, hipStream_t stream) {
+  PH_CHECK_ARG(x && y && n > 0 && (((uintptr_t)y) & 15) == 0 && (((uintptr_t)x) & 7) == 0, "ph_cast_bf16_to_f32: bad args");
+  hipLaunchKernelGGL(cast_b2f_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, stream, (const bf16*)x, y, n);
+  PH_LAUNCH_CHECK("cast_b2f_kernel");
+  return PH_OK;
+}
+extern "C" int ph_colsum_bf16(const void* x, int M, int N, int ld, float* out, hipStream_t stream) {
+  PH_CHECK_ARG(x && out && M > 0 && N > 0 && ld % 8 == 0 && (((uintptr_t)x) & 15) == 0, "ph_colsum_bf16: bad args");
+  int grid = std::min(M, 256);
+  hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(256), 0, stream, (const bf16*)x, M, N, ld, out);
+  PH_LAUNCH_CHECK("colsum_kernel");
+  return PH_OK;
+}
+extern "C" int ph_add_bf16(const void* a, const void* b, void* y, int64_t n, hipStream_t stream) {
+  PH_CHECK_ARG(a && b && y && n > 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)y)) & 15) == 0, "ph_add_bf16: bad args");
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, stream, (const bf16*)a, (const bf16*)b, (bf16*)y, n);
+  PH_LAUNCH_CHECK("add_kernel");
+  return PH_OK;
+}
+extern "C" int ph_copy_rows_bf16(const void* src, int lds, ph_rowmap src_map, void* dst, int ldd, ph_rowmap dst_map, int rows,
+                                 int cols, int accumulate, hipStream_t stream) {
+  PH_CHECK_ARG(src && dst && rows > 0 && cols > 0 && cols % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0, "ph_copy_rows_bf16: bad args");
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for((int64_t)rows * cols / 8)), dim3(256), 0, stream, (const bf16*)src, lds, src_map,
+                     (bf16*)dst, ldd, dst_map, rows, cols, accumulate);
+  PH_LAUNCH_CHECK("copy_rows_kernel");
+  return PH_OK;
+}
+extern "C" int ph_conv_weight_to_shadow(const float* w, void* shadow, int Cout, int Cin, int ks, int Kp, hipStream_t stream) {
+  PH_CHECK_ARG(w && shadow && Kp >= Cin * ks * ks, "ph_conv_weight_to_shadow: bad args");
+  hipLaunchKernelGGL(conv_w_shadow_kernel, dim3((unsigned)ceil_div64((int64_t)Cout * Kp, 256)), dim3(256), 0, stream, w, (bf16*)shadow, Cout, Cin, ks, Kp);
+  PH_LAUNCH_CHECK("conv_w_shadow_kernel");
+  return PH_OK;
+}
+extern "C" int ph_conv_grad_from_shadow(const float* dshadow, float* dw, int Cout, int Cin, int ks, int Kp, hipStream_t stream) {
+  PH_CHECK_ARG(dshadow && dw && Kp >= Cin * ks * ks, "ph_conv_grad_from_shadow: bad args");
+  hipLaunchKernelGGL(conv_g_shadow_kernel, dim3((unsigned)ceil_div64((int64_t)Cout * Cin * ks * ks, 256)), dim3(256), 0, stream, dshadow, dw, Cout, Cin, ks, Kp);
+  PH_LAUNCH_CHECK("conv_g_shadow_kernel");
+  return PH_OK;
+}
+extern "C" int ph_advance_seed(uint64_t* seed, hipStream_t stream) {
+  PH_CHECK_ARG(seed, "ph_advance_seed: null");
+  hipLaunchKernelGGL(advance_seed_kernel, dim3(1), dim3(1), 0, stream, seed);
+  PH_LAUNCH_CHECK("advance_seed_kernel");
+  return PH_OK;
+}
+extern "C" int ph_probe_layouts(const void* in_bf16, float* out, hipStream_t stream) {
+  PH_CHECK_ARG(in_bf16 && out, "ph_probe_layouts: null");
+  hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, stream, (const bf16*)in_bf16, out);
+  PH_LAUNCH_CHECK("probe_kernel");
+  return PH_OK;
+}

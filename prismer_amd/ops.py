@@ -1,0 +1,322 @@
+"""Tensor-level wrappers over the C ABI (prismer_amd/_lib.py).  torch supplies device memory and the current
+HIP stream; every arithmetic step runs in libprismer_hip.so.  No fallbacks: a missing library fails at import.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_RELU2, IDENT, RowMap, check, lib, ptr)
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Dropout:
+    """Dropout descriptor: probability, device seed tensor (uint64 viewed as int64[1]) and a per-call-site stream id."""
+    __slots__ = ('p', 'seed', 'stream')
+
+    def __init__(self, p, seed, stream):
+        self.p, self.seed, self.stream = float(p), seed, int(stream)
+
+
+NO_DROP = None
+
+
+def gemm(a, b, out=None, *, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, pre_out=None, act_in=None,
+         residual=None, drop=None, out_f32=False, accumulate=False, alpha=1.0, split_k=0, M=None, N=None, K=None):
+    """out[M,N] = epi(alpha * opA . opB^T).  a: [M,K] (or [K,M] if trans_a), b: [N,K] (or [K,N] if trans_b)."""
+    if M is None:
+        M = a.shape[1] if trans_a else a.shape[0]
+    if K is None:
+        K = a.shape[0] if trans_a else a.shape[1]
+    if N is None:
+        N = b.shape[1] if trans_b else b.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=F32 if out_f32 else BF16, device=a.device)
+    g = _lib.GemmArgs()
+    g.A, g.B, g.C = a.data_ptr(), b.data_ptr(), out.data_ptr()
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldb, g.ldc = a.stride(0), b.stride(0), out.stride(0)
+    g.trans_a, g.trans_b = int(trans_a), int(trans_b)
+    g.bias = ptr(bias)
+    g.act = act
+    g.pre_out = ptr(pre_out)
+    g.act_in = ptr(act_in)
+    g.ld_act = act_in.stride(0) if act_in is not None else 0
+    g.residual = ptr(residual)
+    g.ldr = residual.stride(0) if residual is not None else 0
+    if drop is not None and drop.p > 0.0:
+        g.drop_p, g.drop_seed, g.drop_stream = drop.p, drop.seed.data_ptr(), drop.stream
+    else:
+        g.drop_p, g.drop_seed, g.drop_stream = 0.0, None, 0
+    g.out_f32, g.accumulate, g.alpha, g.split_k = int(out_f32), int(accumulate), float(alpha), int(split_k)
+    check(lib.ph_gemm_bf16(C.byref(g), _stream()), 'ph_gemm_bf16')
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5, out=None, out_map=IDENT, out2=None, out2_map=IDENT, save_stats=True):
+    M, D = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    mean = rstd = None
+    if save_stats:
+        stats = torch.empty((2, M), dtype=F32, device=x.device)
+        mean, rstd = stats[0], stats[1]
+    a = _lib.LayerNormFwdArgs(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), out_map, ptr(out2), out2_map,
+                              ptr(mean), ptr(rstd), M, D, eps)
+    check(lib.ph_layernorm_fwd(C.byref(a), _stream()), 'ph_layernorm_fwd')
+    return out, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, *, dy_map=IDENT, dy2=None, dy2_map=IDENT, dskip=None, dgamma=None, dbeta=None,
+                  drop=None, dx=None, dx_drop=None):
+    M, D = x.shape
+    if dx is None:
+        dx = torch.empty_like(x)
+    a = _lib.LayerNormBwdArgs()
+    a.dy, a.dy_map, a.dy2, a.dy2_map = dy.data_ptr(), dy_map, ptr(dy2), dy2_map
+    a.x, a.mean, a.rstd, a.gamma = x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr()
+    a.dskip, a.dx = ptr(dskip), dx.data_ptr()
+    if drop is not None and drop.p > 0.0:
+        if dx_drop is None:
+            dx_drop = torch.empty_like(x)
+        a.dx_drop, a.drop_p, a.drop_seed, a.drop_stream = dx_drop.data_ptr(), drop.p, drop.seed.data_ptr(), drop.stream
+    else:
+        dx_drop = None
+        a.dx_drop, a.drop_p, a.drop_seed, a.drop_stream = None, 0.0, None, 0
+    a.dgamma, a.dbeta, a.M, a.D = ptr(dgamma), ptr(dbeta), M, D
+    check(lib.ph_layernorm_bwd(C.byref(a), _stream()), 'ph_layernorm_bwd')
+    return dx, (dx_drop if dx_drop is not None else dx)
+
+
+def _attn_args(q, k, v, o, B, H, Sq, Sk, dh, strides, scale, key_mask, causal, drop, lse):
+    f = _lib.AttnFwdArgs()
+    f.q, f.k, f.v, f.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
+    (f.q_bs, f.q_ts), (f.k_bs, f.k_ts), (f.v_bs, f.v_ts), (f.o_bs, f.o_ts) = strides
+    f.B, f.H, f.Sq, f.Sk, f.dh = B, H, Sq, Sk, dh
+    f.scale = scale
+    f.key_mask = ptr(key_mask)
+    f.causal = int(causal)
+    if drop is not None and drop.p > 0.0:
+        f.drop_p, f.drop_seed, f.drop_stream = drop.p, drop.seed.data_ptr(), drop.stream
+    else:
+        f.drop_p, f.drop_seed, f.drop_stream = 0.0, None, 0
+    f.lse = ptr(lse)
+    return f
+
+
+def attention_fwd(q, k, v, B, H, Sq, Sk, dh, *, q_strides, k_strides, v_strides, key_mask=None, causal=False, drop=None,
+                  out=None):
+    """q/k/v: any tensors whose (batch, token) strides (in elements) are given; heads contiguous (h*dh + c).
+    Returns (o [B*Sq, H*dh] bf16, lse [B*H*Sq] fp32)."""
+    if out is None:
+        out = torch.empty((B * Sq, H * dh), dtype=BF16, device=q.device)
+    lse = torch.empty((B * H * Sq,), dtype=F32, device=q.device)
+    o_strides = (Sq * H * dh, H * dh)
+    f = _attn_args(q, k, v, out, B, H, Sq, Sk, dh, (q_strides, k_strides, v_strides, o_strides), dh ** -0.5, key_mask,
+                   causal, drop, lse)
+    check(lib.ph_attention_fwd(C.byref(f), _stream()), 'ph_attention_fwd')
+    return out, lse
+
+
+def attention_bwd(d_o, q, k, v, o, lse, B, H, Sq, Sk, dh, *, q_strides, k_strides, v_strides, dq, dk, dv, dq_strides,
+                  dk_strides, dv_strides, key_mask=None, causal=False, drop=None):
+    a = _lib.AttnBwdArgs()
+    o_strides = (Sq * H * dh, H * dh)
+    a.f = _attn_args(q, k, v, o, B, H, Sq, Sk, dh, (q_strides, k_strides, v_strides, o_strides), dh ** -0.5, key_mask,
+                     causal, drop, lse)
+    a.d_o = d_o.data_ptr()
+    a.do_bs, a.do_ts = o_strides
+    a.dq, a.dk, a.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    (a.dq_bs, a.dq_ts), (a.dk_bs, a.dk_ts), (a.dv_bs, a.dv_ts) = dq_strides, dk_strides, dv_strides
+    delta = torch.empty((B * H * Sq,), dtype=F32, device=q.device)
+    a.delta = delta.data_ptr()
+    check(lib.ph_attention_bwd(C.byref(a), _stream()), 'ph_attention_bwd')
+
+
+# ---------------------------------------------------------------------------------------------- front end
+
+def patchify(img, p, Kp):
+    B, Cc, R, _ = img.shape
+    g = R // p
+    col = torch.empty((B * g * g, Kp), dtype=BF16, device=img.device)
+    check(lib.ph_patchify(img.data_ptr(), col.data_ptr(), B, Cc, R, p, Kp, _stream()), 'ph_patchify')
+    return col
+
+
+def resize_to_nhwc(x, Hout, Wout):
+    B, Cc, Hin, Win = x.shape
+    y = torch.empty((B, Hout, Wout, Cc), dtype=BF16, device=x.device)
+    check(lib.ph_resize_bilinear_nchw_to_nhwc(x.data_ptr(), y.data_ptr(), B, Cc, Hin, Win, Hout, Wout, _stream()),
+          'ph_resize_bilinear_nchw_to_nhwc')
+    return y
+
+
+def conv_out_size(H, ks, stride):
+    pad = ks // 2
+    return (H + 2 * pad - ks) // stride + 1
+
+
+def im2col(x, B, H, W, Cc, ks, stride, Kp, bn_scale=None, bn_shift=None):
+    Ho, Wo = conv_out_size(H, ks, stride), conv_out_size(W, ks, stride)
+    col = torch.empty((B * Ho * Wo, Kp), dtype=BF16, device=x.device)
+    check(lib.ph_im2col_nhwc(x.data_ptr(), col.data_ptr(), B, H, W, Cc, ks, stride, Kp, ptr(bn_scale), ptr(bn_shift), _stream()),
+          'ph_im2col_nhwc')
+    return col
+
+
+def col2im(dcol, B, H, W, Cc, ks, stride, Kp):
+    dx = torch.empty((B * H * W, Cc), dtype=BF16, device=dcol.device)
+    check(lib.ph_col2im_nhwc(dcol.data_ptr(), dx.data_ptr(), B, H, W, Cc, ks, stride, Kp, _stream()), 'ph_col2im_nhwc')
+    return dx
+
+
+def bn_stats(y, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5):
+    """returns stats [4, C] fp32 = (mean, rstd, scale, shift); y: bf16 [M, C] conv output."""
+    M, Cc = y.shape
+    st = torch.empty((4, Cc), dtype=F32, device=y.device)
+    check(lib.ph_bn_stats(y.data_ptr(), M, Cc, gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
+                          momentum, eps, int(training), st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(),
+                          _stream()), 'ph_bn_stats')
+    return st
+
+
+def bn_relu_bwd(da, y, gamma, beta, stats, dgamma, dbeta):
+    M, Cc = y.shape
+    dy = torch.empty_like(y)
+    sums = torch.empty((2 * Cc,), dtype=F32, device=y.device)
+    check(lib.ph_bn_relu_bwd(da.data_ptr(), y.data_ptr(), dy.data_ptr(), M, Cc, gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(),
+                             stats[1].data_ptr(), ptr(dgamma), ptr(dbeta), sums.data_ptr(), _stream()), 'ph_bn_relu_bwd')
+    return dy
+
+
+def tokens_finalize(feat, pos, tokens, B, G, D, tok_per_batch, tok_off, inst=None, E=0, g=0, table=None, inst_emb=None):
+    check(lib.ph_tokens_finalize(feat.data_ptr(), pos.data_ptr(), tokens.data_ptr(), B, G, D, tok_per_batch, tok_off, ptr(inst), E, g,
+                                 ptr(table), ptr(inst_emb), _stream()), 'ph_tokens_finalize')
+
+
+def tokens_finalize_bwd(dtokens, dfeat, dpos, B, G, D, tok_per_batch, tok_off, inst=None, E=0, g=0, table=None, dinst_emb=None):
+    check(lib.ph_tokens_finalize_bwd(dtokens.data_ptr(), ptr(dfeat), ptr(dpos), B, G, D, tok_per_batch, tok_off, ptr(inst), E, g,
+                                     ptr(table), ptr(dinst_emb), _stream()), 'ph_tokens_finalize_bwd')
+
+
+def gather_taps(inp, idx, w, n_out, taps, D):
+    out = torch.empty((n_out, D), dtype=F32, device=inp.device)
+    check(lib.ph_gather_taps(inp.data_ptr(), out.data_ptr(), idx.data_ptr(), w.data_ptr(), n_out, taps, D, _stream()), 'ph_gather_taps')
+    return out
+
+
+def scatter_taps(dout, din, idx, w, n_out, taps, D):
+    check(lib.ph_scatter_taps(dout.data_ptr(), din.data_ptr(), idx.data_ptr(), w.data_ptr(), n_out, taps, D, _stream()), 'ph_scatter_taps')
+
+
+# ---------------------------------------------------------------------------------------------- decoder ends
+
+def embed_args(ids, word, pos, typ, gamma, beta, eps, pad_id, out, xhat, rstd, drop):
+    B, T = ids.shape
+    a = _lib.EmbedFwdArgs()
+    a.ids, a.B, a.T, a.H, a.pad_id = ids.data_ptr(), B, T, word.shape[1], pad_id
+    a.word, a.pos, a.type = word.data_ptr(), pos.data_ptr(), typ.data_ptr()
+    a.gamma, a.beta, a.eps = gamma.data_ptr(), beta.data_ptr(), eps
+    a.out, a.xhat, a.rstd = out.data_ptr(), ptr(xhat), ptr(rstd)
+    if drop is not None and drop.p > 0.0:
+        a.drop_p, a.drop_seed, a.drop_stream = drop.p, drop.seed.data_ptr(), drop.stream
+    else:
+        a.drop_p, a.drop_seed, a.drop_stream = 0.0, None, 0
+    return a
+
+
+def embed_fwd(ids, word, pos, typ, gamma, beta, eps, pad_id, drop=None):
+    B, T = ids.shape
+    H = word.shape[1]
+    out = torch.empty((B * T, H), dtype=BF16, device=ids.device)
+    xhat = torch.empty((B * T, H), dtype=BF16, device=ids.device)
+    rstd = torch.empty((B * T,), dtype=F32, device=ids.device)
+    a = embed_args(ids, word, pos, typ, gamma, beta, eps, pad_id, out, xhat, rstd, drop)
+    check(lib.ph_embed_fwd(C.byref(a), _stream()), 'ph_embed_fwd')
+    return out, xhat, rstd
+
+
+def embed_bwd(dout, ids, word, pos, typ, gamma, beta, eps, pad_id, xhat, rstd, drop, dword, dpos, dtype, dgamma, dbeta):
+    a = _lib.EmbedBwdArgs()
+    a.f = embed_args(ids, word, pos, typ, gamma, beta, eps, pad_id, dout, xhat, rstd, drop)
+    a.dout = dout.data_ptr()
+    a.dword, a.dpos, a.dtype, a.dgamma, a.dbeta = ptr(dword), ptr(dpos), ptr(dtype), ptr(dgamma), ptr(dbeta)
+    check(lib.ph_embed_bwd(C.byref(a), _stream()), 'ph_embed_bwd')
+
+
+def ce_fwd(logits, labels, B, T, V, eps):
+    loss = torch.empty((B,), dtype=F32, device=logits.device)
+    row_lse = torch.empty((B * T,), dtype=F32, device=logits.device)
+    check(lib.ph_ce_fwd(logits.data_ptr(), logits.stride(0), labels.data_ptr(), B, T, V, eps, loss.data_ptr(), row_lse.data_ptr(),
+                        _stream()), 'ph_ce_fwd')
+    return loss, row_lse
+
+
+def ce_bwd(logits, labels, B, T, V, eps, row_lse, dloss):
+    check(lib.ph_ce_bwd(logits.data_ptr(), logits.stride(0), labels.data_ptr(), B, T, V, logits.shape[1], eps, row_lse.data_ptr(),
+                        dloss.data_ptr(), _stream()), 'ph_ce_bwd')
+    return logits
+
+
+# ---------------------------------------------------------------------------------------------- utilities
+
+def adamw(p, g, m, v, p_bf16, n, hyper, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.05, grad_scale=1.0):
+    check(lib.ph_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), ptr(p_bf16), n, hyper.data_ptr(), beta1, beta2, eps,
+                       weight_decay, grad_scale, _stream()), 'ph_adamw')
+
+
+def cast_to_bf16(x, out=None):
+    if out is None:
+        out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    check(lib.ph_cast_f32_to_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), 'ph_cast_f32_to_bf16')
+    return out
+
+
+def cast_to_f32(x, out=None):
+    if out is None:
+        out = torch.empty(x.shape, dtype=F32, device=x.device)
+    check(lib.ph_cast_bf16_to_f32(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), 'ph_cast_bf16_to_f32')
+    return out
+
+
+def colsum(x, out, M=None, N=None):
+    """out[N] (fp32) += column sums of bf16 x[M, N]."""
+    M = x.shape[0] if M is None else M
+    N = x.shape[1] if N is None else N
+    check(lib.ph_colsum_bf16(x.data_ptr(), M, N, x.stride(0), out.data_ptr(), _stream()), 'ph_colsum_bf16')
+
+
+def add(a, b, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib.ph_add_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), 'ph_add_bf16')
+    return out
+
+
+def copy_rows(src, dst, rows, cols, src_map=IDENT, dst_map=IDENT, accumulate=False, src_ld=None, dst_ld=None):
+    check(lib.ph_copy_rows_bf16(src.data_ptr(), src_ld or src.stride(0), src_map, dst.data_ptr(), dst_ld or dst.stride(0), dst_map,
+                                rows, cols, int(accumulate), _stream()), 'ph_copy_rows_bf16')
+
+
+def conv_weight_to_shadow(w, shadow, Cout, Cin, ks, Kp):
+    check(lib.ph_conv_weight_to_shadow(w.data_ptr(), shadow.data_ptr(), Cout, Cin, ks, Kp, _stream()), 'ph_conv_weight_to_shadow')
+
+
+def conv_grad_from_shadow(dshadow, dw, Cout, Cin, ks, Kp):
+    check(lib.ph_conv_grad_from_shadow(dshadow.data_ptr(), dw.data_ptr(), Cout, Cin, ks, Kp, _stream()), 'ph_conv_grad_from_shadow')
+
+
+def advance_seed(seed):
+    check(lib.ph_advance_seed(seed.data_ptr(), _stream()), 'ph_advance_seed')
+
+
+def probe_layouts(inp):
+    out = torch.empty((512 + 1024,), dtype=F32, device=inp.device)
+    check(lib.ph_probe_layouts(inp.data_ptr(), out.data_ptr(), _stream()), 'ph_probe_layouts')
+    return out

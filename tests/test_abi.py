@@ -1,0 +1,73 @@
+"""CPU: the C-ABI shared library builds for gfx950, loads, and exports every symbol include/prismer_hip.h declares.
+No compute calls here (no GPU in the build container)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, 'include', 'prismer_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(ph_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_builds_and_exports_header_symbols():
+    from prismer_amd import build
+    path = build.build(verbose=False)
+    assert os.path.isfile(path)
+    from prismer_amd import _lib
+    syms = header_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(_lib.lib, s), f'{s} declared in prismer_hip.h but not exported'
+    assert sorted(_lib.EXPORTS) == syms, (set(_lib.EXPORTS) ^ set(syms))
+    assert _lib.lib.ph_version() == 100
+    assert _lib.lib.ph_last_error() is not None
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are rejected on the host before any launch (error code + message, no abort)."""
+    import ctypes as C
+    from prismer_amd import _lib
+    g = _lib.GemmArgs()
+    rc = _lib.lib.ph_gemm_bf16(C.byref(g), None)
+    assert rc == -1 and b'null pointer' in _lib.lib.ph_last_error()
+    f = _lib.AttnFwdArgs()
+    f.q = f.k = f.v = f.o = 16
+    f.B = f.H = f.Sq = f.Sk = 1
+    f.dh = 48
+    rc = _lib.lib.ph_attention_fwd(C.byref(f), None)
+    assert rc == -1 and b'head dim 48' in _lib.lib.ph_last_error()
+
+
+def test_struct_sizes_match_header():
+    """ctypes mirrors of the ABI structs must have the C layout (checked against a tiny C program)."""
+    import ctypes as C
+    import subprocess
+    import tempfile
+    from prismer_amd import _lib
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "prismer_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ph_gemm_args), sizeof(ph_layernorm_fwd_args), sizeof(ph_layernorm_bwd_args),
+         sizeof(ph_attn_fwd_args), sizeof(ph_attn_bwd_args), sizeof(ph_embed_fwd_args), sizeof(ph_embed_bwd_args), sizeof(ph_rowmap));
+  printf("%zu %zu %zu %zu\n", offsetof(ph_gemm_args, split_k), offsetof(ph_layernorm_bwd_args, D), offsetof(ph_attn_bwd_args, delta),
+         offsetof(ph_embed_bwd_args, dbeta));
+  return 0;
+}'''
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, 't.c'); exe = os.path.join(td, 't')
+        open(src, 'w').write(prog)
+        subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), src, '-o', exe])
+        out = subprocess.check_output([exe]).decode().split()
+    sizes = [int(v) for v in out[:8]]
+    offs = [int(v) for v in out[8:]]
+    assert sizes == [C.sizeof(_lib.GemmArgs), C.sizeof(_lib.LayerNormFwdArgs), C.sizeof(_lib.LayerNormBwdArgs), C.sizeof(_lib.AttnFwdArgs),
+                     C.sizeof(_lib.AttnBwdArgs), C.sizeof(_lib.EmbedFwdArgs), C.sizeof(_lib.EmbedBwdArgs), C.sizeof(_lib.RowMap)]
+    assert offs == [_lib.GemmArgs.split_k.offset, _lib.LayerNormBwdArgs.D.offset, _lib.AttnBwdArgs.delta.offset,
+                    _lib.EmbedBwdArgs.dbeta.offset]

@@ -1,0 +1,460 @@
+"""GPU: every HIP kernel (through the C ABI) against a plain PyTorch fp32 reference of the same op.
+Tolerances: bf16 outputs carry one rounding (2^-9 relative) on top of fp32-accumulated math: rel-Frobenius
+<= 6e-3; fp32 outputs of bf16-input contractions <= 2e-4."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import bf16_round, dropout_keep_attention, dropout_keep_linear, max_abs, rel_fro
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from prismer_amd import ops as o
+    return o
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=BF):
+    g = torch.Generator(device='cpu').manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).cuda()
+
+
+def seed_tensor(val):
+    return torch.tensor([val], dtype=torch.int64, device='cuda')
+
+
+# ---------------------------------------------------------------------------------------------- layouts
+def test_probe_layouts(ops):
+    inp = (torch.arange(1024) % 256).to(BF).cuda()
+    out = ops.probe_layouts(inp).cpu()
+    src = (torch.arange(1024) % 256).float()
+    tr = out[:256].reshape(64, 4)
+    exp = torch.empty(64, 4)
+    for l in range(64):
+        for j in range(4):
+            exp[l, j] = src[(l & 15) + j * 16 + (l >> 4) * 64]       # guide: lane l, elem j of a lane-linear tr read
+    assert torch.equal(tr, exp), f'ds_read_b64_tr_b16 semantics differ:\n got {tr[:20].tolist()}\n exp {exp[:20].tolist()}'
+    c16 = out[256:512].reshape(64, 4)
+    e16 = torch.empty(64, 4)
+    for l in range(64):
+        for r in range(4):
+            e16[l, r] = src[((l >> 4) * 4 + r) * 16 + (l & 15)]
+    assert torch.equal(c16, e16), 'mfma 16x16x32 C layout differs'
+    c32 = out[512:].reshape(64, 16)
+    e32 = torch.zeros(64, 16)
+    for l in range(64):
+        for r in range(16):
+            row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)
+            if row < 16:
+                e32[l, r] = src[row * 32 + (l & 31)]
+    assert torch.equal(c32, e32), 'mfma 32x32x16 C layout differs'
+
+
+# ---------------------------------------------------------------------------------------------- GEMM
+GEMM_SHAPES = [(128, 128, 64), (200, 136, 96), (960, 768, 768), (1000, 2304, 768), (77, 1003, 256), (4160, 768, 3072),
+               (300, 96, 32), (64, 64, 64)]
+
+
+@pytest.mark.parametrize('M,N,K', GEMM_SHAPES)
+@pytest.mark.parametrize('layout', ['nt', 'nn', 'tn'])
+def test_gemm_layouts(ops, M, N, K, layout):
+    Np = (N + 7) // 8 * 8
+    Mp = (M + 7) // 8 * 8
+    a = rnd(M, K, scale=0.5, seed=1)
+    b = rnd(N, K, scale=0.5, seed=2)
+    ref = a.float() @ b.float().t()
+    if layout == 'nt':
+        if K % 8:
+            pytest.skip('NT needs K % 8 == 0')
+        out = ops.gemm(a, b)
+    elif layout == 'nn':          # B stored [K][N] (padded leading dim)
+        bt = torch.zeros(K, Np, dtype=BF, device='cuda'); bt[:, :N] = b.t()
+        out = ops.gemm(a, bt, trans_b=True, N=N)
+    else:                         # both stored [K][rows]
+        at = torch.zeros(K, Mp, dtype=BF, device='cuda'); at[:, :M] = a.t()
+        bt = torch.zeros(K, Np, dtype=BF, device='cuda'); bt[:, :N] = b.t()
+        out = ops.gemm(at, bt, trans_a=True, trans_b=True, M=M, N=N)
+    assert out.shape == (M, N)
+    assert rel_fro(out, ref) < 6e-3, (layout, M, N, K, rel_fro(out, ref))
+
+
+@pytest.mark.parametrize('act', [0, 1, 2, 3, 4])
+def test_gemm_epilogue(ops, act):
+    M, N, K = 333, 520, 256
+    a, b = rnd(M, K, scale=0.5, seed=3), rnd(N, K, scale=0.3, seed=4)
+    bias = rnd(N, dtype=torch.float32, seed=5)
+    res = rnd(M, N, seed=6)
+    pre = torch.empty(M, N, dtype=BF, device='cuda')
+    out = ops.gemm(a, b, bias=bias, act=act, pre_out=pre, residual=res)
+    z = a.float() @ b.float().t() + bias
+    fn = {0: lambda t: t, 1: lambda t: t * torch.sigmoid(1.702 * t), 2: lambda t: torch.relu(t) ** 2,
+          3: lambda t: F.gelu(t), 4: torch.relu}[act]
+    assert rel_fro(pre, z) < 6e-3
+    assert rel_fro(out, fn(z) + res.float()) < 6e-3
+    # backward-through-activation epilogue: C = acc * act'(act_in)
+    dy = rnd(M, N, scale=0.5, seed=7)
+    w2 = rnd(N, K, scale=0.3, seed=8)          # dY[M,N] . W[N,K] -> [M,K], times act'(p) with p [M,K]
+    p = rnd(M, K, seed=9)
+    got = ops.gemm(dy, w2, trans_b=True, act=act, act_in=p)
+    pf = p.float().requires_grad_(True)
+    fn(pf).backward(torch.ones_like(pf))
+    ref = (dy.float() @ w2.float()) * pf.grad
+    assert rel_fro(got, ref) < 6e-3
+
+
+def test_gemm_f32_accumulate_splitk(ops):
+    M, N, K = 768, 768, 4160           # wgrad shape: dW[N_out, K_in] = dY^T X, reduction over 4160 rows
+    dy, x = rnd(K, M, scale=0.3, seed=10), rnd(K, N, scale=0.3, seed=11)
+    ref = dy.float().t() @ x.float()
+    c0 = torch.randn(M, N, device='cuda')
+    for split in (1, 0, 7):
+        c = c0.clone()
+        ops.gemm(dy, x, out=c, trans_a=True, trans_b=True, out_f32=True, accumulate=True, split_k=split)
+        assert rel_fro(c - c0, ref) < 3e-4, (split, rel_fro(c - c0, ref))
+    c = ops.gemm(dy, x, trans_a=True, trans_b=True, out_f32=True)
+    assert rel_fro(c, ref) < 3e-4
+    # bf16 accumulate
+    cb = rnd(M, N, seed=12)
+    cb0 = cb.clone()
+    ops.gemm(dy, x, out=cb, trans_a=True, trans_b=True, accumulate=True, alpha=0.5)
+    assert rel_fro(cb, cb0.float() + 0.5 * ref) < 6e-3
+
+
+def test_gemm_dropout_mask(ops):
+    M, N, K = 96, 128, 64
+    a = torch.eye(M, K, dtype=BF, device='cuda')                    # out = dropout(B^T rows) on the first 64 rows
+    b = rnd(N, K, seed=13)
+    seed = 0x1234567890ABCDEF
+    d = ops.Dropout(0.1, seed_tensor(seed), 77)
+    out = ops.gemm(a, b, drop=d)
+    keep = dropout_keep_linear(M * N, seed, 77, 0.1).reshape(M, N)
+    ref = (a.float() @ b.float().t()).cpu() * keep / 0.9
+    assert rel_fro(out, ref) < 6e-3
+    assert abs(keep.float().mean().item() - 0.9) < 0.02
+
+
+def test_gemm_errors(ops):
+    a, b = rnd(16, 12), rnd(16, 12)
+    with pytest.raises(RuntimeError):
+        ops.gemm(a, b)                  # lda = 12: not a multiple of 8
+
+
+# ---------------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize('M,D', [(37, 256), (960, 768), (515, 1024)])
+def test_layernorm(ops, M, D):
+    x = rnd(M, D, seed=20)
+    g = 1 + 0.1 * rnd(D, dtype=torch.float32, seed=21)
+    b = 0.1 * rnd(D, dtype=torch.float32, seed=22)
+    y, mean, rstd = ops.layernorm_fwd(x, g, b)
+    xf = x.float().requires_grad_(True)
+    gf, bf = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xf, (D,), gf, bf, 1e-5)
+    assert rel_fro(y, ref) < 6e-3
+    assert rel_fro(mean, xf.mean(1)) < 1e-5
+    dy = rnd(M, D, seed=23)
+    dsk = rnd(M, D, seed=24)
+    dg = torch.zeros(D, device='cuda'); db = torch.zeros(D, device='cuda')
+    dx, _ = ops.layernorm_bwd(dy, x, mean, rstd, g, dskip=dsk, dgamma=dg, dbeta=db)
+    ref.backward(dy.float())
+    assert rel_fro(dx, xf.grad + dsk.float()) < 6e-3
+    assert rel_fro(dg, gf.grad) < 1e-4 and rel_fro(db, bf.grad) < 1e-4
+
+
+def test_layernorm_rowmap_and_dropout(ops):
+    from prismer_amd._lib import RowMap
+    B, L, Mx, D = 3, 8, 20, 256
+    x = rnd(B * Mx, D, seed=25)
+    g = torch.ones(D, device='cuda'); b = torch.zeros(D, device='cuda')
+    kv = torch.zeros(B * (L + Mx), D, dtype=BF, device='cuda')
+    ops.layernorm_fwd(x, g, b, out=kv, out_map=RowMap(Mx, L + Mx, L))
+    ref = F.layer_norm(x.float(), (D,))
+    got = kv.reshape(B, L + Mx, D)[:, L:].reshape(B * Mx, D)
+    assert rel_fro(got, ref) < 6e-3 and kv.reshape(B, L + Mx, D)[:, :L].abs().max() == 0
+    # backward reading dy through the same map + dropout-masked second output
+    _, mean, rstd = ops.layernorm_fwd(x, g, b)
+    dkv = rnd(B * (L + Mx), D, seed=26)
+    seed = 99
+    d = ops.Dropout(0.25, seed_tensor(seed), 5)
+    dx, dxd = ops.layernorm_bwd(dkv, x, mean, rstd, g, dy_map=RowMap(Mx, L + Mx, L), drop=d)
+    xf = x.float().requires_grad_(True)
+    F.layer_norm(xf, (D,)).backward(dkv.float().reshape(B, L + Mx, D)[:, L:].reshape(B * Mx, D))
+    assert rel_fro(dx, xf.grad) < 6e-3
+    keep = dropout_keep_linear(B * Mx * D, seed, 5, 0.25).reshape(B * Mx, D)
+    assert rel_fro(dxd, dx.float().cpu() * keep / 0.75) < 6e-3
+
+
+# ---------------------------------------------------------------------------------------------- attention
+def attn_ref(q, k, v, scale, key_mask=None, causal=False, keep=None, p=0.0):
+    """q [B,H,Sq,dh] fp32 etc.; finfo.min masking + clamp like roberta.py:113-115."""
+    s = q @ k.transpose(-1, -2) * scale
+    Sq, Sk = s.shape[-2:]
+    m = torch.ones(Sq, Sk, dtype=torch.bool, device=q.device)
+    if causal:
+        m = torch.tril(m)
+    m = m[None, None].expand_as(s).clone()
+    if key_mask is not None:
+        m &= key_mask.bool()[:, None, None, :]
+    s = s.masked_fill(~m, torch.finfo(torch.float32).min)
+    pr = torch.softmax(s, dim=-1)
+    if keep is not None:
+        pr = pr * keep.to(pr.device).reshape(pr.shape) / (1 - p)
+    return pr @ v
+
+
+ATTN_CASES = [  # B, H, Sq, Sk, dh, causal, masked, drop
+    (2, 3, 260, 260, 64, False, False, 0.0),     # ViT self-attention (vit.py:53)
+    (2, 8, 64, 300, 96, False, False, 0.0),      # perceiver cross-attention, head dim 96 (resampler.py:31)
+    (3, 4, 30, 30, 64, True, True, 0.0),         # decoder self-attention: causal + padding (roberta.py:110-115)
+    (2, 4, 30, 260, 64, False, False, 0.1),      # decoder cross-attention with prob-dropout (roberta.py:123)
+    (2, 2, 70, 130, 32, True, False, 0.0),
+    (1, 2, 100, 200, 128, False, True, 0.2),
+]
+
+
+@pytest.mark.parametrize('B,H,Sq,Sk,dh,causal,masked,p', ATTN_CASES)
+def test_attention(ops, B, H, Sq, Sk, dh, causal, masked, p):
+    D = H * dh
+    q = rnd(B * Sq, D, seed=30)
+    kv = rnd(B * Sk, 2 * D, seed=31)             # packed [k | v] rows like the KV projection output
+    k, v = kv[:, :D], kv[:, D:]
+    km = None
+    if masked:
+        km = torch.ones(B, Sk, dtype=torch.uint8, device='cuda')
+        for b in range(B):
+            km[b, Sk - 3 - 2 * b:] = 0
+    seed = 4242
+    drop = ops.Dropout(p, seed_tensor(seed), 11) if p > 0 else None
+    qs, ks = (Sq * D, D), (Sk * 2 * D, 2 * D)
+    o, lse = ops.attention_fwd(q, k, v, B, H, Sq, Sk, dh, q_strides=qs, k_strides=ks, v_strides=ks, key_mask=km, causal=causal,
+                               drop=drop)
+    qf = q.float().reshape(B, Sq, H, dh).transpose(1, 2).requires_grad_(True)
+    kf = k.float().reshape(B, Sk, H, dh).transpose(1, 2).requires_grad_(True)
+    vf = v.float().reshape(B, Sk, H, dh).transpose(1, 2).requires_grad_(True)
+    keep = dropout_keep_attention(B * H, Sq, Sk, seed, 11, p).reshape(B, H, Sq, Sk).cuda() if p > 0 else None
+    ref = attn_ref(qf, kf, vf, dh ** -0.5, km, causal, keep, p)
+    ref_flat = ref.transpose(1, 2).reshape(B * Sq, D)
+    assert rel_fro(o, ref_flat) < 8e-3, rel_fro(o, ref_flat)
+    d_o = rnd(B * Sq, D, seed=32)
+    dq = torch.empty_like(q); dkv = torch.empty_like(kv)
+    ops.attention_bwd(d_o, q, k, v, o, lse, B, H, Sq, Sk, dh, q_strides=qs, k_strides=ks, v_strides=ks, dq=dq, dk=dkv[:, :D],
+                      dv=dkv[:, D:], dq_strides=qs, dk_strides=ks, dv_strides=ks, key_mask=km, causal=causal, drop=drop)
+    ref.backward(d_o.float().reshape(B, Sq, H, dh).transpose(1, 2))
+    gq = qf.grad.transpose(1, 2).reshape(B * Sq, D)
+    gk = kf.grad.transpose(1, 2).reshape(B * Sk, D)
+    gv = vf.grad.transpose(1, 2).reshape(B * Sk, D)
+    assert rel_fro(dq, gq) < 1.5e-2, ('dq', rel_fro(dq, gq))
+    assert rel_fro(dkv[:, :D], gk) < 1.5e-2, ('dk', rel_fro(dkv[:, :D], gk))
+    assert rel_fro(dkv[:, D:], gv) < 1.5e-2, ('dv', rel_fro(dkv[:, D:], gv))
+
+
+# ---------------------------------------------------------------------------------------------- front end
+def test_patchify_and_resize(ops):
+    img = torch.randn(2, 3, 64, 64, device='cuda')
+    col = ops.patchify(img, 16, 768)
+    ref = F.unfold(img, 16, stride=16).transpose(1, 2).reshape(-1, 768)       # (c, py, px) order
+    assert rel_fro(col, ref) < 4e-3
+    col14 = ops.patchify(torch.randn(1, 3, 56, 56, device='cuda'), 14, 592)
+    assert col14.shape == (16, 592) and col14[:, 588:].abs().max() == 0
+    x = torch.randn(2, 64, 48, 48, device='cuda')
+    y = ops.resize_to_nhwc(x, 12, 12)
+    ref = F.interpolate(x, size=(12, 12), mode='bilinear', align_corners=True).permute(0, 2, 3, 1)
+    assert rel_fro(y, ref) < 4e-3
+    x3 = torch.randn(2, 3, 28, 28, device='cuda')
+    y3 = ops.resize_to_nhwc(x3, 32, 32)                                       # p=14 style up-scaling, C % 8 != 0
+    assert rel_fro(y3, F.interpolate(x3, size=(32, 32), mode='bilinear', align_corners=True).permute(0, 2, 3, 1)) < 4e-3
+    y1 = ops.resize_to_nhwc(x3[:, :1].contiguous(), 28, 28)                   # identity resize = layout change
+    assert rel_fro(y1, x3[:, :1].permute(0, 2, 3, 1)) < 4e-3
+
+
+@pytest.mark.parametrize('C,stride,ks', [(64, 2, 3), (32, 1, 3), (3, 2, 3), (1, 2, 3), (64, 1, 1)])
+def test_conv_as_gemm(ops, C, stride, ks):
+    B, H, W, Co = 2, 20, 20, 48
+    x = rnd(B, H, W, C, seed=40)                                              # NHWC
+    w = rnd(Co, C, ks, ks, scale=0.2, seed=41, dtype=torch.float32)
+    K = ks * ks * C
+    Kp = (K + 7) // 8 * 8
+    shadow = torch.empty(Co, Kp, dtype=BF, device='cuda')
+    ops.conv_weight_to_shadow(w, shadow, Co, C, ks, Kp)
+    sc = 1 + 0.1 * rnd(C, dtype=torch.float32, seed=42)
+    sh = 0.1 * rnd(C, dtype=torch.float32, seed=43)
+    for bn in (False, True):
+        col = ops.im2col(x, B, H, W, C, ks, stride, Kp, sc if bn else None, sh if bn else None)
+        y = ops.gemm(col, shadow)
+        xin = x.float().permute(0, 3, 1, 2)
+        if bn:
+            xin = torch.relu(xin * sc[None, :, None, None] + sh[None, :, None, None])
+        ref = F.conv2d(bf16_round(xin), bf16_round(w), stride=stride, padding=ks // 2).permute(0, 2, 3, 1).reshape(-1, Co)
+        assert rel_fro(y, ref) < 8e-3, (bn, rel_fro(y, ref))
+    if C % 8 == 0:
+        Ho = ops.conv_out_size(H, ks, stride)
+        dcol = rnd(B * Ho * Ho, Kp, seed=44)
+        dx = ops.col2im(dcol, B, H, W, C, ks, stride, Kp)
+        xr = torch.zeros(B, C, H, W, device='cuda', requires_grad=True)
+        cols = F.unfold(xr, ks, padding=ks // 2, stride=stride)               # [B, C*ks*ks, L] with (c, ky, kx) order
+        d = dcol.float()[:, :K].reshape(B, Ho * Ho, ks * ks, C).permute(0, 3, 2, 1).reshape(B, C * ks * ks, Ho * Ho)
+        cols.backward(d)
+        assert rel_fro(dx.reshape(B, H, W, C), xr.grad.permute(0, 2, 3, 1)) < 6e-3
+    # weight-gradient layout round trip
+    ds = torch.randn(Co, Kp, device='cuda')
+    dw = torch.zeros_like(w)
+    ops.conv_grad_from_shadow(ds, dw, Co, C, ks, Kp)
+    assert rel_fro(dw, ds[:, :K].reshape(Co, ks, ks, C).permute(0, 3, 1, 2)) < 1e-6
+
+
+@pytest.mark.parametrize('M,C', [(5000, 96), (777, 32), (3000, 768)])
+def test_batchnorm(ops, M, C):
+    y = rnd(M, C, seed=50) * 2 + 0.5
+    g = 1 + 0.1 * rnd(C, dtype=torch.float32, seed=51)
+    b = 0.1 * rnd(C, dtype=torch.float32, seed=52)
+    rm = 0.1 * rnd(C, dtype=torch.float32, seed=53); rv = 1 + 0.2 * rnd(C, dtype=torch.float32, seed=54).abs()
+    rm0, rv0 = rm.clone(), rv.clone()
+    st = ops.bn_stats(y, g, b, rm, rv, True)
+    yf = y.float().requires_grad_(True)
+    gf, bf_ = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rmr, rvr = rm0.clone(), rv0.clone()
+    ref = torch.relu(F.batch_norm(yf, rmr, rvr, gf, bf_, True, 0.1, 1e-5))
+    assert rel_fro(st[0], yf.mean(0)) < 1e-4 and rel_fro(st[1], (yf.var(0, unbiased=False) + 1e-5).rsqrt()) < 1e-3
+    assert rel_fro(rm, rmr) < 1e-4 and rel_fro(rv, rvr) < 1e-3
+    got = torch.relu(y.float() * st[2] + st[3])
+    assert rel_fro(got, ref) < 2e-3
+    da = rnd(M, C, seed=55)
+    dg = torch.zeros(C, device='cuda'); db = torch.zeros(C, device='cuda')
+    dy = ops.bn_relu_bwd(da, y, g, b, st, dg, db)
+    ref.backward(da.float())
+    assert rel_fro(dy, yf.grad) < 1e-2, rel_fro(dy, yf.grad)
+    assert rel_fro(dg, gf.grad) < 2e-3 and rel_fro(db, bf_.grad) < 2e-3
+    ev = ops.bn_stats(y, g, b, rm, rv, False)
+    assert rel_fro(ev[2], g * (rv + 1e-5).rsqrt()) < 1e-5
+
+
+def test_tokens_finalize(ops):
+    B, g_, D, E = 2, 4, 256, 64
+    G = g_ * g_
+    feat = rnd(B * G, D, seed=60)
+    pos = rnd(G, D, dtype=torch.float32, seed=61)
+    inst = torch.randint(0, 256, (B, 1, E, E), device='cuda')
+    table = torch.randint(0, 128, (256,), dtype=torch.int32, device='cuda')
+    emb = rnd(128, D, dtype=torch.float32, seed=62)
+    tpb, off = 3 * G, G
+    tok = torch.zeros(B * tpb, D, dtype=BF, device='cuda')
+    ops.tokens_finalize(feat, pos, tok, B, G, D, tpb, off, inst, E, g_, table, emb)
+    im = F.interpolate(inst.float(), size=(g_, g_), mode='nearest')[:, 0].long()            # vit.py:142
+    ref = feat.float().reshape(B, G, D) + pos[None] + emb[table.long()[im]].reshape(B, G, D)
+    assert rel_fro(tok.reshape(B, tpb, D)[:, off:off + G], ref) < 4e-3
+    dtok = rnd(B * tpb, D, seed=63)
+    dfeat = torch.empty(B * G, D, dtype=BF, device='cuda')
+    dpos = torch.zeros(G, D, device='cuda'); demb = torch.zeros(128, D, device='cuda')
+    ops.tokens_finalize_bwd(dtok, dfeat, dpos, B, G, D, tpb, off, inst, E, g_, table, demb)
+    sl = dtok.float().reshape(B, tpb, D)[:, off:off + G]
+    assert torch.equal(dfeat.reshape(B, G, D), dtok.reshape(B, tpb, D)[:, off:off + G])
+    assert rel_fro(dpos, sl.sum(0)) < 1e-5
+    ref_e = torch.zeros(128, D, device='cuda').index_add_(0, table.long()[im].reshape(-1), sl.reshape(-1, D))
+    assert rel_fro(demb, ref_e) < 1e-5
+
+
+def test_taps(ops):
+    n_in, n_out, taps, D = 36, 16, 16, 64
+    inp = torch.randn(n_in, D, device='cuda')
+    idx = torch.randint(0, n_in, (n_out, taps), dtype=torch.int32, device='cuda')
+    w = torch.randn(n_out, taps, device='cuda')
+    out = ops.gather_taps(inp, idx, w, n_out, taps, D)
+    ref = (w[:, :, None] * inp[idx.long()]).sum(1)
+    assert rel_fro(out, ref) < 1e-5
+    din = torch.zeros(n_in, D, device='cuda')
+    dout = torch.randn(n_out, D, device='cuda')
+    ops.scatter_taps(dout, din, idx, w, n_out, taps, D)
+    ref_in = torch.zeros(n_in, D, device='cuda').index_add_(0, idx.long().reshape(-1), (w[:, :, None] * dout[:, None]).reshape(-1, D))
+    assert rel_fro(din, ref_in) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------- decoder ends
+def test_embed(ops):
+    B, T, H, V, pad = 3, 12, 256, 1003, 1
+    ids = torch.randint(3, V, (B, T), device='cuda')
+    ids[:, 0] = 0; ids[1, 8:] = pad; ids[2, 5:] = pad
+    word = rnd(V, H, scale=0.05, dtype=torch.float32, seed=70); posw = rnd(514, H, scale=0.05, dtype=torch.float32, seed=71)
+    typ = rnd(1, H, scale=0.05, dtype=torch.float32, seed=72)
+    g = 1 + 0.1 * rnd(H, dtype=torch.float32, seed=73); b = 0.1 * rnd(H, dtype=torch.float32, seed=74)
+    seed = 31337
+    d = ops.Dropout(0.1, seed_tensor(seed), 3)
+    out, xhat, rstd = ops.embed_fwd(ids, word, posw, typ, g, b, 1e-5, pad, d)
+    m = (ids != pad).long()
+    pid = torch.cumsum(m, 1) * m + pad
+    wf, pf, tf = word.clone().requires_grad_(True), posw.clone().requires_grad_(True), typ.clone().requires_grad_(True)
+    gf, bf_ = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    e = F.embedding(ids, wf, padding_idx=pad) + tf[0] + F.embedding(pid, pf, padding_idx=pad)
+    keep = dropout_keep_linear(B * T * H, seed, 3, 0.1).reshape(B * T, H).cuda()
+    ref = F.layer_norm(e, (H,), gf, bf_, 1e-5).reshape(B * T, H) * keep / 0.9
+    assert rel_fro(out, ref) < 6e-3
+    dout = rnd(B * T, H, seed=75)
+    dw, dp, dt = torch.zeros_like(word), torch.zeros_like(posw), torch.zeros_like(typ)
+    dg, db = torch.zeros_like(g), torch.zeros_like(b)
+    ops.embed_bwd(dout, ids, word, posw, typ, g, b, 1e-5, pad, xhat, rstd, d, dw, dp, dt, dg, db)
+    ref.backward(dout.float())
+    for got, want, name in ((dw, wf.grad, 'word'), (dp, pf.grad, 'pos'), (dt, tf.grad, 'type'), (dg, gf.grad, 'gamma'), (db, bf_.grad, 'beta')):
+        assert rel_fro(got, want) < 1e-2, (name, rel_fro(got, want))
+    assert dw[pad].abs().max() == 0 and dp[pad].abs().max() == 0
+
+
+@pytest.mark.parametrize('V', [1003, 50265])
+def test_cross_entropy(ops, V):
+    B, T = 3, 9
+    Vp = (V + 63) // 64 * 64
+    logits = torch.zeros(B * T, Vp, dtype=BF, device='cuda')
+    logits[:, :V] = rnd(B * T, V, scale=2.0, seed=80)
+    logits[:, V:] = 7.0                                        # garbage in the pad columns must be ignored
+    labels = torch.randint(0, V, (B, T), device='cuda')
+    labels[:, :3] = -100; labels[1, 6:] = -100
+    loss, lse = ops.ce_fwd(logits, labels, B, T, V, 0.1)
+    lf = logits[:, :V].float().reshape(B, T, V).requires_grad_(True)
+    ref = F.cross_entropy(lf[:, :-1].reshape(-1, V), labels[:, 1:].reshape(-1), reduction='none', label_smoothing=0.1).view(B, -1).sum(1)
+    assert rel_fro(loss, ref) < 1e-4, (loss, ref)
+    dl = torch.tensor([0.5, 0.25, 1.0], device='cuda')
+    (ref * dl).sum().backward()
+    ops.ce_bwd(logits, labels, B, T, V, 0.1, lse, dl)
+    assert rel_fro(logits[:, :V].reshape(B, T, V), lf.grad) < 8e-3
+    assert logits[:, V:].abs().max() == 0
+
+
+# ---------------------------------------------------------------------------------------------- optimizer / utils
+def test_adamw_matches_torch(ops):
+    n = 10007
+    p = torch.randn(n, device='cuda')
+    ref_p = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([ref_p], lr=5e-5, weight_decay=0.05)
+    m = torch.zeros(n, device='cuda'); v = torch.zeros(n, device='cuda'); pb = torch.empty(n, dtype=BF, device='cuda')
+    for step in (1, 2, 3):
+        g = torch.randn(n, device='cuda')
+        ref_p.grad = g.clone()
+        opt.step()
+        hyper = torch.tensor([5e-5, 1 - 0.9 ** step, 1 - 0.999 ** step], device='cuda')
+        ops.adamw(p, g, m, v, pb, n, hyper)
+    assert max_abs(p, ref_p) < 1e-6
+    assert rel_fro(pb, p) < 4e-3
+
+
+def test_small_utils(ops):
+    x = torch.randn(1000, 72, device='cuda')
+    xb = ops.cast_to_bf16(x)
+    assert torch.equal(xb, x.to(BF))
+    assert torch.equal(ops.cast_to_f32(xb), xb.float())
+    out = torch.ones(72, device='cuda')
+    ops.colsum(xb, out)
+    assert rel_fro(out, 1 + xb.float().sum(0)) < 1e-5
+    a, b = rnd(999, 8, seed=90), rnd(999, 8, seed=91)
+    assert rel_fro(ops.add(a, b), a.float() + b.float()) < 4e-3
+    from prismer_amd._lib import RowMap
+    src = rnd(12, 64, seed=92)
+    dst = torch.zeros(3 * 10, 64, dtype=BF, device='cuda')
+    ops.copy_rows(src, dst, 12, 64, dst_map=RowMap(4, 10, 2))
+    assert torch.equal(dst.reshape(3, 10, 64)[:, 2:6].reshape(12, 64), src)
+    s = torch.tensor([5], dtype=torch.int64, device='cuda')
+    ops.advance_seed(s)
+    assert s.item() != 5
