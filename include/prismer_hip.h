@@ -127,8 +127,8 @@ int ph_attention_bwd(const ph_attn_bwd_args* args, hipStream_t stream);
 /* ------------------------------------------------------------------------------------------------
  * Encoder front end (vit.py:86-160).
  * ---------------------------------------------------------------------------------------------- */
-/* fp32 NCHW image -> bf16 patch matrix [B*g*g, Kp], column order (c, py, px) = Conv2d weight [D,3,p,p]
- * flattened (vit.py:86,138), zero-padded to Kp. */
+/* fp32 NCHW image -> bf16 patch matrix [B*g*g, Kp], column order (py, px, c) (the order ph_conv_weight_to_shadow
+ * gives the Conv2d(3, D, p, stride=p) weight of vit.py:86,138), zero-padded to Kp. */
 int ph_patchify(const float* img, void* col, int B, int C, int R, int p, int Kp, hipStream_t stream);
 /* nn.UpsamplingBilinear2d (align_corners=True, vit.py:89,106) fused with NCHW fp32 -> NHWC bf16. */
 int ph_resize_bilinear_nchw_to_nhwc(const float* x, void* y, int B, int C, int Hin, int Win, int Hout, int Wout,
@@ -146,7 +146,7 @@ int ph_col2im_nhwc(const void* dcol, void* dx, int B, int H, int W, int C, int k
  * training == 0: scale/shift from the running statistics, nothing updated. */
 int ph_bn_stats(const void* y, int M, int C, const float* gamma, const float* beta, float* running_mean,
                 float* running_var, float momentum, float eps, int training, float* mean, float* rstd,
-                float* scale, float* shift, hipStream_t stream);
+                float* scale, float* shift, hipStream_t stream);   /* scale and shift must be ONE [2*C] block: shift == scale + C */
 /* BatchNorm + ReLU backward.  da = gradient w.r.t. relu(bn(y)).  Two kernels inside:
  * (1) dgamma += sum g*xhat, dbeta += sum g with g = da * [bn(y) > 0];  (2) dy = gamma*rstd*(g - dbeta/M - xhat*dgamma/M).
  * sums: fp32 workspace [2*C] (zeroed by the call). */
@@ -212,6 +212,9 @@ int ph_cast_f32_to_bf16(const float* x, void* y, int64_t n, hipStream_t stream);
 int ph_cast_bf16_to_f32(const void* x, float* y, int64_t n, hipStream_t stream);
 /* out[n] += sum_m x[m,n]  (bias gradients) */
 int ph_colsum_bf16(const void* x, int M, int N, int ld, float* out, hipStream_t stream);
+/* dx = dy * act'(pre)  (bf16, n elements): backward through an activation that is not fused into a GEMM
+ * (LM head: dense -> gelu -> LayerNorm, roberta.py:421-425) */
+int ph_act_bwd_bf16(const void* dy, const void* pre, void* dx, int64_t n, int act, hipStream_t stream);
 /* y = a + b (bf16, n elements) */
 int ph_add_bf16(const void* a, const void* b, void* y, int64_t n, hipStream_t stream);
 /* generic 2-D strided copy of bf16 rows: dst[r*ldd + c] = src[map(r)*lds + c], c < cols */

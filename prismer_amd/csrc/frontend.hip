@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
       int k = k2 * 2 + e;
       float v = 0.f;
       if (k < C * p * p) {
-        int c = k / (p * p), rem = k % (p * p), py = rem / p, px = rem % p;
+        int c = k % C, tap = k / C, py = tap / p, px = tap % p;   // column order (py, px, c): same as the conv shadows
         v = img[(((int64_t)b * C + c) * R + gy * p + py) * R + gx * p + px];
       }
       o[e] = f2bf(v);

@@ -24,9 +24,16 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <utility>
+
 #include "common.h"
 
 namespace {
+
+template <int... Is, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
 
 constexpr int BK = 64;
 constexpr int KC_ROW_BYTES = BK * 2;   // K-contiguous image: 128 B per row
@@ -132,6 +139,72 @@ __device__ __forceinline__ bf16x8 frag_ks(const char* lds, int rbase, int kk, in
   return o;
 }
 
+// one lane's 4 consecutive outputs C[m][n..n+3]
+__device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n, float (&v)[4], bool splitk, bool drop,
+                                               const DropCtx& dc) {
+  const bool full = (n + 4 <= p.N);
+  if (splitk) {   // raw fp32 atomics; bias / activation are not allowed with split-K (checked on host)
+    float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (n + e < p.N) atomicAdd(c + e, v[e]);
+    return;
+  }
+  if (p.bias) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += p.bias[min(n + e, p.N - 1)];
+  }
+  if (p.pre_out) {
+    bf16* q = p.pre_out + (size_t)m * p.ldc + n;
+    if (full) { bf16x4 t = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *reinterpret_cast<bf16x4*>(q) = t; }
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (n + e < p.N) q[e] = f2bf(v[e]);
+    }
+  }
+  if (p.act_in) {       // backward through an activation: multiply by act'(saved pre-activation)
+    const bf16* q = p.act_in + (size_t)m * p.ld_act + n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= act_grad(p.act, bf2f(q[min(e, p.N - 1 - n)]));
+  } else if (p.act != PH_ACT_NONE) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = act_fwd(p.act, v[e]);
+  }
+  if (drop) {           // element index m*N+n ; N % 4 == 0 is required with dropout (checked on host)
+    u32x4 r = drop_rand4(dc, ((uint64_t)m * (uint64_t)p.N + (uint64_t)n) >> 2);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = drop_apply(dc, r[e], v[e]);
+  }
+  if (p.residual) {
+    const bf16* q = p.residual + (size_t)m * p.ldr + n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += bf2f(q[min(e, p.N - 1 - n)]);
+  }
+  if (p.out_f32) {
+    float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+    if (p.accumulate) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += c[e];
+    }
+    if (full && ((p.ldc & 3) == 0)) { f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(c) = t; }
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (n + e < p.N) c[e] = v[e];
+    }
+  } else {
+    bf16* c = reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n;
+    if (p.accumulate) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += bf2f(c[e]);
+    }
+    if (full && ((p.ldc & 3) == 0)) { bf16x4 t = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *reinterpret_cast<bf16x4*>(c) = t; }
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (n + e < p.N) c[e] = f2bf(v[e]);
+    }
+  }
+}
+
 template <int BM, int BN, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   constexpr int WM = BM / 2, WN = BN / 2;   // wave tile
@@ -162,9 +235,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   u32x4 ra[BM * 8 / 256], rb[BN * 8 / 256];
   auto gload = [&](int kt) {
@@ -213,74 +284,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   DropCtx dc;
   const bool drop = p.drop_p > 0.0f;
   if (drop) dc = make_drop(p.drop_seed, p.drop_stream, p.drop_p);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    int m = m0 + wm * WM + i * 32 + (lane & 31);
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        int n = n0 + wn * WN + j * 32 + g * 8 + (lane >> 5) * 4;
-        if (n >= p.N) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e] * p.alpha;
-        bool full = (n + 4 <= p.N);
-        if (splitk) {   // raw fp32 atomics; bias / activation are not allowed with split-K (checked on host)
-          float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) atomicAdd(c + e, v[e]);
-          continue;
-        }
-        if (p.bias) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += p.bias[min(n + e, p.N - 1)];
-        }
-        if (p.pre_out) {
-          bf16* q = p.pre_out + (size_t)m * p.ldc + n;
-          if (full) { bf16x4 t = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *reinterpret_cast<bf16x4*>(q) = t; }
-          else { for (int e = 0; e < 4; ++e) if (n + e < p.N) q[e] = f2bf(v[e]); }
-        }
-        if (p.act_in) {       // backward through an activation: multiply by act'(saved pre-activation)
-          const bf16* q = p.act_in + (size_t)m * p.ld_act + n;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= act_grad(p.act, bf2f(q[min(e, p.N - 1 - n)]));
-        } else if (p.act != PH_ACT_NONE) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = act_fwd(p.act, v[e]);
-        }
-        if (drop) {           // element index m*N+n ; N % 4 == 0 is required with dropout (checked on host)
-          u32x4 r = drop_rand4(dc, ((uint64_t)m * (uint64_t)p.N + (uint64_t)n) >> 2);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = drop_apply(dc, r[e], v[e]);
-        }
-        if (p.residual) {
-          const bf16* q = p.residual + (size_t)m * p.ldr + n;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bf2f(q[min(e, p.N - 1 - n)]);
-        }
-        if (p.out_f32) {
-          float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
-          if (p.accumulate) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += c[e];
-          }
-          if (full && ((p.ldc & 3) == 0)) { f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(c) = t; }
-          else { for (int e = 0; e < 4; ++e) if (n + e < p.N) c[e] = v[e]; }
-        } else {
-          bf16* c = reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n;
-          if (p.accumulate) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += bf2f(c[e]);
-          }
-          if (full && ((p.ldc & 3) == 0)) { bf16x4 t = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *reinterpret_cast<bf16x4*>(c) = t; }
-          else { for (int e = 0; e < 4; ++e) if (n + e < p.N) c[e] = f2bf(v[e]); }
-        }
-      }
-    }
-  }
+  // acc[][] must only ever be indexed with compile-time constants (a runtime index demotes the accumulators to
+  // scratch memory and the main loop then spills them every k-tile), so the tile loop is a static_for.
+  static_for(std::make_integer_sequence<int, TM * TN * 4>{}, [&](auto idx) {
+    constexpr int i = decltype(idx)::value / (TN * 4), j = (decltype(idx)::value / 4) % TN, g = decltype(idx)::value % 4;
+    const int m = m0 + wm * WM + i * 32 + (lane & 31);
+    const int n = n0 + wn * WN + j * 32 + g * 8 + (lane >> 5) * 4;
+    float v[4] = {acc[i][j][g * 4 + 0] * p.alpha, acc[i][j][g * 4 + 1] * p.alpha, acc[i][j][g * 4 + 2] * p.alpha,
+                  acc[i][j][g * 4 + 3] * p.alpha};
+    if (m < p.M && n < p.N) epilogue_store(p, m, n, v, splitk, drop, dc);
+  });
 }
 
 template <int BM, int BN, bool TA, bool TB>

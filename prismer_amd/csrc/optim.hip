@@ -72,6 +72,17 @@ __global__ __launch_bounds__(256) void add_kernel(const bf16* __restrict__ a, co
   if (blockIdx.x == 0 && threadIdx.x < (n & 7)) { int64_t i = (n8 << 3) + threadIdx.x; y[i] = f2bf(bf2f(a[i]) + bf2f(b[i])); }
 }
 
+__global__ __launch_bounds__(256) void act_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ pre, bf16* __restrict__ dx, int64_t n, int act) {
+  int64_t n8 = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    bf16x8 td = reinterpret_cast<const bf16x8*>(dy)[i], tp = reinterpret_cast<const bf16x8*>(pre)[i], o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(td[e]) * act_grad(act, bf2f(tp[e])));
+    reinterpret_cast<bf16x8*>(dx)[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) { int64_t i = (n8 << 3) + threadIdx.x; dx[i] = f2bf(bf2f(dy[i]) * act_grad(act, bf2f(pre[i]))); }
+}
+
 // out[n] += sum_m x[m][n] : each block owns a 64-row strip, thread t owns columns {t*8 .. t*8+7} mod pass.
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, int M, int N, int ld, float* __restrict__ out) {
   const int nch = N / 8;
@@ -213,6 +224,12 @@ extern "C" int ph_add_bf16(const void* a, const void* b, void* y, int64_t n, hip
   PH_CHECK_ARG(a && b && y && n > 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)y)) & 15) == 0, "ph_add_bf16: bad args");
   hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, stream, (const bf16*)a, (const bf16*)b, (bf16*)y, n);
   PH_LAUNCH_CHECK("add_kernel");
+  return PH_OK;
+}
+extern "C" int ph_act_bwd_bf16(const void* dy, const void* pre, void* dx, int64_t n, int act, hipStream_t stream) {
+  PH_CHECK_ARG(dy && pre && dx && n > 0 && ((((uintptr_t)dy) | ((uintptr_t)pre) | ((uintptr_t)dx)) & 15) == 0, "ph_act_bwd_bf16: bad args");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)pre, (bf16*)dx, n, act);
+  PH_LAUNCH_CHECK("act_bwd_kernel");
   return PH_OK;
 }
 extern "C" int ph_copy_rows_bf16(const void* src, int lds, ph_rowmap src_map, void* dst, int ldd, ph_rowmap dst_map, int rows,

@@ -299,6 +299,13 @@ def add(a, b, out=None):
     return out
 
 
+def act_bwd(dy, pre, act, out=None):
+    if out is None:
+        out = torch.empty_like(dy)
+    check(lib.ph_act_bwd_bf16(dy.data_ptr(), pre.data_ptr(), out.data_ptr(), dy.numel(), act, _stream()), 'ph_act_bwd_bf16')
+    return out
+
+
 def copy_rows(src, dst, rows, cols, src_map=IDENT, dst_map=IDENT, accumulate=False, src_ld=None, dst_ld=None):
     check(lib.ph_copy_rows_bf16(src.data_ptr(), src_ld or src.stride(0), src_map, dst.data_ptr(), dst_ld or dst.stride(0), dst_map,
                                 rows, cols, int(accumulate), _stream()), 'ph_copy_rows_bf16')

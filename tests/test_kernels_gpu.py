@@ -258,7 +258,7 @@ def test_attention(ops, B, H, Sq, Sk, dh, causal, masked, p):
 def test_patchify_and_resize(ops):
     img = torch.randn(2, 3, 64, 64, device='cuda')
     col = ops.patchify(img, 16, 768)
-    ref = F.unfold(img, 16, stride=16).transpose(1, 2).reshape(-1, 768)       # (c, py, px) order
+    ref = F.unfold(img, 16, stride=16).transpose(1, 2).reshape(-1, 3, 256).transpose(1, 2).reshape(-1, 768)   # (py, px, c) order
     assert rel_fro(col, ref) < 4e-3
     col14 = ops.patchify(torch.randn(1, 3, 56, 56, device='cuda'), 14, 592)
     assert col14.shape == (16, 592) and col14[:, 588:].abs().max() == 0
@@ -450,6 +450,9 @@ def test_small_utils(ops):
     assert rel_fro(out, 1 + xb.float().sum(0)) < 1e-5
     a, b = rnd(999, 8, seed=90), rnd(999, 8, seed=91)
     assert rel_fro(ops.add(a, b), a.float() + b.float()) < 4e-3
+    af = a.float().requires_grad_(True)
+    F.gelu(af).backward(b.float())
+    assert rel_fro(ops.act_bwd(b, a, 3), af.grad) < 6e-3
     from prismer_amd._lib import RowMap
     src = rnd(12, 64, seed=92)
     dst = torch.zeros(3 * 10, 64, dtype=BF, device='cuda')
