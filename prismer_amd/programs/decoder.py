@@ -1,0 +1,238 @@
+"""Layer programs (forward + hand-written backward) of the Prismer language decoder on the HIP operator set.
+
+Reference graph: RobertaForCausalLMModified.forward (model/modules/roberta.py:358-399) =
+RobertaEmbeddings (:66-76) -> 12 x [self-attn, cross-attn, Adaptor(norm_late), MLP] + output_layer (:223-231)
+-> RobertaLMHead (:421-426) -> shifted label-smoothed CE (:381-387).
+Differences in FORM (not in arithmetic): the three q/k/v nn.Linear of a self-attention run as one packed GEMM
+(their parameters are adjacent in the flat store), cross-attention k/v likewise; every
+`LayerNorm(dropout(dense(x)) + residual)` is a GEMM with a fused bias+dropout+residual epilogue followed by the
+LayerNorm kernel; logits live in a [B*T, Vpad] bf16 buffer (Vpad = vocab rounded up to 64) and the backward
+overwrites it with dlogits.
+"""
+import torch
+
+from .. import ops
+from .._lib import ACT_GELU, ACT_RELU2
+from .encoder import LN, Linear
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+class DecoderProgram:
+    def __init__(self, module, dims, store):
+        self.mod, self.d, self.P = module, dims, store
+        d, P = dims, store
+        H, Hv = d.hidden_size, d.vision_hidden_size
+        eps = d.layer_norm_eps
+        self.Vpad = (d.vocab_size + 63) // 64 * 64
+
+        def self_attn(p):
+            return dict(qkv=Linear(P, p + 'self.query.weight', p + 'self.query.bias', rows=3 * H, cols=H),
+                        out=Linear(P, p + 'output.dense.weight', p + 'output.dense.bias'), ln=LN(P, p + 'output.LayerNorm', eps))
+
+        def mlp(p):
+            return dict(inter=Linear(P, p + 'intermediate.dense.weight', p + 'intermediate.dense.bias'),
+                        out=Linear(P, p + 'output.dense.weight', p + 'output.dense.bias'), ln=LN(P, p + 'output.LayerNorm', eps))
+
+        self.layers = []
+        for l in range(d.num_hidden_layers):
+            p = f'roberta.encoder.layer.{l}.'
+            self.layers.append(dict(
+                idx=l, sa=self_attn(p + '0.attention.'), mlp=mlp(p + '0.'),
+                ca=dict(q=Linear(P, p + '1.self.query.weight', p + '1.self.query.bias'),
+                        kv=Linear(P, p + '1.self.key.weight', p + '1.self.key.bias', rows=2 * H, cols=Hv),
+                        out=Linear(P, p + '1.output.dense.weight', p + '1.output.dense.bias'), ln=LN(P, p + '1.output.LayerNorm', eps)),
+                ad=dict(down=Linear(P, p + '2.adaptor.down_proj.weight', p + '2.adaptor.down_proj.bias'),
+                        up=Linear(P, p + '2.adaptor.up_proj.weight', p + '2.adaptor.up_proj.bias'), ln=LN(P, p + '2.adaptor_ln', 1e-5))))
+        p = 'roberta.encoder.output_layer.'
+        self.final = dict(idx=d.num_hidden_layers, sa=self_attn(p + 'attention.'), mlp=mlp(p))
+        self.head_dense = Linear(P, 'lm_head.dense.weight', 'lm_head.dense.bias')
+        self.head_ln = LN(P, 'lm_head.layer_norm', eps)
+        self.emb_ln = LN(P, 'roberta.embeddings.LayerNorm', eps)
+        # the q/k/v packing relies on adjacency in the flat store
+        o = P.offset
+        n = 'roberta.encoder.output_layer.attention.self.'
+        assert o[n + 'key.weight'] - o[n + 'query.weight'] == H * H and o[n + 'value.weight'] - o[n + 'key.weight'] == H * H
+        assert o[n + 'key.bias'] - o[n + 'query.bias'] == H, 'q/k/v biases must be adjacent (H % 64 == 0 required)'
+
+    def drop(self, site, p, seed):
+        return ops.Dropout(p, seed, site) if (seed is not None and p > 0.0) else None
+
+    # ---------------------------------------------------------------------------------------- sub-blocks
+    def self_attn_fwd(self, blk, li, h, B, T, key_mask, seed, sv):
+        d = self.d
+        H, nh = d.hidden_size, d.num_attention_heads
+        dh = H // nh
+        qkv = blk['qkv'].fwd(h)
+        st = (T * 3 * H, 3 * H)
+        dr_a = self.drop(li * 16 + 1, d.attention_probs_dropout_prob, seed)
+        o, lse = ops.attention_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, nh, T, T, dh, q_strides=st, k_strides=st, v_strides=st,
+                                   key_mask=key_mask, causal=True, drop=dr_a)
+        dr_h = self.drop(li * 16 + 2, d.hidden_dropout_prob, seed)
+        s = blk['out'].fwd(o, drop=dr_h, residual=h)
+        y, m, r = blk['ln'].fwd(s)
+        if sv is not None:
+            sv.append(dict(h=h, qkv=qkv, o=o, lse=lse, s=s, m=m, r=r, dr_a=dr_a, dr_h=dr_h))
+        return y
+
+    def self_attn_bwd(self, blk, s, dy, B, T, key_mask):
+        d = self.d
+        H, nh = d.hidden_size, d.num_attention_heads
+        dh = H // nh
+        ds, dsd = blk['ln'].bwd(dy, s['s'], s['m'], s['r'], drop=s['dr_h'])
+        do = blk['out'].dgrad(dsd)
+        blk['out'].wgrad(dsd, s['o'])
+        qkv = s['qkv']
+        dqkv = torch.empty_like(qkv)
+        st = (T * 3 * H, 3 * H)
+        ops.attention_bwd(do, qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], s['o'], s['lse'], B, nh, T, T, dh, q_strides=st, k_strides=st,
+                          v_strides=st, dq=dqkv[:, :H], dk=dqkv[:, H:2 * H], dv=dqkv[:, 2 * H:], dq_strides=st, dk_strides=st, dv_strides=st,
+                          key_mask=key_mask, causal=True, drop=s['dr_a'])
+        blk['qkv'].wgrad(dqkv, s['h'])
+        return blk['qkv'].dgrad(dqkv, residual=ds)
+
+    def cross_attn_fwd(self, blk, li, h, enc, B, T, S, seed, sv):
+        d = self.d
+        H, nh = d.hidden_size, d.num_attention_heads
+        dh = H // nh
+        q = blk['q'].fwd(h)
+        kv = blk['kv'].fwd(enc)
+        ks = (S * 2 * H, 2 * H)
+        dr_a = self.drop(li * 16 + 3, d.attention_probs_dropout_prob, seed)
+        o, lse = ops.attention_fwd(q, kv[:, :H], kv[:, H:], B, nh, T, S, dh, q_strides=(T * H, H), k_strides=ks, v_strides=ks, drop=dr_a)
+        dr_h = self.drop(li * 16 + 4, d.hidden_dropout_prob, seed)
+        s = blk['out'].fwd(o, drop=dr_h, residual=h)
+        y, m, r = blk['ln'].fwd(s)
+        if sv is not None:
+            sv.append(dict(h=h, q=q, kv=kv, o=o, lse=lse, s=s, m=m, r=r, dr_a=dr_a, dr_h=dr_h))
+        return y
+
+    def cross_attn_bwd(self, blk, s, dy, enc, denc, B, T, S):
+        d = self.d
+        H, nh = d.hidden_size, d.num_attention_heads
+        dh = H // nh
+        ds, dsd = blk['ln'].bwd(dy, s['s'], s['m'], s['r'], drop=s['dr_h'])
+        do = blk['out'].dgrad(dsd)
+        blk['out'].wgrad(dsd, s['o'])
+        dq = torch.empty_like(s['q'])
+        dkv = torch.empty_like(s['kv'])
+        ks = (S * 2 * H, 2 * H)
+        ops.attention_bwd(do, s['q'], s['kv'][:, :H], s['kv'][:, H:], s['o'], s['lse'], B, nh, T, S, dh, q_strides=(T * H, H), k_strides=ks,
+                          v_strides=ks, dq=dq, dk=dkv[:, :H], dv=dkv[:, H:], dq_strides=(T * H, H), dk_strides=ks, dv_strides=ks,
+                          drop=s['dr_a'])
+        blk['q'].wgrad(dq, s['h'])
+        blk['kv'].wgrad(dkv, enc)
+        blk['kv'].dgrad(dkv, out=denc, out_f32=True, accumulate=True)     # 12 layers accumulate in fp32
+        return blk['q'].dgrad(dq, residual=ds)
+
+    def adaptor_fwd(self, blk, h, sv):
+        dpre = torch.empty_like(h)
+        dact = blk['down'].fwd(h, act=ACT_RELU2, pre_out=dpre)
+        s = blk['up'].fwd(dact, residual=h)
+        y, m, r = blk['ln'].fwd(s)                                       # norm_late (utils.py:61-62)
+        if sv is not None:
+            sv.append(dict(h=h, dpre=dpre, dact=dact, s=s, m=m, r=r))
+        return y
+
+    def adaptor_bwd(self, blk, s, dy):
+        ds, _ = blk['ln'].bwd(dy, s['s'], s['m'], s['r'])
+        ddpre = blk['up'].dgrad(ds, act=ACT_RELU2, act_in=s['dpre'])
+        blk['up'].wgrad(ds, s['dact'])
+        blk['down'].wgrad(ddpre, s['h'])
+        return blk['down'].dgrad(ddpre, residual=ds)
+
+    def mlp_fwd(self, blk, li, h, seed, sv):
+        d = self.d
+        ipre = torch.empty(h.shape[0], d.intermediate_size, dtype=BF16, device=h.device)
+        iact = blk['inter'].fwd(h, act=ACT_GELU, pre_out=ipre)
+        dr_h = self.drop(li * 16 + 5, d.hidden_dropout_prob, seed)
+        s = blk['out'].fwd(iact, drop=dr_h, residual=h)
+        y, m, r = blk['ln'].fwd(s)
+        if sv is not None:
+            sv.append(dict(h=h, ipre=ipre, iact=iact, s=s, m=m, r=r, dr_h=dr_h))
+        return y
+
+    def mlp_bwd(self, blk, s, dy):
+        ds, dsd = blk['ln'].bwd(dy, s['s'], s['m'], s['r'], drop=s['dr_h'])
+        dipre = blk['out'].dgrad(dsd, act=ACT_GELU, act_in=s['ipre'])
+        blk['out'].wgrad(dsd, s['iact'])
+        blk['inter'].wgrad(dipre, s['h'])
+        return blk['inter'].dgrad(dipre, residual=ds)
+
+    # ---------------------------------------------------------------------------------------- whole decoder
+    def forward(self, input_ids, attention_mask, enc, labels, seed, save, want_logits=True):
+        """enc: [B, S, Hv] bf16 contiguous. seed: int64[1] device tensor or None (no dropout = eval mode).
+        Returns (logits_buf [B*T, Vpad] bf16, loss [B] fp32 or None, saved)."""
+        d, P = self.d, self.P
+        B, T = input_ids.shape
+        S = enc.shape[1]
+        H = d.hidden_size
+        e = 'roberta.embeddings.'
+        input_ids = input_ids.contiguous()
+        key_mask = None
+        if attention_mask is not None:
+            key_mask = (attention_mask != 0).to(torch.uint8).contiguous()
+        enc2 = enc.reshape(B * S, enc.shape[2])
+        sv = [] if save else None
+        dr_e = self.drop(9000, d.hidden_dropout_prob, seed)
+        h, xhat, erstd = ops.embed_fwd(input_ids, P.f(e + 'word_embeddings.weight'), P.f(e + 'position_embeddings.weight'),
+                                       P.f(e + 'token_type_embeddings.weight'), P.f(e + 'LayerNorm.weight'), P.f(e + 'LayerNorm.bias'),
+                                       d.layer_norm_eps, d.pad_token_id, dr_e)
+        for L in self.layers:
+            h = self.self_attn_fwd(L['sa'], L['idx'], h, B, T, key_mask, seed, sv)
+            h = self.cross_attn_fwd(L['ca'], L['idx'], h, enc2, B, T, S, seed, sv)
+            h = self.adaptor_fwd(L['ad'], h, sv)
+            h = self.mlp_fwd(L['mlp'], L['idx'], h, seed, sv)
+        F_ = self.final
+        h = self.self_attn_fwd(F_['sa'], F_['idx'], h, B, T, key_mask, seed, sv)
+        h = self.mlp_fwd(F_['mlp'], F_['idx'], h, seed, sv)
+        t0pre = torch.empty_like(h)
+        t0 = self.head_dense.fwd(h, act=ACT_GELU, pre_out=t0pre)
+        t1, hm, hr = self.head_ln.fwd(t0)
+        V = d.vocab_size
+        logits = torch.empty(B * T, self.Vpad, dtype=BF16, device=h.device)
+        ops.gemm(t1, P.w(e + 'word_embeddings.weight'), out=logits, bias=P.f('lm_head.bias'), N=V)      # tied decoder weight
+        loss = row_lse = None
+        if labels is not None:
+            labels = labels.contiguous()
+            loss, row_lse = ops.ce_fwd(logits, labels, B, T, V, d.label_smoothing)
+        saved = None
+        if save:
+            saved = dict(blocks=sv, B=B, T=T, S=S, ids=input_ids, key_mask=key_mask, enc=enc2, xhat=xhat, erstd=erstd, dr_e=dr_e, hL=h,
+                         t0pre=t0pre, t0=t0, t1=t1, hm=hm, hr=hr, logits=logits, labels=labels, row_lse=row_lse)
+        return logits, loss, saved
+
+    def backward(self, sv, dloss):
+        """dloss: fp32 [B] gradient of the per-sample losses. Returns d(enc) as bf16 [B, S, Hv]."""
+        d, P = self.d, self.P
+        B, T, S = sv['B'], sv['T'], sv['S']
+        V = d.vocab_size
+        e = 'roberta.embeddings.'
+        dlogits = ops.ce_bwd(sv['logits'], sv['labels'], B, T, V, d.label_smoothing, sv['row_lse'], dloss.contiguous())
+        wname = e + 'word_embeddings.weight'
+        gw = P.g(wname)
+        if gw is not None:
+            ops.gemm(dlogits, sv['t1'], out=gw, trans_a=True, trans_b=True, out_f32=True, accumulate=True, M=V, N=d.hidden_size, K=B * T)
+        gb = P.g('lm_head.bias')
+        if gb is not None:
+            ops.colsum(dlogits, gb, N=V)
+        dt1 = ops.gemm(dlogits, P.w(wname), trans_b=True, K=V)            # [B*T, H]
+        dt0, _ = self.head_ln.bwd(dt1, sv['t0'], sv['hm'], sv['hr'])
+        dt0pre = ops.act_bwd(dt0, sv['t0pre'], ACT_GELU)
+        self.head_dense.wgrad(dt0pre, sv['hL'])
+        dh = self.head_dense.dgrad(dt0pre)
+        blocks = list(sv['blocks'])
+        denc = torch.zeros(B * S, d.vision_hidden_size, dtype=F32, device=dh.device)
+        F_ = self.final
+        dh = self.mlp_bwd(F_['mlp'], blocks.pop(), dh)
+        dh = self.self_attn_bwd(F_['sa'], blocks.pop(), dh, B, T, sv['key_mask'])
+        for L in reversed(self.layers):
+            dh = self.mlp_bwd(L['mlp'], blocks.pop(), dh)
+            dh = self.adaptor_bwd(L['ad'], blocks.pop(), dh)
+            dh = self.cross_attn_bwd(L['ca'], blocks.pop(), dh, sv['enc'], denc, B, T, S)
+            dh = self.self_attn_bwd(L['sa'], blocks.pop(), dh, B, T, sv['key_mask'])
+        ops.embed_bwd(dh, sv['ids'], P.f(wname), P.f(e + 'position_embeddings.weight'), P.f(e + 'token_type_embeddings.weight'),
+                      P.f(e + 'LayerNorm.weight'), P.f(e + 'LayerNorm.bias'), d.layer_norm_eps, d.pad_token_id, sv['xhat'], sv['erstd'],
+                      sv['dr_e'], P.g(wname), P.g(e + 'position_embeddings.weight'), P.g(e + 'token_type_embeddings.weight'),
+                      P.g(e + 'LayerNorm.weight'), P.g(e + 'LayerNorm.bias'))
+        return ops.cast_to_bf16(denc).view(B, S, d.vision_hidden_size)

@@ -1,0 +1,398 @@
+"""Layer programs (forward + hand-written backward) of the Prismer vision side on the HIP operator set.
+
+What the reference expresses as an nn.Module graph walked by autograd
+  VisionTransformer.forward        model/modules/vit.py:133-172
+  expert stems                     vit.py:88-120
+  PerceiverResampler               model/modules/resampler.py:33-52
+  Transformer / Adaptor            vit.py:70-75, model/modules/utils.py:48-65
+is here a straight-line program of C-ABI kernel launches; the backward program replays the saved activations in
+reverse and writes weight gradients directly into the flat fp32 gradient buffer (prismer_amd/store.py).
+Internal activation layout is batch-major [B*tokens, D] bf16; the [S, B, D] view the reference returns is a
+permuted view of the final buffer.
+"""
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+from .._lib import ACT_QUICKGELU, ACT_RELU2, IDENT, RowMap
+from ..config import LABEL_DOMAINS
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+class Linear:
+    """y = act(x W^T + b) bookkeeping shared by all programs: forward GEMM, dgrad GEMM, wgrad GEMM + bias colsum."""
+
+    def __init__(self, P, wname, bname=None, rows=None, cols=None):
+        self.P, self.wname, self.bname = P, wname, bname
+        shp = P.shape[wname]
+        self.rows = rows or shp[0]
+        self.cols = cols or shp[1]
+
+    @property
+    def w(self):
+        return self.P.w2(self.wname, self.rows, self.cols)
+
+    @property
+    def b(self):
+        return self.P.fvec(self.bname, self.rows) if self.bname else None
+
+    def fwd(self, x, **kw):
+        return ops.gemm(x, self.w, bias=self.b, **kw)
+
+    def dgrad(self, dy, **kw):
+        """dx = dy . W   (W stored [out][in] = K-strided operand)"""
+        return ops.gemm(dy, self.w, trans_b=True, N=self.cols, K=self.rows, **kw)
+
+    def wgrad(self, dy, x):
+        gw = self.P.g2(self.wname, self.rows, self.cols)
+        if gw is not None:
+            ops.gemm(dy, x, out=gw, trans_a=True, trans_b=True, out_f32=True, accumulate=True, M=self.rows, N=self.cols, K=dy.shape[0])
+        if self.bname:
+            gb = self.P.gvec(self.bname, self.rows)
+            if gb is not None:
+                ops.colsum(dy, gb, N=self.rows)
+
+
+class LN:
+    def __init__(self, P, prefix, eps=1e-5):
+        self.P, self.wn, self.bn, self.eps = P, prefix + '.weight', prefix + '.bias', eps
+
+    def fwd(self, x, **kw):
+        return ops.layernorm_fwd(x, self.P.f(self.wn), self.P.f(self.bn), self.eps, **kw)
+
+    def bwd(self, dy, x, mean, rstd, **kw):
+        return ops.layernorm_bwd(dy, x, mean, rstd, self.P.f(self.wn), dgamma=self.P.g(self.wn), dbeta=self.P.g(self.bn), **kw)
+
+
+class EncoderProgram:
+    def __init__(self, module, dims, store):
+        self.mod, self.d, self.P = module, dims, store
+        d, P = dims, store
+        W = d.width
+        self.Kp_rgb = _rup(3 * d.patch_size ** 2, 8)
+        self.experts = [e for e in d.experts if e != 'rgb']
+        self.blocks = []
+        for l in range(d.vit_layers):
+            p = f'transformer.resblocks.{l}.'
+            self.blocks.append(dict(
+                ln_1=LN(P, p + '0.ln_1'), ln_2=LN(P, p + '0.ln_2'), aln=LN(P, p + '1.adaptor_ln'),
+                qkv=Linear(P, p + '0.attn.in_proj_weight', p + '0.attn.in_proj_bias'),
+                out=Linear(P, p + '0.attn.out_proj.weight', p + '0.attn.out_proj.bias'),
+                down=Linear(P, p + '1.adaptor.down_proj.weight', p + '1.adaptor.down_proj.bias'),
+                up=Linear(P, p + '1.adaptor.up_proj.weight', p + '1.adaptor.up_proj.bias'),
+                fc=Linear(P, p + '0.mlp.c_fc.weight', p + '0.mlp.c_fc.bias'),
+                proj=Linear(P, p + '0.mlp.c_proj.weight', p + '0.mlp.c_proj.bias')))
+        self.rblocks = []
+        if d.has_experts:
+            for l in range(d.resampler_layers):
+                p = f'resampler.perceiver_blocks.{l}.'
+                self.rblocks.append(dict(
+                    ln_1=LN(P, p + 'ln_1'), ln_2=LN(P, p + 'ln_2'), ln_ff=LN(P, p + 'ln_ff'),
+                    out=Linear(P, p + 'attn.out_proj.weight', p + 'attn.out_proj.bias'),
+                    fc=Linear(P, p + 'mlp.c_fc.weight', p + 'mlp.c_fc.bias'),
+                    proj=Linear(P, p + 'mlp.c_proj.weight', p + 'mlp.c_proj.bias'),
+                    inw=p + 'attn.in_proj_weight', inb=p + 'attn.in_proj_bias'))
+        self.ln_pre, self.ln_post = LN(P, 'ln_pre'), LN(P, 'ln_post')
+        self._taps = None
+
+    # ---------------------------------------------------------------------------------------- conv weight shadows
+    def conv_shadow(self, name, ks):
+        Co, Ci = self.P.shape[name][0], self.P.shape[name][1]
+        Kp = _rup(ks * ks * Ci, 8)
+        return self.P.derived_buffer(name, (Co, Kp), lambda t: ops.conv_weight_to_shadow(self.P.f(name), t, Co, Ci, ks, Kp)), Kp
+
+    def conv_wgrad(self, name, ks, dy, col):
+        """dW (shadow layout [Cout, Kp], fp32) = dy^T . col, folded back into the [Cout,Cin,k,k] gradient."""
+        g = self.P.g(name)
+        if g is None:
+            return
+        Co, Ci = self.P.shape[name][0], self.P.shape[name][1]
+        Kp = col.shape[1]
+        if ks == 1 and Kp == Ci:
+            ops.gemm(dy, col, out=g.view(Co, Ci), trans_a=True, trans_b=True, out_f32=True, accumulate=True, M=Co, N=Kp, K=dy.shape[0])
+            return
+        ds = ops.gemm(dy, col, trans_a=True, trans_b=True, out_f32=True, M=Co, N=Kp, K=dy.shape[0])
+        ops.conv_grad_from_shadow(ds, g, Co, Ci, ks, Kp)
+
+    # ---------------------------------------------------------------------------------------- positional embedding
+    def expert_pos(self):
+        """vit.py:157 / utils.py:34-44: bicubic (align_corners=False) re-grid when the expert grid differs from the rgb
+        grid.  The interpolation is linear in the table: out = sum_t w[i,t] * pos[idx[i,t]] with <= 16 taps."""
+        d = self.d
+        pos = self.P.f('positional_embedding')
+        if d.expert_grid == d.rgb_grid:
+            return pos
+        if self._taps is None:
+            n, g = d.rgb_grid, d.expert_grid
+            eye = torch.eye(n * n).reshape(1, n * n, n, n)           # basis images (host, once)
+            Wm = F.interpolate(eye, size=(g, g), mode='bicubic', align_corners=False).reshape(n * n, g * g).t()
+            w, idx = torch.topk(Wm.abs(), 16, dim=1)
+            w = torch.gather(Wm, 1, idx)
+            self._taps = (idx.to(torch.int32).contiguous().to(pos.device), w.contiguous().to(pos.device))
+        idx, w = self._taps
+        return ops.gather_taps(pos, idx, w, d.expert_grid ** 2, 16, d.width)
+
+    def expert_pos_bwd(self, dpos_e):
+        d = self.d
+        g = self.P.g('positional_embedding')
+        if g is None or d.expert_grid == d.rgb_grid:
+            return
+        idx, w = self._taps
+        ops.scatter_taps(dpos_e, g, idx, w, d.expert_grid ** 2, 16, d.width)
+
+    # ---------------------------------------------------------------------------------------- expert stems
+    def stem_fwd(self, dom, x, training, sv):
+        d = self.d
+        B, Cin = x.shape[0], x.shape[1]
+        label = dom in LABEL_DOMAINS
+        Hs = int(d.expert_resolution * (4 if label else 16) / d.patch_size)
+        strides = (2, 2, 1, 1) if label else (2, 2, 2, 2)
+        a = ops.resize_to_nhwc(x, Hs, Hs)
+        seq = self.mod.conv1[dom]
+        H, C = Hs, Cin
+        scale = shift = None
+        cols, ys, stats, geo = [], [], [], []
+        for i, s in enumerate(strides):
+            wname = f'conv1.{dom}.{1 + 3 * i}.weight'
+            shadow, Kp = self.conv_shadow(wname, 3)
+            col = ops.im2col(a, B, H, H, C, 3, s, Kp, scale, shift)
+            y = ops.gemm(col, shadow)
+            bn = seq[2 + 3 * i]
+            st = ops.bn_stats(y, self.P.f(f'conv1.{dom}.{2 + 3 * i}.weight'), self.P.f(f'conv1.{dom}.{2 + 3 * i}.bias'),
+                              bn.running_mean, bn.running_var, training, bn.momentum, bn.eps)
+            if training:
+                bn.num_batches_tracked += 1
+            geo.append((H, C, s, Kp))
+            H = ops.conv_out_size(H, 3, s)
+            C = y.shape[1]
+            cols.append(col); ys.append(y); stats.append(st)
+            a, scale, shift = y, st[2], st[3]
+        shadow, Kp = self.conv_shadow(f'conv1.{dom}.13.weight', 1)
+        col = ops.im2col(a, B, H, H, C, 1, 1, Kp, scale, shift)          # relu(bn(y_3)) materialised once
+        feat = ops.gemm(col, shadow)
+        if sv is not None:
+            sv[dom] = dict(cols=cols, ys=ys, stats=stats, geo=geo, col_last=col, B=B, Hlast=H)
+        return feat
+
+    def stem_bwd(self, dom, dfeat, sv):
+        s = sv[dom]
+        B = s['B']
+        w13 = f'conv1.{dom}.13.weight'
+        self.conv_wgrad(w13, 1, dfeat, s['col_last'])
+        shadow, _ = self.conv_shadow(w13, 1)
+        da = ops.gemm(dfeat, shadow, trans_b=True)                       # grad wrt relu(bn(y_3))
+        for i in (3, 2, 1, 0):
+            H, C, stride, Kp = s['geo'][i]
+            gname, bname = f'conv1.{dom}.{2 + 3 * i}.weight', f'conv1.{dom}.{2 + 3 * i}.bias'
+            dy = ops.bn_relu_bwd(da, s['ys'][i], self.P.f(gname), self.P.f(bname), s['stats'][i], self.P.g(gname), self.P.g(bname))
+            wname = f'conv1.{dom}.{1 + 3 * i}.weight'
+            self.conv_wgrad(wname, 3, dy, s['cols'][i])
+            if i > 0:
+                shadow, _ = self.conv_shadow(wname, 3)
+                dcol = ops.gemm(dy, shadow, trans_b=True)
+                da = ops.col2im(dcol, B, H, H, C, 3, stride, Kp)
+
+    # ---------------------------------------------------------------------------------------- resampler
+    def resampler_fwd(self, xf, B, h, sv):
+        """resampler.py:46-52; writes the 64 latents of every image into rows [b*S + N + l] of h."""
+        d, P = self.d, self.P
+        W, L, Mx = d.width, d.num_latents, d.num_expert_tokens
+        KV = L + Mx
+        H = d.resampler_heads
+        dh = W // H
+        lat = torch.empty(B * L, W, dtype=BF16, device=xf.device)
+        ops.copy_rows(P.w('resampler.latents'), lat, B * L, W, src_map=RowMap(L, 0, 0))       # repeat 'l d -> l b d'
+        layers = []
+        for blk in self.rblocks:
+            kvin = torch.empty(B * KV, W, dtype=BF16, device=xf.device)
+            qin = torch.empty(B * L, W, dtype=BF16, device=xf.device)
+            _, m1, r1 = blk['ln_1'].fwd(lat, out=kvin, out_map=RowMap(L, KV, 0), out2=qin)
+            _, m2, r2 = blk['ln_2'].fwd(xf, out=kvin, out_map=RowMap(Mx, KV, L))
+            q = ops.gemm(qin, P.w2(blk['inw'], W, W), bias=P.fvec(blk['inb'], W))
+            kv = ops.gemm(kvin, P.w2(blk['inw'], 3 * W, W)[W:], bias=P.fvec(blk['inb'], 3 * W)[W:])
+            ks = (KV * 2 * W, 2 * W)
+            o, lse = ops.attention_fwd(q, kv[:, :W], kv[:, W:], B, H, L, KV, dh, q_strides=(L * W, W), k_strides=ks, v_strides=ks)
+            lat1 = blk['out'].fwd(o, residual=lat)
+            f, m3, r3 = blk['ln_ff'].fwd(lat1)
+            hpre = torch.empty(B * L, 4 * W, dtype=BF16, device=xf.device)
+            hact = blk['fc'].fwd(f, act=ACT_RELU2, pre_out=hpre)
+            lat2 = blk['proj'].fwd(hact, residual=lat1)
+            layers.append(dict(lat=lat, kvin=kvin, qin=qin, m1=m1, r1=r1, m2=m2, r2=r2, q=q, kv=kv, o=o, lse=lse, lat1=lat1, f=f,
+                               m3=m3, r3=r3, hpre=hpre, hact=hact))
+            lat = lat2
+        ops.copy_rows(lat, h, B * L, W, dst_map=RowMap(L, d.seq_len, d.num_rgb_tokens))
+        if sv is not None:
+            sv['resampler'] = layers
+            sv['xf'] = xf
+
+    def resampler_bwd(self, dlat, B, sv):
+        d, P = self.d, self.P
+        W, L, Mx = d.width, d.num_latents, d.num_expert_tokens
+        KV = L + Mx
+        H = d.resampler_heads
+        dh = W // H
+        xf = sv['xf']
+        dxf = None
+        for blk, s in zip(reversed(self.rblocks), reversed(sv['resampler'])):
+            dhpre = blk['proj'].dgrad(dlat, act=ACT_RELU2, act_in=s['hpre'])
+            blk['proj'].wgrad(dlat, s['hact'])
+            blk['fc'].wgrad(dhpre, s['f'])
+            df = blk['fc'].dgrad(dhpre)
+            dlat1, _ = blk['ln_ff'].bwd(df, s['lat1'], s['m3'], s['r3'], dskip=dlat)
+            do = blk['out'].dgrad(dlat1)
+            blk['out'].wgrad(dlat1, s['o'])
+            dq = torch.empty_like(s['q'])
+            dkv = torch.empty_like(s['kv'])
+            ks = (KV * 2 * W, 2 * W)
+            ops.attention_bwd(do, s['q'], s['kv'][:, :W], s['kv'][:, W:], s['o'], s['lse'], B, H, L, KV, dh, q_strides=(L * W, W),
+                              k_strides=ks, v_strides=ks, dq=dq, dk=dkv[:, :W], dv=dkv[:, W:], dq_strides=(L * W, W), dk_strides=ks,
+                              dv_strides=ks)
+            wq, wkv = P.w2(blk['inw'], W, W), P.w2(blk['inw'], 3 * W, W)[W:]
+            gw = P.g2(blk['inw'], 3 * W, W)
+            if gw is not None:
+                ops.gemm(dq, s['qin'], out=gw[:W], trans_a=True, trans_b=True, out_f32=True, accumulate=True, M=W, N=W, K=B * L)
+                ops.gemm(dkv, s['kvin'], out=gw[W:], trans_a=True, trans_b=True, out_f32=True, accumulate=True, M=2 * W, N=W, K=B * KV)
+                gb = P.gvec(blk['inb'], 3 * W)
+                ops.colsum(dq, gb[:W])
+                ops.colsum(dkv, gb[W:])
+            dqin = ops.gemm(dq, wq, trans_b=True)
+            dkvin = ops.gemm(dkv, wkv, trans_b=True)
+            dlat, _ = blk['ln_1'].bwd(dqin, s['lat'], s['m1'], s['r1'], dy2=dkvin, dy2_map=RowMap(L, KV, 0), dskip=dlat1)
+            dxf, _ = blk['ln_2'].bwd(dkvin, xf, s['m2'], s['r2'], dy_map=RowMap(Mx, KV, L), dskip=dxf)
+        g = P.g('resampler.latents')
+        if g is not None:                                                # sum over the batch of d(repeat(latents))
+            ops.colsum(dlat.view(B, L * W), g.view(-1))
+        return dxf
+
+    # ---------------------------------------------------------------------------------------- ViT blocks
+    def block_fwd(self, blk, x, B, S, sv_list):
+        d = self.d
+        W, H = d.width, d.vit_heads
+        dh = W // H
+        a, m1, r1 = blk['ln_1'].fwd(x)
+        qkv = blk['qkv'].fwd(a)
+        st = (S * 3 * W, 3 * W)
+        o, lse = ops.attention_fwd(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], B, H, S, S, dh, q_strides=st, k_strides=st, v_strides=st)
+        x1 = blk['out'].fwd(o, residual=x)
+        b_, m2, r2 = blk['aln'].fwd(x1)                                   # Adaptor, pre-norm (utils.py:63-64)
+        dpre = torch.empty_like(b_)
+        dact = blk['down'].fwd(b_, act=ACT_RELU2, pre_out=dpre)
+        x2 = blk['up'].fwd(dact, residual=x1)
+        c, m3, r3 = blk['ln_2'].fwd(x2)
+        fpre = torch.empty(x.shape[0], 4 * W, dtype=BF16, device=x.device)
+        fact = blk['fc'].fwd(c, act=ACT_QUICKGELU, pre_out=fpre)
+        x3 = blk['proj'].fwd(fact, residual=x2)
+        if sv_list is not None:
+            sv_list.append(dict(x=x, a=a, m1=m1, r1=r1, qkv=qkv, o=o, lse=lse, x1=x1, b=b_, m2=m2, r2=r2, dpre=dpre, dact=dact, x2=x2,
+                                c=c, m3=m3, r3=r3, fpre=fpre, fact=fact))
+        return x3
+
+    def block_bwd(self, blk, s, dx3, B, S):
+        d = self.d
+        W, H = d.width, d.vit_heads
+        dh = W // H
+        dfpre = blk['proj'].dgrad(dx3, act=ACT_QUICKGELU, act_in=s['fpre'])
+        blk['proj'].wgrad(dx3, s['fact'])
+        blk['fc'].wgrad(dfpre, s['c'])
+        dc = blk['fc'].dgrad(dfpre)
+        dx2, _ = blk['ln_2'].bwd(dc, s['x2'], s['m3'], s['r3'], dskip=dx3)
+        ddpre = blk['up'].dgrad(dx2, act=ACT_RELU2, act_in=s['dpre'])
+        blk['up'].wgrad(dx2, s['dact'])
+        blk['down'].wgrad(ddpre, s['b'])
+        db = blk['down'].dgrad(ddpre)
+        dx1, _ = blk['aln'].bwd(db, s['x1'], s['m2'], s['r2'], dskip=dx2)
+        do = blk['out'].dgrad(dx1)
+        blk['out'].wgrad(dx1, s['o'])
+        dqkv = torch.empty_like(s['qkv'])
+        st = (S * 3 * W, 3 * W)
+        qkv = s['qkv']
+        ops.attention_bwd(do, qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], s['o'], s['lse'], B, H, S, S, dh, q_strides=st, k_strides=st,
+                          v_strides=st, dq=dqkv[:, :W], dk=dqkv[:, W:2 * W], dv=dqkv[:, 2 * W:], dq_strides=st, dk_strides=st, dv_strides=st)
+        blk['qkv'].wgrad(dqkv, s['a'])
+        da = blk['qkv'].dgrad(dqkv)
+        dx, _ = blk['ln_1'].bwd(da, s['x'], s['m1'], s['r1'], dskip=dx1)
+        return dx
+
+    # ---------------------------------------------------------------------------------------- whole encoder
+    def forward(self, x, inst_table, training, save):
+        d, P = self.d, self.P
+        W, p = d.width, d.patch_size
+        rgb = x['rgb']
+        B = rgb.shape[0]
+        N, S = d.num_rgb_tokens, d.seq_len
+        dev = rgb.device
+        sv = {} if save else None
+        h = torch.empty(B * S, W, dtype=BF16, device=dev)
+        col = ops.patchify(rgb.contiguous().float(), p, self.Kp_rgb)
+        shadow, _ = self.conv_shadow('conv1.rgb.weight', p)
+        feat = ops.gemm(col, shadow)
+        ops.tokens_finalize(feat, P.f('positional_embedding'), h, B, N, W, S, 0)
+        names = [k for k in x if k != 'rgb']
+        if names:
+            G = d.expert_grid ** 2
+            Mx = len(names) * G
+            assert Mx == d.num_expert_tokens, 'expert dict does not match the configured experts'
+            xf = torch.empty(B * Mx, W, dtype=BF16, device=dev)
+            pos_e = self.expert_pos()
+            for ei, name in enumerate(names):
+                dom = 'seg' if 'seg' in name else name
+                val = x[name]
+                inp = val['label'] if name == 'obj_detection' else val
+                f = self.stem_fwd(dom, inp.contiguous().float(), training, sv)
+                if name == 'obj_detection':
+                    inst = val['instance'].contiguous()
+                    ops.tokens_finalize(f, pos_e, xf, B, G, W, Mx, ei * G, inst, inst.shape[-1], d.expert_grid, inst_table,
+                                        P.f('instance_embedding'))
+                else:
+                    ops.tokens_finalize(f, pos_e, xf, B, G, W, Mx, ei * G)
+            self.resampler_fwd(xf, B, h, sv)
+        h0, mp, rp = self.ln_pre.fwd(h)
+        blocks_sv = [] if save else None
+        t = h0
+        for blk in self.blocks:
+            t = self.block_fwd(blk, t, B, S, blocks_sv)
+        out, mo, ro = self.ln_post.fwd(t)
+        if save:
+            sv.update(B=B, names=names, rgb_col=col, h=h, mp=mp, rp=rp, blocks=blocks_sv, t=t, mo=mo, ro=ro,
+                      inst=(x['obj_detection']['instance'].contiguous() if 'obj_detection' in x else None), inst_table=inst_table)
+        return out.view(B, S, W), sv
+
+    def backward(self, sv, dout):
+        """dout: [B, S, W] bf16 (batch-major). Accumulates every trainable gradient into the store's buffer."""
+        d, P = self.d, self.P
+        W = d.width
+        B, S, N = sv['B'], d.seq_len, d.num_rgb_tokens
+        dt, _ = self.ln_post.bwd(dout.reshape(B * S, W), sv['t'], sv['mo'], sv['ro'])
+        for blk, s in zip(reversed(self.blocks), reversed(sv['blocks'])):
+            dt = self.block_bwd(blk, s, dt, B, S)
+        dh, _ = self.ln_pre.bwd(dt, sv['h'], sv['mp'], sv['rp'])
+        gpos = P.g('positional_embedding')
+        names = sv['names']
+        if names:
+            L, G = d.num_latents, d.expert_grid ** 2
+            Mx = len(names) * G
+            dlat = torch.empty(B * L, W, dtype=BF16, device=dh.device)
+            ops.copy_rows(dh, dlat, B * L, W, src_map=RowMap(L, S, N))
+            dxf = self.resampler_bwd(dlat, B, sv)
+            same = d.expert_grid == d.rgb_grid
+            dpos_e = gpos if same else torch.zeros(G, W, dtype=F32, device=dh.device)
+            for ei, name in enumerate(names):
+                dom = 'seg' if 'seg' in name else name
+                dfeat = torch.empty(B * G, W, dtype=BF16, device=dh.device)
+                if name == 'obj_detection':
+                    inst = sv['inst']
+                    ops.tokens_finalize_bwd(dxf, dfeat, dpos_e, B, G, W, Mx, ei * G, inst, inst.shape[-1], d.expert_grid, sv['inst_table'],
+                                            P.g('instance_embedding'))
+                else:
+                    ops.tokens_finalize_bwd(dxf, dfeat, dpos_e, B, G, W, Mx, ei * G)
+                self.stem_bwd(dom, dfeat, sv)
+            if not same and gpos is not None:
+                self.expert_pos_bwd(dpos_e)
+        drgb = torch.empty(B * N, W, dtype=BF16, device=dh.device)
+        ops.tokens_finalize_bwd(dh, drgb, gpos, B, N, W, S, 0)
+        self.conv_wgrad('conv1.rgb.weight', d.patch_size, drgb, sv['rgb_col'])

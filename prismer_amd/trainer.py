@@ -1,0 +1,213 @@
+"""Native training step for Prismer caption / VQA fine-tuning on MI355X.
+
+Replaces the per-iteration body of the reference training scripts (train_caption.py:126-135, train_vqa.py:118-134):
+    cosine_lr_schedule -> loss = model(...) -> optimizer.zero_grad() -> accelerator.backward(loss) -> optimizer.step()
+with a hand-scheduled step that never enters autograd:
+
+    [memset grads] -> encoder program fwd -> decoder program fwd (+CE) -> decoder program bwd
+        -> (RCCL all-reduce of the decoder's flat fp32 gradient buffer, on the communication stream,
+            overlapping the whole encoder backward)
+    -> encoder program bwd -> (all-reduce of the encoder gradients) -> fused AdamW over the two flat buffers.
+
+The three compute segments are captured once into hipGraphs (torch.cuda.CUDAGraph) and replayed, so the ~2000 kernel
+launches of a step cost three graph launches on the host; the collectives stay outside the graphs (eager RCCL calls
+ordered by stream events), which keeps the multi-GPU path identical to the single-GPU one plus two all_reduce calls.
+Data parallel semantics = DDP's: every rank holds all parameters, gradients are summed over ranks and divided by
+world size (folded into the AdamW kernel as grad_scale), BatchNorm uses per-rank batch statistics (no SyncBN in the
+reference).  DDP's per-step buffer broadcast from rank 0 is replaced by rank-local BN running statistics
+(documented deviation).
+"""
+import math
+import os
+import random
+
+import torch
+
+from . import ops
+
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+def cosine_lr(it, total, init_lr, min_lr):
+    """utils.py:13-17 of the reference."""
+    return (init_lr - min_lr) * 0.5 * (1.0 + math.cos(math.pi * it / total)) + min_lr
+
+
+class Trainer:
+    def __init__(self, model, lr=5e-5, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8, min_lr=0.0, total_steps=1000,
+                 task='caption', use_graph=True, process_group=None, bucket_mb=64):
+        self.model = model
+        self.enc, self.dec = model.expert_encoder, model.text_decoder
+        self.init_lr, self.min_lr, self.total_steps = lr, min_lr, total_steps
+        self.wd, self.betas, self.eps = weight_decay, betas, eps
+        self.task = task
+        self.use_graph = use_graph
+        self.pg = process_group
+        self.world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world = torch.distributed.get_world_size(process_group)
+        self.bucket_elems = bucket_mb * 1024 * 1024 // 4
+        self.it = 0
+        self.graphs = None
+        self.static = None
+        self.enc.train(); self.dec.train()
+        self.enc_prog, self.dec_prog = self.enc._program(), self.dec._program()
+        self.stores = [self.enc._store, self.dec._store]
+        for st in self.stores:
+            st.native_grads = True
+            st.managed = True
+            st._grad_cur = st.grad
+        dev = self.stores[0].master.device
+        self.device = dev
+        self.m = [torch.zeros(st.n_train, dtype=F32, device=dev) for st in self.stores]
+        self.v = [torch.zeros(st.n_train, dtype=F32, device=dev) for st in self.stores]
+        self.hyper = torch.zeros(3, dtype=F32, device=dev)
+        self.hyper_host = torch.zeros(3, dtype=F32).pin_memory()
+        self.table_host = torch.zeros(256, dtype=torch.int32).pin_memory()
+        self.table = torch.zeros(256, dtype=torch.int32, device=dev)
+        self.seed = self.dec.dropout_seed()
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
+        self.loss = None
+        if self.world > 1:
+            self.broadcast_parameters()
+
+    # ------------------------------------------------------------------------------------------ distributed
+    def broadcast_parameters(self):
+        """DDP construction semantics (train_caption.py:117): rank 0's parameters and buffers win."""
+        for st in self.stores:
+            torch.distributed.broadcast(st.master, 0, group=self.pg)
+            st.refresh()
+        for mod in (self.enc, self.dec):
+            for b in mod.buffers():
+                torch.distributed.broadcast(b, 0, group=self.pg)
+
+    def _allreduce_async(self, flat, n):
+        """bucketed SUM all-reduce of flat[:n] on the communication stream, after everything queued so far on the
+        compute stream (the gradients are complete by then)."""
+        if self.world == 1:
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.comm_stream.wait_event(ev)
+        with torch.cuda.stream(self.comm_stream):
+            for o in range(0, n, self.bucket_elems):
+                torch.distributed.all_reduce(flat[o:min(n, o + self.bucket_elems)], group=self.pg)
+
+    def _wait_comm(self):
+        if self.world > 1:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    # ------------------------------------------------------------------------------------------ step pieces
+    def _seg_forward_dec_backward(self, s):
+        for st in self.stores:
+            st.grad.zero_()                                    # optimizer.zero_grad()
+        enc_out, self.sv_e = self.enc_prog.forward(s['experts'], self.table, True, True)
+        logits, loss, self.sv_d = self.dec_prog.forward(s['input_ids'], s['attention_mask'], enc_out, s['labels'], self.seed, True)
+        B = loss.shape[0]
+        if s.get('weights') is not None:                       # VQA: (weights * loss).mean()  (prismer_vqa.py:40-41)
+            dloss = s['weights'].to(F32) / B
+            self.loss_buf = (loss * s['weights']).sum() / B
+        else:                                                  # caption: loss.mean()          (prismer_caption.py:33)
+            dloss = torch.full((B,), 1.0 / B, dtype=F32, device=loss.device)
+            self.loss_buf = loss.sum() / B
+        self.denc = self.dec_prog.backward(self.sv_d, dloss)
+        self.sv_d = None
+
+    def _seg_enc_backward(self):
+        self.enc_prog.backward(self.sv_e, self.denc)
+        self.sv_e = None
+
+    def _seg_optimizer(self):
+        for st, m, v in zip(self.stores, self.m, self.v):
+            ops.adamw(st.master, st.grad, m, v, st.shadow, st.n_train, self.hyper, self.betas[0], self.betas[1], self.eps, self.wd,
+                      1.0 / self.world)
+            st.refresh_derived()
+        ops.advance_seed(self.seed)
+
+    def _host_prologue(self):
+        """per-step host work: LR schedule (cosine per ITERATION, train_caption.py:127), Adam bias corrections and the
+        instance-embedding draw table (vit.py:145-147: Python `random`), shipped with two async pinned copies."""
+        self.it += 1
+        lr = cosine_lr(self.it - 1, self.total_steps, self.init_lr, self.min_lr)
+        self.hyper_host[0] = lr
+        self.hyper_host[1] = 1.0 - self.betas[0] ** self.it
+        self.hyper_host[2] = 1.0 - self.betas[1] ** self.it
+        self.hyper.copy_(self.hyper_host, non_blocking=True)
+        if 'obj_detection' in self.enc.experts:
+            for i in range(256):
+                self.table_host[i] = random.randint(0, 127)
+            self.table.copy_(self.table_host, non_blocking=True)
+
+    # ------------------------------------------------------------------------------------------ public API
+    def set_batch(self, experts, input_ids, attention_mask, labels, weights=None):
+        """(re)binds the static input buffers. First call allocates them; later calls copy into them."""
+        if self.static is None:
+            def clone(t):
+                return {k: clone(v) for k, v in t.items()} if isinstance(t, dict) else t.to(self.device).contiguous().clone()
+            self.static = dict(experts=clone(experts), input_ids=input_ids.to(self.device).contiguous().clone(),
+                               attention_mask=attention_mask.to(self.device).contiguous().clone(),
+                               labels=labels.to(self.device).contiguous().clone(),
+                               weights=None if weights is None else weights.to(self.device).contiguous().clone())
+            return
+
+        def copy(dst, src):
+            if isinstance(dst, dict):
+                for k in dst:
+                    copy(dst[k], src[k])
+            else:
+                dst.copy_(src, non_blocking=True)
+        s = self.static
+        copy(s['experts'], experts); copy(s['input_ids'], input_ids); copy(s['attention_mask'], attention_mask); copy(s['labels'], labels)
+        if weights is not None:
+            copy(s['weights'], weights)
+
+    def _capture(self):
+        s = self.static
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                           # warm-up outside capture (allocations, lazily built shadows)
+            for _ in range(2):
+                self._host_prologue()
+                self._seg_forward_dec_backward(s)
+                self._allreduce_async(self.stores[1].grad, self.stores[1].n_train)
+                self._seg_enc_backward()
+                self._allreduce_async(self.stores[0].grad, self.stores[0].n_train)
+                self._wait_comm()
+                self._seg_optimizer()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, pool=pool):
+            self._seg_forward_dec_backward(s)
+        with torch.cuda.graph(g2, pool=pool):
+            self._seg_enc_backward()
+        with torch.cuda.graph(g3, pool=pool):
+            self._seg_optimizer()
+        self.graphs = (g1, g2, g3)
+
+    def step(self):
+        """one optimisation step on the bound batch; returns the (device) scalar loss tensor without synchronising."""
+        assert self.static is not None, 'call set_batch() first'
+        if self.use_graph and self.graphs is None:
+            self._capture()
+        self._host_prologue()
+        if self.use_graph:
+            g1, g2, g3 = self.graphs
+            g1.replay()
+            self._allreduce_async(self.stores[1].grad, self.stores[1].n_train)
+            g2.replay()
+            self._allreduce_async(self.stores[0].grad, self.stores[0].n_train)
+            self._wait_comm()
+            g3.replay()
+        else:
+            self._seg_forward_dec_backward(self.static)
+            self._allreduce_async(self.stores[1].grad, self.stores[1].n_train)
+            self._seg_enc_backward()
+            self._allreduce_async(self.stores[0].grad, self.stores[0].n_train)
+            self._wait_comm()
+            self._seg_optimizer()
+        return self.loss_buf
+
+    def state_dict(self):
+        return dict(it=self.it, m=[t.clone() for t in self.m], v=[t.clone() for t in self.v], model=self.model.state_dict())

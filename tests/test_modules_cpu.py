@@ -1,0 +1,89 @@
+"""CPU: host-side logic of the nn.Module shells -- state-dict contract, freeze policy
+(model/prismer.py:39-59), q/k/v re-ordering of the flat store, schedules."""
+import math
+
+import pytest
+import torch
+
+from prismer_amd import config, synth
+from prismer_amd.model.prismer import Prismer, _Cfg
+from prismer_amd.modules.roberta import RobertaForCausalLMModified
+from prismer_amd.modules.vit import VisionTransformer
+from prismer_amd.store import _reorder_qkv
+from prismer_amd.trainer import cosine_lr
+
+
+def build(d):
+    enc = VisionTransformer(d.image_resolution, d.patch_size, d.width, d.vit_layers, d.vit_heads, dict(d.experts))
+    dec = RobertaForCausalLMModified(_Cfg(d.roberta_config_dict()))
+    return enc, dec
+
+
+@pytest.mark.parametrize('name', ['prismer_tiny', 'prismer_base'])
+def test_state_dict_contract(name):
+    d = config.CONFIGS[name]()
+    if name == 'prismer_base':
+        d.vit_layers = 2; d.num_hidden_layers = 2          # same key patterns, fewer repeats (keeps the test fast)
+    enc, dec = build(d)
+    es, ds = synth.encoder_spec(d), synth.decoder_spec(d)
+    esd, dsd = enc.state_dict(), dec.state_dict()
+    assert list(sorted(esd)) == list(sorted(es))
+    assert list(sorted(dsd)) == list(sorted(ds))
+    for k, (shape, _) in es.items():
+        assert tuple(esd[k].shape) == tuple(shape), k
+    for k, (shape, _) in ds.items():
+        assert tuple(dsd[k].shape) == tuple(shape), k
+    # strict load of the synthetic (reference-validated) state dicts
+    enc.load_state_dict(synth.synth_encoder_state(d), strict=True)
+    dec.load_state_dict(synth.synth_decoder_state(d), strict=True)
+    assert dec.lm_head.decoder.weight is dec.roberta.embeddings.word_embeddings.weight       # tied (App. C #18)
+    assert dec.lm_head.decoder.bias is dec.lm_head.bias
+
+
+def test_prismerz_has_no_expert_modules():
+    d = config.prismer_tiny(experts=[])
+    enc, _ = build(d)
+    keys = enc.state_dict().keys()
+    assert not any(k.startswith('resampler') or 'instance_embedding' in k for k in keys)     # App. C #21
+    assert [k for k in keys if k.startswith('conv1.')] == ['conv1.rgb.weight']
+
+
+def test_freeze_policy_counts():
+    m = Prismer.__new__(Prismer)
+    torch.nn.Module.__init__(m)
+    d = config.prismer_base()
+    d.vit_layers = 1; d.num_hidden_layers = 1
+    m.expert_encoder, m.text_decoder = build(d)
+    m.prepare_to_train('freeze_vision')
+    frozen = [n for n, p in m.named_parameters() if not p.requires_grad]
+    assert frozen and all('transformer.resblocks' in n and 'adaptor' not in n for n in frozen)
+    assert all(p.requires_grad for n, p in m.named_parameters() if 'adaptor' in n or 'text_decoder' in n or 'conv1' in n)
+    m.prepare_to_train('freeze_lang')
+    frozen = [n for n, p in m.named_parameters() if not p.requires_grad]
+    assert all('encoder.layer' in n and '.0.' in n for n in frozen) and frozen
+    assert m.get_ignored_modules('freeze_vision') is not None and m.get_ignored_modules('none') is None
+    assert len(m.get_ignored_modules('freeze_vision')) == 4
+
+
+def test_qkv_reorder():
+    names = ['a.self.query.weight', 'a.self.query.bias', 'a.self.key.weight', 'a.self.key.bias', 'a.self.value.weight',
+             'a.self.value.bias', 'a.output.dense.weight']
+    assert _reorder_qkv(names) == ['a.self.query.weight', 'a.self.key.weight', 'a.self.value.weight', 'a.self.query.bias',
+                                   'a.self.key.bias', 'a.self.value.bias', 'a.output.dense.weight']
+
+
+def test_cosine_schedule():
+    assert cosine_lr(0, 100, 5e-5, 0) == 5e-5
+    assert abs(cosine_lr(50, 100, 5e-5, 0) - 2.5e-5) < 1e-12
+    assert abs(cosine_lr(100, 100, 5e-5, 1e-6) - 1e-6) < 1e-12
+
+
+def test_no_eager_fallback_on_cpu():
+    d = config.prismer_tiny(experts=[])
+    enc, dec = build(d)
+    with pytest.raises(RuntimeError):
+        enc({'rgb': torch.zeros(1, 3, 64, 64)})
+    with pytest.raises(RuntimeError):
+        dec(torch.zeros(1, 4, dtype=torch.long), encoder_hidden_states=torch.zeros(1, 16, 256))
+    with pytest.raises(RuntimeError):
+        enc.ln_pre(torch.zeros(2, 256))
