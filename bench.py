@@ -1,0 +1,218 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of Prismer-BASE caption fine-tuning (224^2, 6 experts, batch 32 / GPU, freeze_vision,
+T = 30, bf16 storage / fp32 accumulate) on N MI355X -- BASELINE.json `metric`, config[2] (N=1) / config[3] (N=8).
+
+  python bench.py --gpus N --steps K --warmup W
+  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = the full training iteration of the reference loop (train_caption.py:126-135): LR schedule, zero_grad, forward
+(6 expert stems with train-mode BatchNorm, Experts Resampler, ViT + adaptors, decoder with dropout 0.1, LM head, shifted
+label-smoothed CE), backward, gradient all-reduce over RCCL (N > 1) and fused AdamW over the 242.4 M trainable parameters.
+Synthetic inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+Extra legs (rank 0, N = 1 only):
+  roofline      the bf16 MFMA GEMM kernel family: algorithmic FLOPs (2*M*N*K per launch) / summed launch durations, measured
+                with HIP events on the launch stream in an instrumented (eager, non-graph) pass of the same step
+  cpu_baseline  the CPU oracle (oracle/prismer_oracle.py, fp32, all host cores) on a bounded sample of the same workload
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TRAIN_GF_PER_IMG = 263.10      # Prismer-BASE, T=30, freeze_vision (3*fwd minus frozen wgrads)
+PEAK_TFLOPS = 2500.0           # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+FAMILIES = ['gemm', 'layernorm', 'attention_fwd', 'attention_bwd', 'frontend', 'embed_ce', 'optimizer', 'misc']
+
+
+def make_inputs(dims, batch, T, seed, device):
+    """SURVEY 8d synthetic inputs, generated on the device (label experts = uint8 rectangle maps gathered through a
+    [256,64] table of std 0.75; dense experts U(-1,1); rgb N(0,1)); text: <s> prompt(3) body </s>, labels mask the prompt."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    R, E = dims.image_resolution, dims.expert_resolution
+    x = {'rgb': torch.randn(batch, 3, R, R, generator=g, device=device)}
+    names = ['depth', 'normal', 'seg_coco', 'edge', 'obj_detection', 'ocr_detection']
+
+    def label_map():
+        lab = torch.full((batch, E, E), 255, dtype=torch.int64, device=device)
+        rect = torch.randint(0, 1 << 20, (batch, 8, 5), generator=g, device=device).cpu()
+        for b in range(batch):
+            for r in range(8):
+                y0, x0 = int(rect[b, r, 0]) % E, int(rect[b, r, 1]) % E
+                h, w = 1 + int(rect[b, r, 2]) % (E // 2), 1 + int(rect[b, r, 3]) % (E // 2)
+                lab[b, y0:y0 + h, x0:x0 + w] = int(rect[b, r, 4]) % 200
+        table = torch.randn(256, 64, generator=g, device=device) * 0.75
+        return lab, table[lab].permute(0, 3, 1, 2).contiguous()
+    for n in names:
+        if n in ('depth', 'edge'):
+            x[n] = torch.rand(batch, 1, E, E, generator=g, device=device) * 2 - 1
+        elif n == 'normal':
+            x[n] = torch.rand(batch, 3, E, E, generator=g, device=device) * 2 - 1
+        else:
+            lab, m = label_map()
+            x[n] = {'label': m, 'instance': lab.unsqueeze(1)} if n == 'obj_detection' else m
+    ids = torch.randint(3, dims.vocab_size, (batch, T), generator=g, device=device)
+    ids[:, 0] = 0
+    ids[:, 1:4] = torch.tensor([83, 2170, 9], device=device)
+    ids[:, T - 1] = 2
+    mask = torch.ones(batch, T, dtype=torch.int64, device=device)
+    labels = ids.clone()
+    labels[:, :4] = -100
+    return x, ids, mask, labels
+
+
+def build_trainer(batch, use_graph, rank, T=30):
+    from prismer_amd import config as pcfg
+    from prismer_amd.model.prismer_caption import PrismerCaption
+    from prismer_amd.trainer import Trainer
+    dims = pcfg.prismer_base()
+    cfg = {'experts': pcfg.CAPTION_EXPERTS, 'image_resolution': 224, 'prismer_model': 'prismer_base', 'freeze': 'freeze_vision'}
+    torch.manual_seed(0)                                   # identical random-init weights on every rank
+    model = PrismerCaption(cfg).cuda()
+    tr = Trainer(model, lr=5e-5, weight_decay=0.05, total_steps=10000, task='caption', use_graph=use_graph)
+    x, ids, mask, labels = make_inputs(dims, batch, T, 1234 + rank, torch.device('cuda'))
+    tr.set_batch(x, ids, mask, labels)
+    n_train = sum(st.n_train for st in tr.stores)
+    return tr, dims, n_train
+
+
+def kernel_family_pass(tr, steps):
+    """instrumented eager pass: per-family HIP-event timing through the library's measurement hooks."""
+    from prismer_amd._lib import lib
+    tr.use_graph = False
+    tr.step(); torch.cuda.synchronize()
+    lib.ph_prof_enable(1)
+    for _ in range(steps):
+        tr.step()
+    out = (ctypes.c_double * (len(FAMILIES) * 4))()
+    lib.ph_prof_collect(out)
+    lib.ph_prof_enable(0)
+    fam = {}
+    for i, name in enumerate(FAMILIES):
+        ms, fl, by, n = out[4 * i:4 * i + 4]
+        fam[name] = dict(ms_per_step=ms / steps, tflop_per_step=fl / steps / 1e12, launches_per_step=n / steps)
+    return fam
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """CPU oracle (a port: plain-PyTorch fp32 restatement of the reference modules, pinned to reference outputs by
+    tests/golden) timed on the host cores: Prismer-BASE caption train step, batch 4, T=30, freeze_vision."""
+    from oracle import prismer_oracle as O
+    from prismer_amd import config as pcfg, synth
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    d = pcfg.prismer_base()
+    B, T = 4, 30
+    esd, dsd = synth.synth_encoder_state(d, 0), synth.synth_decoder_state(d, 0)
+    names = ['expert_encoder.' + k for k in esd] + ['text_decoder.' + k for k in dsd]
+    fm = O.freeze_mask(names, 'freeze_vision')
+    leaves, seen = [], set()
+    for pre, sd in (('expert_encoder.', esd), ('text_decoder.', dsd)):
+        for k, v in sd.items():
+            if v.is_floating_point() and 'running' not in k and id(v) not in seen and fm[pre + k]:
+                seen.add(id(v)); v.requires_grad_(True); leaves.append(v)
+    opt = torch.optim.AdamW(leaves, lr=5e-5, weight_decay=0.05)
+    x = synth.synth_experts(d, B, seed=1)
+    ids, mask, labels = synth.synth_text(d, B, T, seed=1)
+    tab = list(range(128)) * 2
+
+    def step():
+        opt.zero_grad()
+        loss, _, _ = O.caption_loss(esd, dsd, x, ids, mask, labels, d, train_bn=True, instance_table=tab, bn_updates={})
+        loss.backward()
+        opt.step()
+    step()                                             # warm-up
+    t0 = time.time(); n = 0
+    while n < 1 or (time.time() - t0) < seconds_budget * 0.6:
+        step(); n += 1
+    dt = (time.time() - t0) / n
+    return dict(value=round(B / dt, 3), unit='images/sec', cores=cores, kind='port',
+                sample=f'Prismer-BASE caption train step (fwd+bwd+AdamW, freeze_vision, fp32), batch {B}, T={T}, {n} timed step(s) of '
+                       f'{dt:.2f} s on {cores} host threads')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback path exists)')
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    tr, dims, n_train = build_trainer(args.batch, not args.no_graph, rank)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    ms = dt / args.steps * 1e3
+    value = world * args.batch * args.steps / dt
+    final_loss = float(loss.item())
+
+    out = {
+        'metric': 'images/sec Prismer-BASE caption train, 224^2 + 6 experts, bs32/GPU',
+        'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
+        'data': 'synthetic',
+        'config': {'workload': 'Prismer-BASE caption fine-tune step (fwd+bwd+allreduce+AdamW), 224^2, 6 experts + Resampler, T=30, '
+                               'freeze_vision, dropout 0.1, train-mode BatchNorm',
+                   'model': 'prismer_base', 'global_batch': world * args.batch, 'seq_len': dims.seq_len, 'text_len': 30,
+                   'parallelism': f'dp{world}', 'trainable_params': n_train, 'hip_graph': not args.no_graph,
+                   'final_loss': round(final_loss, 4)},
+        'step_tflops': round(value / world * TRAIN_GF_PER_IMG / 1e3, 2),
+        'step_mfma_frac': round(value / world * TRAIN_GF_PER_IMG / 1e3 / PEAK_TFLOPS, 4),
+    }
+    if rank == 0 and world == 1:
+        if not args.no_roofline:
+            fam = kernel_family_pass(tr, min(args.steps, 5))
+            g = fam['gemm']
+            ach = g['tflop_per_step'] / (g['ms_per_step'] / 1e3) if g['ms_per_step'] > 0 else 0.0
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_kernel<*> (all bf16 MFMA GEMM launches of one step)',
+                               'achieved': round(ach, 1), 'peak': PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_TFLOPS, 4),
+                               'traffic': None, 'avg_launch_us': round(g['ms_per_step'] * 1e3 / max(g['launches_per_step'], 1), 2),
+                               'launches_per_step': g['launches_per_step'], 'gemm_tflop_per_step': round(g['tflop_per_step'], 3)}
+            out['kernel_families_ms_per_step'] = {k: round(v['ms_per_step'], 3) for k, v in fam.items()}
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -227,6 +227,13 @@ int ph_conv_grad_from_shadow(const float* dshadow, float* dw, int Cout, int Cin,
 /* advance the dropout seed (device-side, graph-replay safe): seed[0] = splitmix(seed[0]) */
 int ph_advance_seed(uint64_t* seed, hipStream_t stream);
 
+/* Measurement hooks (bench.py): when enabled, every entry point brackets its launches with HIP events on the launch
+ * stream.  ph_prof_collect synchronises and writes, per kernel family f (0 gemm, 1 layernorm, 2 attention fwd,
+ * 3 attention bwd, 4 front end, 5 embed+CE, 6 optimizer, 7 misc), out[4f..4f+3] = {ms, algorithmic flops, algorithmic
+ * bytes, launches}.  Must stay disabled during hipGraph capture. */
+int ph_prof_enable(int on);
+int ph_prof_collect(double* out);
+
 /* unit-test probe: exercises ds_read_b64_tr_b16 / MFMA lane layouts on the device (tests/test_kernels_gpu.py) */
 int ph_probe_layouts(const void* in_bf16, float* out, hipStream_t stream);
 

@@ -116,6 +116,8 @@ _SIGS = {
     'ph_conv_weight_to_shadow': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ph_conv_grad_from_shadow': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ph_advance_seed': (c_int, [c_void_p, c_void_p]),
+    'ph_prof_enable': (c_int, [c_int]),
+    'ph_prof_collect': (c_int, [c_void_p]),
     'ph_probe_layouts': (c_int, [c_void_p, c_void_p, c_void_p]),
 }
 

@@ -219,24 +219,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(ph_attn_fwd_args a) {
 }
 
 // =====================================================================================================
-// backward: delta = rowsum(dO * O)
-// =====================================================================================================
-__global__ __launch_bounds__(256) void attn_delta_kernel(ph_attn_bwd_args a) {
-  // one wave per (b, h, q): DH <= 128 -> 2 elements per lane max
-  int gid = blockIdx.x * 4 + (threadIdx.x >> 6);
-  int lane = threadIdx.x & 63;
-  int total = a.f.B * a.f.H * a.f.Sq;
-  if (gid >= total) return;
-  int q = gid % a.f.Sq, bh = gid / a.f.Sq, h = bh % a.f.H, b = bh / a.f.H;
-  const bf16* O = reinterpret_cast<const bf16*>(a.f.o) + b * a.f.o_bs + (int64_t)q * a.f.o_ts + (int64_t)h * a.f.dh;
-  const bf16* dO = reinterpret_cast<const bf16*>(a.d_o) + b * a.do_bs + (int64_t)q * a.do_ts + (int64_t)h * a.f.dh;
-  float s = 0.f;
-  for (int d = lane; d < a.f.dh; d += 64) s += bf2f(O[d]) * bf2f(dO[d]);
-  s = wave_sum(s);
-  if (lane == 0) a.delta[gid] = s;
-}
-
-// =====================================================================================================
 // backward: dQ  (same streaming structure as forward)
 // =====================================================================================================
 template <int DH>
@@ -264,7 +246,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(ph_attn_bwd_args a) {
     dof[ks] = *reinterpret_cast<const bf16x8*>(dO + (int64_t)qr * a.do_ts + ks * 32 + g * 8);
   }
   const int64_t ridx = (int64_t)(b * f.H + h) * f.Sq + qr;
-  const float lse = f.lse[ridx], delta = a.delta[ridx];
+  const float lse = f.lse[ridx];
   DropCtx dc;
   const bool drop = f.drop_p > 0.f;
   if (drop) dc = make_drop(f.drop_seed, f.drop_stream, f.drop_p);
@@ -274,54 +256,69 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(ph_attn_bwd_args a) {
 #pragma unroll
   for (int d = 0; d < C::DT; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Two passes over the K/V tiles.  Pass 0 computes delta_i = sum_j P_ij * dP_ij in fp32 from the SAME recomputed P
+  // and dP the second pass uses (softmax backward needs dP_ij - delta_i, which cancels to ~0 on peaked rows; taking
+  // delta from the bf16-rounded forward output O, rowsum(dO*O), leaves a 2^-9 relative inconsistency that shows up as
+  // 10 %-level noise in dQ/dK of peaked attention rows).  Pass 1 forms dS and accumulates dQ.
   const int ntiles = (f.Sk + 63) / 64;
   u32x4 rk[C::NLD], rv[C::NLD];
-  tile_gload<DH>(K, f.k_ts, 0, f.Sk, rk);
-  tile_gload<DH>(V, f.v_ts, 0, f.Sk, rv);
-  tile_lstore<DH>(smem, rk);
-  tile_lstore<DH>(smem + C::TILE, rv);
-  __syncthreads();
-  int cur = 0;
-  for (int t = 0; t < ntiles; ++t) {
-    const bool more = t + 1 < ntiles;
-    if (more) {
-      tile_gload<DH>(K, f.k_ts, (t + 1) * 64, f.Sk, rk);
-      tile_gload<DH>(V, f.v_ts, (t + 1) * 64, f.Sk, rv);
-    }
-    const bf16* kl = smem + cur * 2 * C::TILE;
-    const bf16* vl = kl + C::TILE;
-    f32x4 ds[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(kl, nt * 16, ks, lane), qf[ks], acc, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(vl, nt * 16, ks, lane), dof[ks], dp, 0, 0, 0);
-      }
-      u32x4 rnd;
-      if (drop) rnd = philox4x32((uint32_t)((t * 64 + nt * 16 + g * 4) >> 2), rowid, dc.stream, 0xa77eu, dc.k0, dc.k1);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int ki = t * 64 + nt * 16 + g * 4 + r;
-        float p = __expf(mask_score(acc[r], f.scale, qi, ki, f.Sk, km, f.causal) - lse);
-        float dpe = drop ? drop_apply(dc, rnd[r], dp[r]) : dp[r];
-        ds[nt][r] = p * (dpe - delta);
-      }
-    }
-#pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) {
-      bf16x8 dsf = pack2(ds[2 * k2], ds[2 * k2 + 1]);
-#pragma unroll
-      for (int d = 0; d < C::DT; ++d)
-        dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(kl, k2 * 32, d * 16, lane), dsf, dq[d], 0, 0, 0);
-    }
-    if (more) {
-      tile_lstore<DH>(smem + (cur ^ 1) * 2 * C::TILE, rk);
-      tile_lstore<DH>(smem + (cur ^ 1) * 2 * C::TILE + C::TILE, rv);
-    }
+  float delta = 0.f;
+  for (int pass = 0; pass < 2; ++pass) {
+    tile_gload<DH>(K, f.k_ts, 0, f.Sk, rk);
+    tile_gload<DH>(V, f.v_ts, 0, f.Sk, rv);
+    tile_lstore<DH>(smem, rk);
+    tile_lstore<DH>(smem + C::TILE, rv);
     __syncthreads();
-    cur ^= 1;
+    int cur = 0;
+    float dsum = 0.f;
+    for (int t = 0; t < ntiles; ++t) {
+      const bool more = t + 1 < ntiles;
+      if (more) {
+        tile_gload<DH>(K, f.k_ts, (t + 1) * 64, f.Sk, rk);
+        tile_gload<DH>(V, f.v_ts, (t + 1) * 64, f.Sk, rv);
+      }
+      const bf16* kl = smem + cur * 2 * C::TILE;
+      const bf16* vl = kl + C::TILE;
+      f32x4 ds[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(kl, nt * 16, ks, lane), qf[ks], acc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(vl, nt * 16, ks, lane), dof[ks], dp, 0, 0, 0);
+        }
+        u32x4 rnd;
+        if (drop) rnd = philox4x32((uint32_t)((t * 64 + nt * 16 + g * 4) >> 2), rowid, dc.stream, 0xa77eu, dc.k0, dc.k1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int ki = t * 64 + nt * 16 + g * 4 + r;
+          float p = __expf(mask_score(acc[r], f.scale, qi, ki, f.Sk, km, f.causal) - lse);
+          float dpe = drop ? drop_apply(dc, rnd[r], dp[r]) : dp[r];
+          dsum += p * dpe;
+          ds[nt][r] = p * (dpe - delta);
+        }
+      }
+      if (pass == 1) {
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          bf16x8 dsf = pack2(ds[2 * k2], ds[2 * k2 + 1]);
+#pragma unroll
+          for (int d = 0; d < C::DT; ++d)
+            dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(kl, k2 * 32, d * 16, lane), dsf, dq[d], 0, 0, 0);
+        }
+      }
+      if (more) {
+        tile_lstore<DH>(smem + (cur ^ 1) * 2 * C::TILE, rk);
+        tile_lstore<DH>(smem + (cur ^ 1) * 2 * C::TILE + C::TILE, rv);
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+    if (pass == 0) {
+      delta = xor_sum(dsum);
+      if (g == 0 && qi < f.Sq) a.delta[ridx] = delta;      // consumed by the dK/dV kernel (launched after this one)
+    }
   }
   if (qi < f.Sq) {
     bf16* dQ = reinterpret_cast<bf16*>(a.dq) + b * a.dq_bs + (int64_t)qi * a.dq_ts + (int64_t)h * DH;
@@ -470,6 +467,7 @@ int check_fwd(const ph_attn_fwd_args* f, const char* who) {
 extern "C" int ph_attention_fwd(const ph_attn_fwd_args* a, hipStream_t stream) {
   int rc = check_fwd(a, "ph_attention_fwd");
   if (rc) return rc;
+  ProfScope prof__(PH_FAM_ATTN_FWD, 4.0 * a->B * (double)a->H * a->Sq * (double)a->Sk * a->dh, 0.0, stream);
   dim3 grid(ceil_div(a->Sq, 64), a->B * a->H);
 #define PH_FWD(DHV)                                                                        \
   case DHV: {                                                                              \
@@ -484,12 +482,12 @@ extern "C" int ph_attention_fwd(const ph_attn_fwd_args* a, hipStream_t stream) {
 
 extern "C" int ph_attention_bwd(const ph_attn_bwd_args* a, hipStream_t stream) {
   PH_CHECK_ARG(a, "ph_attention_bwd: null args");
+  ProfScope prof__(PH_FAM_ATTN_BWD, 10.0 * a->f.B * (double)a->f.H * a->f.Sq * (double)a->f.Sk * a->f.dh, 0.0, stream);
   int rc = check_fwd(&a->f, "ph_attention_bwd");
   if (rc) return rc;
   PH_CHECK_ARG(a->d_o && a->dq && a->dk && a->dv && a->delta && a->f.lse, "ph_attention_bwd: null pointer");
   PH_CHECK_ARG(((a->do_ts | a->dq_ts | a->dk_ts | a->dv_ts | a->do_bs | a->dq_bs | a->dk_bs | a->dv_bs) % 8) == 0, "ph_attention_bwd: strides must be multiples of 8");
   const ph_attn_fwd_args& f = a->f;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3(ceil_div(f.B * f.H * f.Sq, 4)), dim3(256), 0, stream, *a);
   dim3 gq(ceil_div(f.Sq, 64), f.B * f.H), gk(ceil_div(f.Sk, 64), f.B * f.H);
 #define PH_BWD(DHV)                                                                          \
   case DHV: {                                                                                \

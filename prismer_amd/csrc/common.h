@@ -30,6 +30,18 @@ int ph_fail(int code, const char* fmt, ...);
     if (e__ != hipSuccess) return ph_fail(PH_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
   } while (0)
 
+// ---- optional per-family kernel timing (HIP events on the launch stream; off by default, never inside graph capture)
+enum { PH_FAM_GEMM = 0, PH_FAM_LAYERNORM, PH_FAM_ATTN_FWD, PH_FAM_ATTN_BWD, PH_FAM_FRONTEND, PH_FAM_EMBED_CE, PH_FAM_OPTIM, PH_FAM_MISC,
+       PH_FAM_COUNT };
+extern int g_ph_prof_enabled;
+void ph_prof_begin(int family, double flops, double bytes, hipStream_t s);
+void ph_prof_end(hipStream_t s);
+struct ProfScope {
+  hipStream_t s; bool on;
+  ProfScope(int family, double flops, double bytes, hipStream_t st) : s(st), on(g_ph_prof_enabled != 0) { if (on) ph_prof_begin(family, flops, bytes, st); }
+  ~ProfScope() { if (on) ph_prof_end(s); }
+};
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -256,6 +256,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(bf16* __restrict__ logits, 
 
 extern "C" int ph_embed_fwd(const ph_embed_fwd_args* a, hipStream_t stream) {
   PH_CHECK_ARG(a && a->ids && a->word && a->pos && a->type && a->gamma && a->beta && a->out, "ph_embed_fwd: null pointer");
+  ProfScope prof__(PH_FAM_EMBED_CE, 0.0, 0.0, stream);
   PH_CHECK_ARG(a->H % 4 == 0 && a->H <= MAX_CH * 256 && a->B > 0 && a->T > 0, "ph_embed_fwd: bad dims");
   PH_CHECK_ARG(!(a->drop_p > 0.f) || a->drop_seed, "ph_embed_fwd: dropout needs a seed");
   hipLaunchKernelGGL(embed_fwd_kernel, dim3(ceil_div(a->B * a->T, 4)), dim3(256), 0, stream, *a);
@@ -265,6 +266,7 @@ extern "C" int ph_embed_fwd(const ph_embed_fwd_args* a, hipStream_t stream) {
 
 extern "C" int ph_embed_bwd(const ph_embed_bwd_args* a, hipStream_t stream) {
   PH_CHECK_ARG(a && a->dout && a->f.ids && a->f.xhat && a->f.rstd && a->f.gamma, "ph_embed_bwd: null pointer");
+  ProfScope prof__(PH_FAM_EMBED_CE, 0.0, 0.0, stream);
   PH_CHECK_ARG(a->f.H % 4 == 0 && a->f.H <= MAX_CH * 256, "ph_embed_bwd: bad dims");
   int grid = min(ceil_div(a->f.B * a->f.T, 4), 256);
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid), dim3(256), 0, stream, *a);
@@ -275,6 +277,7 @@ extern "C" int ph_embed_bwd(const ph_embed_bwd_args* a, hipStream_t stream) {
 extern "C" int ph_ce_fwd(const void* logits, int ld, const int64_t* labels, int B, int T, int V, float eps, float* loss,
                          float* row_lse, hipStream_t stream) {
   PH_CHECK_ARG(logits && labels && loss && row_lse && ld % 8 == 0 && ld >= V && B > 0 && T > 1, "ph_ce_fwd: bad args");
+  ProfScope prof__(PH_FAM_EMBED_CE, 0.0, 2.0 * B * (double)T * V, stream);
   (void)hipMemsetAsync(loss, 0, sizeof(float) * B, stream);
   hipLaunchKernelGGL(ce_fwd_kernel, dim3(B * T), dim3(256), 0, stream, (const bf16*)logits, ld, labels, B, T, V, eps, loss, row_lse);
   PH_LAUNCH_CHECK("ce_fwd_kernel");
@@ -284,6 +287,7 @@ extern "C" int ph_ce_fwd(const void* logits, int ld, const int64_t* labels, int 
 extern "C" int ph_ce_bwd(void* logits, int ld, const int64_t* labels, int B, int T, int V, int Vpad, float eps, const float* row_lse,
                          const float* dloss, hipStream_t stream) {
   PH_CHECK_ARG(logits && labels && row_lse && dloss && ld % 8 == 0 && Vpad % 8 == 0 && Vpad <= ld && Vpad >= V, "ph_ce_bwd: bad args");
+  ProfScope prof__(PH_FAM_EMBED_CE, 0.0, 4.0 * B * (double)T * V, stream);
   hipLaunchKernelGGL(ce_bwd_kernel, dim3(B * T), dim3(256), 0, stream, (bf16*)logits, ld, labels, B, T, V, Vpad, eps, row_lse, dloss);
   PH_LAUNCH_CHECK("ce_bwd_kernel");
   return PH_OK;

@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(ph_layernorm_bwd_args a) {
 
 extern "C" int ph_layernorm_fwd(const ph_layernorm_fwd_args* a, hipStream_t stream) {
   PH_CHECK_ARG(a && a->x && a->y && a->gamma && a->beta, "ph_layernorm_fwd: null pointer");
+  ProfScope prof__(PH_FAM_LAYERNORM, 0.0, 4.0 * a->M * (double)a->D, stream);
   PH_CHECK_ARG(a->M > 0 && a->D > 0 && (a->D % 4) == 0 && a->D <= MAX_CH * 256, "ph_layernorm_fwd: D=%d unsupported (need D%%4==0, D<=%d)", a->D, MAX_CH * 256);
   hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(a->M, 4)), dim3(256), 0, stream, *a);
   PH_LAUNCH_CHECK("ln_fwd_kernel");
@@ -175,6 +176,7 @@ extern "C" int ph_layernorm_fwd(const ph_layernorm_fwd_args* a, hipStream_t stre
 
 extern "C" int ph_layernorm_bwd(const ph_layernorm_bwd_args* a, hipStream_t stream) {
   PH_CHECK_ARG(a && a->dy && a->x && a->mean && a->rstd && a->gamma && a->dx, "ph_layernorm_bwd: null pointer");
+  ProfScope prof__(PH_FAM_LAYERNORM, 0.0, 6.0 * a->M * (double)a->D, stream);
   PH_CHECK_ARG(a->M > 0 && a->D > 0 && (a->D % 4) == 0 && a->D <= MAX_CH * 256, "ph_layernorm_bwd: D=%d unsupported", a->D);
   PH_CHECK_ARG(!a->dx_drop || !(a->drop_p > 0.f) || a->drop_seed, "ph_layernorm_bwd: dropout needs a seed");
   int grid = min(ceil_div(a->M, 4), 512);

@@ -195,6 +195,7 @@ inline int grid_for(int64_t work_items) { return (int)std::min<int64_t>(ceil_div
 extern "C" int ph_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const float* hyper, float beta1,
                         float beta2, float eps, float weight_decay, float grad_scale, hipStream_t stream) {
   PH_CHECK_ARG(p && g && m && v && hyper && n > 0, "ph_adamw: bad args");
+  ProfScope prof__(PH_FAM_OPTIM, 0.0, 30.0 * (double)n, stream);
   PH_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && (((uintptr_t)p_bf16) & 7) == 0, "ph_adamw: misaligned");
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, stream, p, g, m, v, (bf16*)p_bf16, n, hyper, beta1, beta2, eps,
                      weight_decay, grad_scale);
@@ -203,18 +204,21 @@ extern "C" int ph_adamw(float* p, const float* g, float* m, float* v, void* p_bf
 }
 extern "C" int ph_cast_f32_to_bf16(const float* x, void* y, int64_t n, hipStream_t stream) {
   PH_CHECK_ARG(x && y && n > 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 7) == 0, "ph_cast_f32_to_bf16: bad args");
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream);
   hipLaunchKernelGGL(cast_f2b_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, stream, x, (bf16*)y, n);
   PH_LAUNCH_CHECK("cast_f2b_kernel");
   return PH_OK;
 }
 extern "C" int ph_cast_bf16_to_f32(const void* x, float* y, int64_t n, hipStream_t stream) {
   PH_CHECK_ARG(x && y && n > 0 && (((uintptr_t)y) & 15) == 0 && (((uintptr_t)x) & 7) == 0, "ph_cast_bf16_to_f32: bad args");
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream);
   hipLaunchKernelGGL(cast_b2f_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, stream, (const bf16*)x, y, n);
   PH_LAUNCH_CHECK("cast_b2f_kernel");
   return PH_OK;
 }
 extern "C" int ph_colsum_bf16(const void* x, int M, int N, int ld, float* out, hipStream_t stream) {
   PH_CHECK_ARG(x && out && M > 0 && N > 0 && ld % 8 == 0 && (((uintptr_t)x) & 15) == 0, "ph_colsum_bf16: bad args");
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream);
   int grid = std::min(M, 256);
   hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(256), 0, stream, (const bf16*)x, M, N, ld, out);
   PH_LAUNCH_CHECK("colsum_kernel");
@@ -222,12 +226,14 @@ extern "C" int ph_colsum_bf16(const void* x, int M, int N, int ld, float* out, h
 }
 extern "C" int ph_add_bf16(const void* a, const void* b, void* y, int64_t n, hipStream_t stream) {
   PH_CHECK_ARG(a && b && y && n > 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)y)) & 15) == 0, "ph_add_bf16: bad args");
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream);
   hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, stream, (const bf16*)a, (const bf16*)b, (bf16*)y, n);
   PH_LAUNCH_CHECK("add_kernel");
   return PH_OK;
 }
 extern "C" int ph_act_bwd_bf16(const void* dy, const void* pre, void* dx, int64_t n, int act, hipStream_t stream) {
   PH_CHECK_ARG(dy && pre && dx && n > 0 && ((((uintptr_t)dy) | ((uintptr_t)pre) | ((uintptr_t)dx)) & 15) == 0, "ph_act_bwd_bf16: bad args");
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream);
   hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)pre, (bf16*)dx, n, act);
   PH_LAUNCH_CHECK("act_bwd_kernel");
   return PH_OK;
@@ -235,6 +241,7 @@ extern "C" int ph_act_bwd_bf16(const void* dy, const void* pre, void* dx, int64_
 extern "C" int ph_copy_rows_bf16(const void* src, int lds, ph_rowmap src_map, void* dst, int ldd, ph_rowmap dst_map, int rows,
                                  int cols, int accumulate, hipStream_t stream) {
   PH_CHECK_ARG(src && dst && rows > 0 && cols > 0 && cols % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0, "ph_copy_rows_bf16: bad args");
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream);
   hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for((int64_t)rows * cols / 8)), dim3(256), 0, stream, (const bf16*)src, lds, src_map,
                      (bf16*)dst, ldd, dst_map, rows, cols, accumulate);
   PH_LAUNCH_CHECK("copy_rows_kernel");
@@ -242,18 +249,21 @@ extern "C" int ph_copy_rows_bf16(const void* src, int lds, ph_rowmap src_map, vo
 }
 extern "C" int ph_conv_weight_to_shadow(const float* w, void* shadow, int Cout, int Cin, int ks, int Kp, hipStream_t stream) {
   PH_CHECK_ARG(w && shadow && Kp >= Cin * ks * ks, "ph_conv_weight_to_shadow: bad args");
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream);
   hipLaunchKernelGGL(conv_w_shadow_kernel, dim3((unsigned)ceil_div64((int64_t)Cout * Kp, 256)), dim3(256), 0, stream, w, (bf16*)shadow, Cout, Cin, ks, Kp);
   PH_LAUNCH_CHECK("conv_w_shadow_kernel");
   return PH_OK;
 }
 extern "C" int ph_conv_grad_from_shadow(const float* dshadow, float* dw, int Cout, int Cin, int ks, int Kp, hipStream_t stream) {
   PH_CHECK_ARG(dshadow && dw && Kp >= Cin * ks * ks, "ph_conv_grad_from_shadow: bad args");
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream);
   hipLaunchKernelGGL(conv_g_shadow_kernel, dim3((unsigned)ceil_div64((int64_t)Cout * Cin * ks * ks, 256)), dim3(256), 0, stream, dshadow, dw, Cout, Cin, ks, Kp);
   PH_LAUNCH_CHECK("conv_g_shadow_kernel");
   return PH_OK;
 }
 extern "C" int ph_advance_seed(uint64_t* seed, hipStream_t stream) {
   PH_CHECK_ARG(seed, "ph_advance_seed: null");
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream);
   hipLaunchKernelGGL(advance_seed_kernel, dim3(1), dim3(1), 0, stream, seed);
   PH_LAUNCH_CHECK("advance_seed_kernel");
   return PH_OK;

@@ -13,6 +13,8 @@ from prismer_amd/synth.py (integer-hash generator), so a fixture holds only what
   gnorm.* gsamp.* gfull.*   gradients of `total_train` under the reference freeze rule 'freeze_vision'
                 (model/prismer.py:39-59 executed by the reference's own Prismer.prepare_to_train)
   requires_grad names joined by '\n'
+  ac_samp.* ac_norm.* ac_enc_train   error of PyTorch's own bf16 autocast (same reference modules, CPU) w.r.t. the fp32
+                values above: the noise yardstick for the bf16 HIP path
 """
 import os
 import random
@@ -57,7 +59,7 @@ def run_case(name):
     out['total_train'] = total.detach().numpy()
     for k, v in enc.state_dict().items():
         if 'running_' in k or 'num_batches' in k:
-            out['bn.' + k] = v.numpy()
+            out['bn.' + k] = v.numpy().copy()
     names = []
     for n, p in holder.named_parameters():
         if not p.requires_grad:
@@ -70,6 +72,25 @@ def run_case(name):
         if n in C.FULL_GRAD_KEYS:
             out['gfull.' + n] = g.numpy()
     out['requires_grad'] = np.array('\n'.join(names))
+    # yardstick: what eager PyTorch's OWN bf16 autocast does to the same gradients on the same modules (CPU).
+    # The HIP path (bf16 storage, fp32 accumulate) is held to max(6e-2, 2x this) per parameter in tests/test_parity_gpu.py.
+    for p in holder.parameters():
+        p.grad = None
+    for k, v in case.weights()[0].items():                       # restore the BatchNorm running statistics
+        if 'running_' in k or 'num_batches' in k:
+            enc.state_dict()[k].copy_(v)
+    with torch.autocast('cpu', dtype=torch.bfloat16):
+        e2, o2 = fwd()
+        total2 = (o2.loss.float() if weights is None else weights * o2.loss.float()).mean()
+    total2.backward()
+    out['ac_enc_train'] = np.float64(((e2.float() - e.detach()).norm() / e.detach().norm()).item())
+    for n, p in holder.named_parameters():
+        if not p.requires_grad:
+            continue
+        ref_s = out['gsamp.' + n]
+        s = p.grad.detach().flatten()[C.sample_idx(n, p.numel())].float().numpy()
+        out['ac_samp.' + n] = np.float64(np.linalg.norm(s - ref_s) / (np.linalg.norm(ref_s) + 1e-30))
+        out['ac_norm.' + n] = np.float64(abs(p.grad.double().norm().item() - float(out['gnorm.' + n])) / (float(out['gnorm.' + n]) + 1e-30))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), name + '.npz')
     np.savez_compressed(path, **out)
     print(f'{name}: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)  loss_eval={out["loss_eval"]}  '
