@@ -91,6 +91,8 @@ def kernel_family_pass(tr, steps):
     lib.ph_prof_enable(1)
     for _ in range(steps):
         tr.step()
+    if os.environ.get('PH_PROF_DUMP'):
+        lib.ph_prof_dump(os.environ['PH_PROF_DUMP'].encode())
     out = (ctypes.c_double * (len(FAMILIES) * 4))()
     lib.ph_prof_collect(out)
     lib.ph_prof_enable(0)

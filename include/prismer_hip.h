@@ -233,6 +233,7 @@ int ph_advance_seed(uint64_t* seed, hipStream_t stream);
  * bytes, launches}.  Must stay disabled during hipGraph capture. */
 int ph_prof_enable(int on);
 int ph_prof_collect(double* out);
+int ph_prof_dump(const char* path);   /* CSV: family,ms,flops,description per recorded call */
 
 /* unit-test probe: exercises ds_read_b64_tr_b16 / MFMA lane layouts on the device (tests/test_kernels_gpu.py) */
 int ph_probe_layouts(const void* in_bf16, float* out, hipStream_t stream);

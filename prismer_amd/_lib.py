@@ -7,6 +7,9 @@ torch tensor into one (torch is used for device memory and streams only).
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- must be imported BEFORE the library: torch wheels bundle their own libamdhip64; loading
+#                        ours first would bring up a second HIP runtime that cannot see torch's device/streams.
+
 from . import build as _build
 
 c_void_p, c_int, c_float, c_i64, c_u32, c_u64 = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_uint32, C.c_uint64
@@ -118,6 +121,7 @@ _SIGS = {
     'ph_advance_seed': (c_int, [c_void_p, c_void_p]),
     'ph_prof_enable': (c_int, [c_int]),
     'ph_prof_collect': (c_int, [c_void_p]),
+    'ph_prof_dump': (c_int, [C.c_char_p]),
     'ph_probe_layouts': (c_int, [c_void_p, c_void_p, c_void_p]),
 }
 

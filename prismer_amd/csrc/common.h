@@ -34,11 +34,11 @@ int ph_fail(int code, const char* fmt, ...);
 enum { PH_FAM_GEMM = 0, PH_FAM_LAYERNORM, PH_FAM_ATTN_FWD, PH_FAM_ATTN_BWD, PH_FAM_FRONTEND, PH_FAM_EMBED_CE, PH_FAM_OPTIM, PH_FAM_MISC,
        PH_FAM_COUNT };
 extern int g_ph_prof_enabled;
-void ph_prof_begin(int family, double flops, double bytes, hipStream_t s);
+void ph_prof_begin(int family, double flops, double bytes, hipStream_t s, const char* desc = nullptr);
 void ph_prof_end(hipStream_t s);
 struct ProfScope {
   hipStream_t s; bool on;
-  ProfScope(int family, double flops, double bytes, hipStream_t st) : s(st), on(g_ph_prof_enabled != 0) { if (on) ph_prof_begin(family, flops, bytes, st); }
+  ProfScope(int family, double flops, double bytes, hipStream_t st, const char* desc = nullptr) : s(st), on(g_ph_prof_enabled != 0) { if (on) ph_prof_begin(family, flops, bytes, st, desc); }
   ~ProfScope() { if (on) ph_prof_end(s); }
 };
 

@@ -352,7 +352,7 @@ inline int grid_for(int64_t work_items) { return (int)std::min<int64_t>(ceil_div
 
 extern "C" int ph_patchify(const float* img, void* col, int B, int C, int R, int p, int Kp, hipStream_t stream) {
   PH_CHECK_ARG(img && col && B > 0 && R % p == 0 && Kp >= C * p * p && Kp % 8 == 0, "ph_patchify: bad args");
-  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream);
+  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream, "ph_patchify");
   int g = R / p;
   hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((int64_t)B * g * g * (Kp / 2))), dim3(256), 0, stream, img, (bf16*)col, B, C, R, p, Kp);
   PH_LAUNCH_CHECK("patchify_kernel");
@@ -362,7 +362,7 @@ extern "C" int ph_patchify(const float* img, void* col, int B, int C, int R, int
 extern "C" int ph_resize_bilinear_nchw_to_nhwc(const float* x, void* y, int B, int C, int Hin, int Win, int Hout, int Wout,
                                                hipStream_t stream) {
   PH_CHECK_ARG(x && y && B > 0 && C > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "ph_resize_bilinear: bad args");
-  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream);
+  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream, "ph_resize_bilinear_nchw_to_nhwc");
   int64_t blocks = (int64_t)B * Hout * ((C + 7) / 8);
   PH_CHECK_ARG(blocks < (1ll << 31), "ph_resize_bilinear: grid too large");
   hipLaunchKernelGGL(resize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, (bf16*)y, B, C, Hin, Win, Hout, Wout);
@@ -373,7 +373,7 @@ extern "C" int ph_resize_bilinear_nchw_to_nhwc(const float* x, void* y, int B, i
 extern "C" int ph_im2col_nhwc(const void* x, void* col, int B, int H, int W, int C, int ksize, int stride, int Kp,
                               const float* bn_scale, const float* bn_shift, hipStream_t stream) {
   PH_CHECK_ARG(x && col && (ksize == 1 || ksize == 3) && stride >= 1 && Kp >= ksize * ksize * C && Kp % 8 == 0, "ph_im2col_nhwc: bad args");
-  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream);
+  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream, "ph_im2col_nhwc");
   PH_CHECK_ARG((bn_scale == nullptr) == (bn_shift == nullptr), "ph_im2col_nhwc: scale/shift must come together");
   int pad = ksize / 2;
   int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
@@ -391,7 +391,7 @@ extern "C" int ph_im2col_nhwc(const void* x, void* col, int B, int H, int W, int
 extern "C" int ph_col2im_nhwc(const void* dcol, void* dx, int B, int H, int W, int C, int ksize, int stride, int Kp,
                               hipStream_t stream) {
   PH_CHECK_ARG(dcol && dx && (ksize == 1 || ksize == 3) && C % 8 == 0 && Kp >= ksize * ksize * C, "ph_col2im_nhwc: bad args");
-  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream);
+  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream, "ph_col2im_nhwc");
   int pad = ksize / 2;
   int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
   hipLaunchKernelGGL(col2im_kernel, dim3(grid_for((int64_t)B * H * W * (C / 8))), dim3(256), 0, stream, (const bf16*)dcol, (bf16*)dx, B,
@@ -404,7 +404,7 @@ extern "C" int ph_bn_stats(const void* y, int M, int C, const float* gamma, cons
                            float* running_var, float momentum, float eps, int training, float* mean, float* rstd, float* scale,
                            float* shift, hipStream_t stream) {
   PH_CHECK_ARG(gamma && beta && running_mean && running_var && mean && rstd && scale && shift, "ph_bn_stats: null pointer");
-  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream);
+  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream, "ph_bn_stats");
   PH_CHECK_ARG(C % 8 == 0 && C <= 2048 && M > 0, "ph_bn_stats: C=%d unsupported", C);
   float* sums = scale;   // scale/shift double as the [2*C] reduction scratch when they are contiguous; otherwise use mean/rstd
   // we need 2*C contiguous floats: require shift == scale + C (the host allocates the four vectors as one block)
@@ -427,7 +427,7 @@ extern "C" int ph_bn_relu_bwd(const void* da, const void* y, void* dy, int M, in
                               const float* mean, const float* rstd, float* dgamma, float* dbeta, float* sums,
                               hipStream_t stream) {
   PH_CHECK_ARG(da && y && dy && gamma && beta && mean && rstd && sums, "ph_bn_relu_bwd: null pointer");
-  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream);
+  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream, "ph_bn_relu_bwd");
   PH_CHECK_ARG(C % 8 == 0 && C <= 2048 && M > 0, "ph_bn_relu_bwd: C=%d unsupported", C);
   (void)hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, stream);
   int rpp = 256 / (C / 8);
@@ -444,7 +444,7 @@ extern "C" int ph_tokens_finalize(const void* feat, const float* pos, void* toke
                                   int tok_off, const int64_t* inst, int E, int g, const int32_t* table, const float* inst_emb,
                                   hipStream_t stream) {
   PH_CHECK_ARG(feat && pos && tokens && D % 4 == 0 && (!inst || g * g == G), "ph_tokens_finalize: bad args");
-  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream);
+  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream, "ph_tokens_finalize");
   PH_CHECK_ARG(!inst || (table && inst_emb && E > 0), "ph_tokens_finalize: instance inputs incomplete");
   hipLaunchKernelGGL(tokens_kernel, dim3(grid_for((int64_t)B * G * (D / 4))), dim3(256), 0, stream, (const bf16*)feat, pos, (bf16*)tokens, B,
                      G, D, tok_per_batch, tok_off, inst, E, g, table, inst_emb);
@@ -456,7 +456,7 @@ extern "C" int ph_tokens_finalize_bwd(const void* dtokens, void* dfeat, float* d
                                       int tok_off, const int64_t* inst, int E, int g, const int32_t* table, float* dinst_emb,
                                       hipStream_t stream) {
   PH_CHECK_ARG(dtokens && D % 4 == 0 && (!inst || g * g == G), "ph_tokens_finalize_bwd: bad args");
-  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream);
+  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream, "ph_tokens_finalize_bwd");
   hipLaunchKernelGGL(tokens_bwd_kernel, dim3(ceil_div(G * (D / 4), 256)), dim3(256), 0, stream, (const bf16*)dtokens, (bf16*)dfeat, dpos, B, G,
                      D, tok_per_batch, tok_off, inst, E, g, table, dinst_emb);
   PH_LAUNCH_CHECK("tokens_bwd_kernel");
@@ -466,7 +466,7 @@ extern "C" int ph_tokens_finalize_bwd(const void* dtokens, void* dfeat, float* d
 extern "C" int ph_gather_taps(const float* in, float* out, const int32_t* idx, const float* w, int n_out, int taps, int D,
                               hipStream_t stream) {
   PH_CHECK_ARG(in && out && idx && w, "ph_gather_taps: null pointer");
-  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream);
+  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream, "ph_gather_taps");
   hipLaunchKernelGGL(gather_taps_kernel, dim3((unsigned)ceil_div64((int64_t)n_out * D, 256)), dim3(256), 0, stream, in, out, idx, w, n_out, taps, D);
   PH_LAUNCH_CHECK("gather_taps_kernel");
   return PH_OK;
@@ -474,7 +474,7 @@ extern "C" int ph_gather_taps(const float* in, float* out, const int32_t* idx, c
 extern "C" int ph_scatter_taps(const float* dout, float* din, const int32_t* idx, const float* w, int n_out, int taps, int D,
                                hipStream_t stream) {
   PH_CHECK_ARG(dout && din && idx && w, "ph_scatter_taps: null pointer");
-  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream);
+  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream, "ph_scatter_taps");
   hipLaunchKernelGGL(scatter_taps_kernel, dim3((unsigned)ceil_div64((int64_t)n_out * D, 256)), dim3(256), 0, stream, dout, din, idx, w, n_out, taps, D);
   PH_LAUNCH_CHECK("scatter_taps_kernel");
   return PH_OK;

@@ -323,7 +323,9 @@ int dispatch_layout(const GemmParams& p, int ta, int tb, int splits, hipStream_t
 
 extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
   PH_CHECK_ARG(a && a->A && a->B && a->C, "ph_gemm_bf16: null pointer");
-  ProfScope prof__(PH_FAM_GEMM, 2.0 * a->M * (double)a->N * a->K, 2.0 * ((double)a->M * a->K + (double)a->N * a->K + (double)a->M * a->N), stream);
+  char desc__[96];
+  if (g_ph_prof_enabled) snprintf(desc__, sizeof(desc__), "gemm M=%d N=%d K=%d ta=%d tb=%d f32=%d acc=%d", a->M, a->N, a->K, a->trans_a, a->trans_b, a->out_f32, a->accumulate);
+  ProfScope prof__(PH_FAM_GEMM, 2.0 * a->M * (double)a->N * a->K, 2.0 * ((double)a->M * a->K + (double)a->N * a->K + (double)a->M * a->N), stream, desc__);
   PH_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "ph_gemm_bf16: bad dims M=%d N=%d K=%d", a->M, a->N, a->K);
   PH_CHECK_ARG((a->lda % 8) == 0 && (a->ldb % 8) == 0, "ph_gemm_bf16: lda/ldb must be multiples of 8 (16-B rows)");
   PH_CHECK_ARG((((uintptr_t)a->A | (uintptr_t)a->B) & 15) == 0, "ph_gemm_bf16: A/B must be 16-B aligned");

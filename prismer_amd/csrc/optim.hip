@@ -204,21 +204,21 @@ extern "C" int ph_adamw(float* p, const float* g, float* m, float* v, void* p_bf
 }
 extern "C" int ph_cast_f32_to_bf16(const float* x, void* y, int64_t n, hipStream_t stream) {
   PH_CHECK_ARG(x && y && n > 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 7) == 0, "ph_cast_f32_to_bf16: bad args");
-  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream);
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_cast_f32_to_bf16");
   hipLaunchKernelGGL(cast_f2b_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, stream, x, (bf16*)y, n);
   PH_LAUNCH_CHECK("cast_f2b_kernel");
   return PH_OK;
 }
 extern "C" int ph_cast_bf16_to_f32(const void* x, float* y, int64_t n, hipStream_t stream) {
   PH_CHECK_ARG(x && y && n > 0 && (((uintptr_t)y) & 15) == 0 && (((uintptr_t)x) & 7) == 0, "ph_cast_bf16_to_f32: bad args");
-  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream);
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_cast_bf16_to_f32");
   hipLaunchKernelGGL(cast_b2f_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, stream, (const bf16*)x, y, n);
   PH_LAUNCH_CHECK("cast_b2f_kernel");
   return PH_OK;
 }
 extern "C" int ph_colsum_bf16(const void* x, int M, int N, int ld, float* out, hipStream_t stream) {
   PH_CHECK_ARG(x && out && M > 0 && N > 0 && ld % 8 == 0 && (((uintptr_t)x) & 15) == 0, "ph_colsum_bf16: bad args");
-  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream);
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_colsum_bf16");
   int grid = std::min(M, 256);
   hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(256), 0, stream, (const bf16*)x, M, N, ld, out);
   PH_LAUNCH_CHECK("colsum_kernel");
@@ -226,14 +226,14 @@ extern "C" int ph_colsum_bf16(const void* x, int M, int N, int ld, float* out, h
 }
 extern "C" int ph_add_bf16(const void* a, const void* b, void* y, int64_t n, hipStream_t stream) {
   PH_CHECK_ARG(a && b && y && n > 0 && ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)y)) & 15) == 0, "ph_add_bf16: bad args");
-  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream);
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_add_bf16");
   hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, stream, (const bf16*)a, (const bf16*)b, (bf16*)y, n);
   PH_LAUNCH_CHECK("add_kernel");
   return PH_OK;
 }
 extern "C" int ph_act_bwd_bf16(const void* dy, const void* pre, void* dx, int64_t n, int act, hipStream_t stream) {
   PH_CHECK_ARG(dy && pre && dx && n > 0 && ((((uintptr_t)dy) | ((uintptr_t)pre) | ((uintptr_t)dx)) & 15) == 0, "ph_act_bwd_bf16: bad args");
-  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream);
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_act_bwd_bf16");
   hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, stream, (const bf16*)dy, (const bf16*)pre, (bf16*)dx, n, act);
   PH_LAUNCH_CHECK("act_bwd_kernel");
   return PH_OK;
@@ -241,7 +241,7 @@ extern "C" int ph_act_bwd_bf16(const void* dy, const void* pre, void* dx, int64_
 extern "C" int ph_copy_rows_bf16(const void* src, int lds, ph_rowmap src_map, void* dst, int ldd, ph_rowmap dst_map, int rows,
                                  int cols, int accumulate, hipStream_t stream) {
   PH_CHECK_ARG(src && dst && rows > 0 && cols > 0 && cols % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0, "ph_copy_rows_bf16: bad args");
-  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream);
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_copy_rows_bf16");
   hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for((int64_t)rows * cols / 8)), dim3(256), 0, stream, (const bf16*)src, lds, src_map,
                      (bf16*)dst, ldd, dst_map, rows, cols, accumulate);
   PH_LAUNCH_CHECK("copy_rows_kernel");
@@ -249,21 +249,21 @@ extern "C" int ph_copy_rows_bf16(const void* src, int lds, ph_rowmap src_map, vo
 }
 extern "C" int ph_conv_weight_to_shadow(const float* w, void* shadow, int Cout, int Cin, int ks, int Kp, hipStream_t stream) {
   PH_CHECK_ARG(w && shadow && Kp >= Cin * ks * ks, "ph_conv_weight_to_shadow: bad args");
-  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream);
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_conv_weight_to_shadow");
   hipLaunchKernelGGL(conv_w_shadow_kernel, dim3((unsigned)ceil_div64((int64_t)Cout * Kp, 256)), dim3(256), 0, stream, w, (bf16*)shadow, Cout, Cin, ks, Kp);
   PH_LAUNCH_CHECK("conv_w_shadow_kernel");
   return PH_OK;
 }
 extern "C" int ph_conv_grad_from_shadow(const float* dshadow, float* dw, int Cout, int Cin, int ks, int Kp, hipStream_t stream) {
   PH_CHECK_ARG(dshadow && dw && Kp >= Cin * ks * ks, "ph_conv_grad_from_shadow: bad args");
-  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream);
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_conv_grad_from_shadow");
   hipLaunchKernelGGL(conv_g_shadow_kernel, dim3((unsigned)ceil_div64((int64_t)Cout * Cin * ks * ks, 256)), dim3(256), 0, stream, dshadow, dw, Cout, Cin, ks, Kp);
   PH_LAUNCH_CHECK("conv_g_shadow_kernel");
   return PH_OK;
 }
 extern "C" int ph_advance_seed(uint64_t* seed, hipStream_t stream) {
   PH_CHECK_ARG(seed, "ph_advance_seed: null");
-  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream);
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_advance_seed");
   hipLaunchKernelGGL(advance_seed_kernel, dim3(1), dim3(1), 0, stream, seed);
   PH_LAUNCH_CHECK("advance_seed_kernel");
   return PH_OK;
