@@ -60,7 +60,9 @@ typedef struct {
   int out_f32;                    /* C is fp32 instead of bf16 */
   int accumulate;                 /* C += result */
   float alpha;
-  int split_k;                    /* 0 = auto (only out_f32 + accumulate GEMMs are ever split) */
+  int split_k;                    /* 0 = auto */
+  void* workspace; int64_t workspace_bytes;   /* optional fp32 scratch for split-K partials (deterministic reduce + full
+                                     epilogue); without it only plain fp32-accumulate GEMMs are split (atomics) */
 } ph_gemm_args;
 int ph_gemm_bf16(const ph_gemm_args* args, hipStream_t stream);
 

@@ -35,7 +35,8 @@ class GemmArgs(C.Structure):
                 ('act_in', c_void_p), ('ld_act', c_int),
                 ('residual', c_void_p), ('ldr', c_int),
                 ('drop_p', c_float), ('drop_seed', c_void_p), ('drop_stream', c_u32),
-                ('out_f32', c_int), ('accumulate', c_int), ('alpha', c_float), ('split_k', c_int)]
+                ('out_f32', c_int), ('accumulate', c_int), ('alpha', c_float), ('split_k', c_int),
+                ('workspace', c_void_p), ('workspace_bytes', c_i64)]
 
 
 class LayerNormFwdArgs(C.Structure):

@@ -58,6 +58,7 @@ struct GemmParams {
   float alpha;
   int k_tiles_per_split;   // in units of BK
   int tiles_m, tiles_n;
+  float* ws; int ldws;     // split-K partial tiles: ws[split][M][ldws] fp32 (plain stores), folded by splitk_reduce_kernel
 };
 
 // ---- global -> register staging ------------------------------------------------------------------------
@@ -143,7 +144,13 @@ __device__ __forceinline__ bf16x8 frag_ks(const char* lds, int rbase, int kk, in
 __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n, float (&v)[4], bool splitk, bool drop,
                                                const DropCtx& dc) {
   const bool full = (n + 4 <= p.N);
-  if (splitk) {   // raw fp32 atomics; bias / activation are not allowed with split-K (checked on host)
+  if (splitk && p.ws) {   // split-K with workspace: raw partial sums, the full epilogue runs in splitk_reduce_kernel
+    float* c = p.ws + ((size_t)blockIdx.z * p.M + m) * p.ldws + n;
+    f32x4 t = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(c) = t;      // ldws % 4 == 0 and n % 4 == 0: always a full, aligned vector (pad columns are scratch)
+    return;
+  }
+  if (splitk) {   // no workspace: raw fp32 atomics into C (host guarantees a plain fp32 accumulate epilogue)
     float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -296,6 +303,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   });
 }
 
+// folds the split-K partials and applies the fused epilogue (bias / activation / dropout / residual / accumulate / dtype)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int splits) {
+  const int n4 = (p.N + 3) / 4;
+  int64_t total = (int64_t)p.M * n4;
+  DropCtx dc;
+  const bool drop = p.drop_p > 0.0f;
+  if (drop) dc = make_drop(p.drop_seed, p.drop_stream, p.drop_p);
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    int m = (int)(id / n4), n = (int)(id % n4) * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < splits; ++s) acc += *reinterpret_cast<const f32x4*>(p.ws + ((size_t)s * p.M + m) * p.ldws + n);
+    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+    epilogue_store(p, m, n, v, false, drop, dc);
+  }
+}
+
 template <int BM, int BN, bool TA, bool TB>
 int launch(const GemmParams& p, int splits, hipStream_t s) {
   constexpr int smem = 2 * ((TA ? TileBytes<BM>::ks : TileBytes<BM>::kc) + (TB ? TileBytes<BN>::ks : TileBytes<BN>::kc));
@@ -343,24 +366,50 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
   p.drop_p = a->drop_p; p.drop_seed = a->drop_seed; p.drop_stream = a->drop_stream;
   p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.alpha = a->alpha;
 
-  bool small = ((int64_t)ceil_div(a->M, 128) * ceil_div(a->N, 128) < 128) || a->M <= 64 || a->N <= 64;
-  int BM = small ? 64 : 128;
-  p.tiles_m = ceil_div(a->M, BM); p.tiles_n = ceil_div(a->N, BM);
-  int kt = ceil_div(a->K, BK);
-  int splits = a->split_k;
-  int tiles = p.tiles_m * p.tiles_n;
-  bool plain = !a->bias && !a->pre_out && !a->act_in && a->act == PH_ACT_NONE && !a->residual && !(a->drop_p > 0.0f) &&
-               a->out_f32 && a->accumulate;
-  if (splits <= 0) {   // auto: split only accumulate-into-fp32 GEMMs (weight gradients) that under-fill the chip
-    splits = 1;
-    if (plain && tiles < 256 && kt >= 8) {
-      splits = min(min(ceil_div(512, tiles), kt / 4), 32);
-      if (splits < 1) splits = 1;
+  // ---- tile shape and split-K selection -------------------------------------------------------------------------
+  // 128x128 tiles when they fill the chip; otherwise split the K loop (partials -> workspace -> reduce+epilogue) so
+  // that >= ~2 blocks per CU are in flight; 64x64 tiles for genuinely small outputs.
+  const int kt = ceil_div(a->K, BK);
+  const int ldws = (a->N + 3) / 4 * 4;
+  const bool plain_acc = !a->bias && !a->pre_out && !a->act_in && a->act == PH_ACT_NONE && !a->residual && !(a->drop_p > 0.0f) &&
+                         a->out_f32 && a->accumulate;
+  auto ws_fits = [&](int sp) { return a->workspace && (int64_t)sp * a->M * ldws * 4 <= a->workspace_bytes; };
+  const int64_t t128 = (int64_t)ceil_div(a->M, 128) * ceil_div(a->N, 128), t64 = (int64_t)ceil_div(a->M, 64) * ceil_div(a->N, 64);
+  int BM = 128, splits = 1;
+  if (a->M <= 64 || a->N <= 64) BM = 64;
+  if (a->split_k > 0) {
+    splits = a->split_k;
+    if (BM == 128 && t128 * splits < 128) BM = 64;
+  } else {
+    int64_t tiles = BM == 128 ? t128 : t64;
+    if (tiles < 200) {
+      int want = (int)min((int64_t)max(kt / 2, 1), (int64_t)ceil_div(512, (int)tiles));
+      while (want > 1 && !ws_fits(want) && !plain_acc) --want;
+      if (want > 1 && (ws_fits(want) || plain_acc)) splits = want;
+      if (BM == 128 && tiles * splits < 160) {   // K too short to split that far: smaller tiles instead
+        BM = 64;
+        tiles = t64;
+        want = (int)min((int64_t)max(kt / 2, 1), (int64_t)ceil_div(512, (int)tiles));
+        while (want > 1 && !ws_fits(want) && !plain_acc) --want;
+        splits = (want > 1 && (ws_fits(want) || plain_acc)) ? want : 1;
+      }
     }
   }
-  PH_CHECK_ARG(splits == 1 || plain, "ph_gemm_bf16: split_k > 1 needs out_f32 + accumulate and no fused epilogue");
+  if (splits > kt) splits = kt;
+  p.tiles_m = ceil_div(a->M, BM); p.tiles_n = ceil_div(a->N, BM);
   p.k_tiles_per_split = ceil_div(kt, splits);
   splits = ceil_div(kt, p.k_tiles_per_split);
-  if (small) return dispatch_layout<64, 64>(p, a->trans_a, a->trans_b, splits, stream);
-  return dispatch_layout<128, 128>(p, a->trans_a, a->trans_b, splits, stream);
+  p.ws = nullptr; p.ldws = ldws;
+  if (splits > 1) {
+    if (ws_fits(splits)) p.ws = (float*)a->workspace;
+    else PH_CHECK_ARG(plain_acc, "ph_gemm_bf16: split_k > 1 without workspace needs out_f32 + accumulate and no fused epilogue");
+  }
+  const bool small = BM == 64;
+  int rc = small ? dispatch_layout<64, 64>(p, a->trans_a, a->trans_b, splits, stream)
+                 : dispatch_layout<128, 128>(p, a->trans_a, a->trans_b, splits, stream);
+  if (rc != PH_OK || !p.ws) return rc;
+  int grid = (int)min((int64_t)2048, ceil_div64((int64_t)a->M * ((a->N + 3) / 4), 256));
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, p, splits);
+  PH_LAUNCH_CHECK("splitk_reduce_kernel");
+  return PH_OK;
 }

@@ -83,25 +83,37 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const bf16* __restrict__ d
   if (blockIdx.x == 0 && threadIdx.x < (n & 7)) { int64_t i = (n8 << 3) + threadIdx.x; dx[i] = f2bf(bf2f(dy[i]) * act_grad(act, bf2f(pre[i]))); }
 }
 
-// out[n] += sum_m x[m][n] : each block owns a 64-row strip, thread t owns columns {t*8 .. t*8+7} mod pass.
+// out[n] += sum_m x[m][n].  Block = 32 column-chunks (8 columns each) x 8 row lanes; grid = (column panels, row strips).
+// Rows are folded in registers, the 8 row lanes through LDS, and each block issues ONE fp32 atomic per column
+// (device-scope atomics are slow on the multi-XCD part: ~35 / ns chip-wide, so they are kept to strips x N).
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, int M, int N, int ld, float* __restrict__ out) {
-  const int nch = N / 8;
-  for (int c = threadIdx.x; c < nch; c += 256) {
-    float acc[8];
+  __shared__ float red[8][256];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 256 + cl * 8;
+  const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  float acc[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    for (int r = blockIdx.x; r < M; r += gridDim.x) {
-      bf16x8 t = *reinterpret_cast<const bf16x8*>(x + (int64_t)r * ld + c * 8);
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (c0 + 8 <= N) {
+    for (int r = r0 + rl; r < r1; r += 8) {
+      bf16x8 t = *reinterpret_cast<const bf16x8*>(x + (int64_t)r * ld + c0);
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += bf2f(t[e]);
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(out + c * 8 + e, acc[e]);
+  } else if (c0 < N) {
+    for (int r = r0 + rl; r < r1; r += 8)
+      for (int e = 0; e < 8 && c0 + e < N; ++e) acc[e] += bf2f(x[(int64_t)r * ld + c0 + e]);
   }
-  for (int n = nch * 8 + threadIdx.x; n < N; n += 256) {   // ragged tail columns
-    float acc = 0.f;
-    for (int r = blockIdx.x; r < M; r += gridDim.x) acc += bf2f(x[(int64_t)r * ld + n]);
-    atomicAdd(out + n, acc);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][cl * 8 + e] = acc[e];
+  __syncthreads();
+  int col = blockIdx.x * 256 + threadIdx.x;
+  if (col < N) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
+    atomicAdd(out + col, s);
   }
 }
 
@@ -219,8 +231,8 @@ extern "C" int ph_cast_bf16_to_f32(const void* x, float* y, int64_t n, hipStream
 extern "C" int ph_colsum_bf16(const void* x, int M, int N, int ld, float* out, hipStream_t stream) {
   PH_CHECK_ARG(x && out && M > 0 && N > 0 && ld % 8 == 0 && (((uintptr_t)x) & 15) == 0, "ph_colsum_bf16: bad args");
   ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_colsum_bf16");
-  int grid = std::min(M, 256);
-  hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(256), 0, stream, (const bf16*)x, M, N, ld, out);
+  int strips = std::max(1, std::min(64, M / 64));
+  hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 256), strips), dim3(256), 0, stream, (const bf16*)x, M, N, ld, out);
   PH_LAUNCH_CHECK("colsum_kernel");
   return PH_OK;
 }

@@ -26,6 +26,18 @@ class Dropout:
 
 NO_DROP = None
 
+_WS = {}
+WS_BYTES = 256 << 20
+
+
+def _workspace(device):
+    """per-device fp32 scratch for split-K partial tiles (allocated once; reused by every GEMM on the stream)"""
+    ws = _WS.get(device)
+    if ws is None:
+        ws = torch.empty(WS_BYTES // 4, dtype=F32, device=device)
+        _WS[device] = ws
+    return ws
+
 
 def gemm(a, b, out=None, *, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, pre_out=None, act_in=None,
          residual=None, drop=None, out_f32=False, accumulate=False, alpha=1.0, split_k=0, M=None, N=None, K=None):
@@ -55,6 +67,8 @@ def gemm(a, b, out=None, *, trans_a=False, trans_b=False, bias=None, act=ACT_NON
     else:
         g.drop_p, g.drop_seed, g.drop_stream = 0.0, None, 0
     g.out_f32, g.accumulate, g.alpha, g.split_k = int(out_f32), int(accumulate), float(alpha), int(split_k)
+    ws = _workspace(a.device)
+    g.workspace, g.workspace_bytes = ws.data_ptr(), WS_BYTES
     check(lib.ph_gemm_bf16(C.byref(g), _stream()), 'ph_gemm_bf16')
     return out
 
