@@ -103,15 +103,17 @@ def kernel_family_pass(tr, steps):
     return fam
 
 
-def cpu_baseline(seconds_budget=25.0):
+def cpu_baseline(seconds_budget=20.0):
     """CPU oracle (a port: plain-PyTorch fp32 restatement of the reference modules, pinned to reference outputs by
-    tests/golden) timed on the host cores: Prismer-BASE caption train step, batch 4, T=30, freeze_vision."""
+    tests/golden) timed on the host: Prismer-BASE caption train step (fwd+bwd+AdamW), batch 2, T=30, freeze_vision.
+    Bounded: at most 32 threads (torch's CPU kernels thrash with hundreds of threads on these op sizes) and the loop stops
+    as soon as the budget is exceeded -- at least one timed step."""
     from oracle import prismer_oracle as O
     from prismer_amd import config as pcfg, synth
-    cores = os.cpu_count()
+    cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     d = pcfg.prismer_base()
-    B, T = 4, 30
+    B, T = 2, 30
     esd, dsd = synth.synth_encoder_state(d, 0), synth.synth_decoder_state(d, 0)
     names = ['expert_encoder.' + k for k in esd] + ['text_decoder.' + k for k in dsd]
     fm = O.freeze_mask(names, 'freeze_vision')
@@ -130,14 +132,16 @@ def cpu_baseline(seconds_budget=25.0):
         loss, _, _ = O.caption_loss(esd, dsd, x, ids, mask, labels, d, train_bn=True, instance_table=tab, bn_updates={})
         loss.backward()
         opt.step()
-    step()                                             # warm-up
-    t0 = time.time(); n = 0
-    while n < 1 or (time.time() - t0) < seconds_budget * 0.6:
-        step(); n += 1
-    dt = (time.time() - t0) / n
+    times = []
+    t_start = time.time()
+    while True:
+        t0 = time.time(); step(); times.append(time.time() - t0)
+        if time.time() - t_start > seconds_budget or len(times) >= 6:
+            break
+    dt = min(times)                                    # first step carries one-off allocation cost: report the best step
     return dict(value=round(B / dt, 3), unit='images/sec', cores=cores, kind='port',
-                sample=f'Prismer-BASE caption train step (fwd+bwd+AdamW, freeze_vision, fp32), batch {B}, T={T}, {n} timed step(s) of '
-                       f'{dt:.2f} s on {cores} host threads')
+                sample=f'Prismer-BASE caption train step (fwd+bwd+AdamW, freeze_vision, fp32 oracle), batch {B}, T={T}: best of '
+                       f'{len(times)} step(s) = {dt:.2f} s on {cores} threads (host has {os.cpu_count()} cpus)')
 
 
 def main():

@@ -344,6 +344,9 @@ class EncoderProgram:
                 val = x[name]
                 inp = val['label'] if name == 'obj_detection' else val
                 f = self.stem_fwd(dom, inp.contiguous().float(), training, sv)
+                if f.shape[0] != B * G:
+                    raise RuntimeError(f'expert map {name}: stem produced {f.shape[0] // B} tokens per image, program expects {G} '
+                                       f'(expert_resolution={d.expert_resolution})')
                 if name == 'obj_detection':
                     inst = val['instance'].contiguous()
                     ops.tokens_finalize(f, pos_e, xf, B, G, W, Mx, ei * G, inst, inst.shape[-1], d.expert_grid, inst_table,

@@ -141,6 +141,14 @@ class Trainer:
     # ------------------------------------------------------------------------------------------ public API
     def set_batch(self, experts, input_ids, attention_mask, labels, weights=None):
         """(re)binds the static input buffers. First call allocates them; later calls copy into them."""
+        for k, v in experts.items():                 # expert-map resolution fixes the program's token geometry
+            if k != 'rgb':
+                er = (v['label'] if isinstance(v, dict) else v).shape[-1]
+                if er != self.enc.expert_resolution:
+                    assert self.graphs is None, 'expert resolution changed after graph capture'
+                    self.enc.expert_resolution, self.enc._prog = er, None
+                    self.enc_prog = self.enc._program()
+                break
         if self.static is None:
             def clone(t):
                 return {k: clone(v) for k, v in t.items()} if isinstance(t, dict) else t.to(self.device).contiguous().clone()
