@@ -93,8 +93,9 @@ typedef struct {
   void* dx;                       /* bf16 [M,D] = LN'(dy) + dskip */
   void* dx_drop;                  /* optional bf16 [M,D] = dx * dropout-mask / (1-p) (mask of the fwd GEMM epilogue) */
   float drop_p; const uint64_t* drop_seed; uint32_t drop_stream;
-  float* dgamma; float* dbeta;    /* fp32 [D], ACCUMULATED (atomics); NULL when the affine is frozen */
+  float* dgamma; float* dbeta;    /* fp32 [D], ACCUMULATED; NULL when the affine is frozen */
   int M, D;
+  float* partial_ws; int64_t partial_ws_bytes;   /* optional scratch (>= 512*2*D*4 B): per-block partials + reduce instead of atomics */
 } ph_layernorm_bwd_args;
 int ph_layernorm_bwd(const ph_layernorm_bwd_args* args, hipStream_t stream);
 

@@ -50,7 +50,8 @@ class LayerNormBwdArgs(C.Structure):
                 ('x', c_void_p), ('mean', c_void_p), ('rstd', c_void_p), ('gamma', c_void_p),
                 ('dskip', c_void_p), ('dx', c_void_p), ('dx_drop', c_void_p),
                 ('drop_p', c_float), ('drop_seed', c_void_p), ('drop_stream', c_u32),
-                ('dgamma', c_void_p), ('dbeta', c_void_p), ('M', c_int), ('D', c_int)]
+                ('dgamma', c_void_p), ('dbeta', c_void_p), ('M', c_int), ('D', c_int),
+                ('partial_ws', c_void_p), ('partial_ws_bytes', c_i64)]
 
 
 class AttnFwdArgs(C.Structure):

@@ -212,7 +212,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
   }
 }
 
-template <int BM, int BN, bool TA, bool TB>
+template <int BM, int BN, bool TA, bool TB, int PF>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   constexpr int WM = BM / 2, WN = BN / 2;   // wave tile
   constexpr int TM = WM / 32, TN = WN / 32; // 32x32 MFMA tiles per wave
@@ -244,27 +244,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  u32x4 ra[BM * 8 / 256], rb[BN * 8 / 256];
-  auto gload = [&](int kt) {
+  // Register prefetch ring of depth D: the global loads of k-tiles t+1 .. t+D are in flight while tile t is multiplied
+  // (HBM/L2 latency is ~1-2 us, one 128x128x64 tile of MFMA work is ~0.2-0.4 us: depth 1 stalls every iteration).
+  // Ring slot s holds tile (t0 + s); slots are indexed with compile-time constants only (static_for) so they stay
+  // in VGPRs.  LDS stays double-buffered: one barrier per k-tile.
+  constexpr int D = PF;
+  u32x4 ra[D][BM * 8 / 256], rb[D][BN * 8 / 256];
+  auto gload = [&](int kt, u32x4 (&xa)[BM * 8 / 256], u32x4 (&xb)[BN * 8 / 256]) {
     int k0 = kt * BK;
-    if (TA) load_ks<BM>(p.A, p.lda, m0, p.M, k0, p.K, ra); else load_kc<BM>(p.A, p.lda, m0, p.M, k0, p.K, ra);
-    if (TB) load_ks<BN>(p.B, p.ldb, n0, p.N, k0, p.K, rb); else load_kc<BN>(p.B, p.ldb, n0, p.N, k0, p.K, rb);
+    if (TA) load_ks<BM>(p.A, p.lda, m0, p.M, k0, p.K, xa); else load_kc<BM>(p.A, p.lda, m0, p.M, k0, p.K, xa);
+    if (TB) load_ks<BN>(p.B, p.ldb, n0, p.N, k0, p.K, xb); else load_kc<BN>(p.B, p.ldb, n0, p.N, k0, p.K, xb);
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, const u32x4 (&xa)[BM * 8 / 256], const u32x4 (&xb)[BN * 8 / 256]) {
     char* sa = smem + buf * STAGE;
     char* sb = sa + A_BYTES;
-    if (TA) store_ks<BM>(sa, ra); else store_kc<BM>(sa, ra);
-    if (TB) store_ks<BN>(sb, rb); else store_kc<BN>(sb, rb);
+    if (TA) store_ks<BM>(sa, xa); else store_kc<BM>(sa, xa);
+    if (TB) store_ks<BN>(sb, xb); else store_kc<BN>(sb, xb);
   };
-
-  gload(kt_begin);
-  lstore(0);
-  __syncthreads();
-  int cur = 0;
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    bool more = kt + 1 < kt_end;
-    if (more) gload(kt + 1);
-    const char* la = smem + cur * STAGE;
+  auto compute = [&](int buf) {
+    const char* la = smem + buf * STAGE;
     const char* lb = la + A_BYTES;
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
@@ -281,9 +279,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fx[i], acc[i][j], 0, 0, 0);
     }
-    if (more) lstore(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
+  };
+
+  static_for(std::make_integer_sequence<int, D>{}, [&](auto sidx) {
+    constexpr int sl = decltype(sidx)::value;
+    if (kt_begin + sl < kt_end) gload(kt_begin + sl, ra[sl], rb[sl]);
+  });
+  lstore(0, ra[0], rb[0]);
+  __syncthreads();
+  int cur = 0;
+  for (int t0 = kt_begin; t0 < kt_end; t0 += D) {
+    static_for(std::make_integer_sequence<int, D>{}, [&](auto sidx) {
+      constexpr int sl = decltype(sidx)::value;
+      constexpr int nx = (sl + 1) % D;
+      const int kt = t0 + sl;
+      if (kt < kt_end) {                                    // block-uniform
+        if (kt + D < kt_end) gload(kt + D, ra[sl], rb[sl]);  // slot sl was drained into LDS one iteration ago
+        compute(cur);
+        if (kt + 1 < kt_end) lstore(cur ^ 1, ra[nx], rb[nx]);
+        __syncthreads();
+        cur ^= 1;
+      }
+    });
   }
 
   // ---- epilogue: lane holds, for tile (i,j): m = l&31 ; n = 8*(r>>2) + 4*(l>>5) + (r&3) -------------------
@@ -319,17 +336,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
   }
 }
 
+// prefetch depth per tile size (VGPR budget: 128x128 tiles hold 32 staging VGPRs per slot, 64x64 tiles 16)
+#define PF_DEPTH(bm) ((bm) == 128 ? 3 : 4)
+
 template <int BM, int BN, bool TA, bool TB>
 int launch(const GemmParams& p, int splits, hipStream_t s) {
   constexpr int smem = 2 * ((TA ? TileBytes<BM>::ks : TileBytes<BM>::kc) + (TB ? TileBytes<BN>::ks : TileBytes<BN>::kc));
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, TA, TB>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, TA, TB, PF_DEPTH(BM)>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, TA, TB>), grid, dim3(256), smem, s, p);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, TA, TB, PF_DEPTH(BM)>), grid, dim3(256), smem, s, p);
   PH_LAUNCH_CHECK("gemm_kernel");
   return PH_OK;
 }

@@ -156,11 +156,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(ph_layernorm_bwd_args a) {
         float sg = 0.f, sb = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) { sg += red_flat[(0 * 4 + w) * 512 + col]; sb += red_flat[(1 * 4 + w) * 512 + col]; }
-        if (a.dgamma) atomicAdd(a.dgamma + gc, sg);
-        if (a.dbeta) atomicAdd(a.dbeta + gc, sb);
+        if (a.partial_ws) {          // per-block partials, folded by ln_param_reduce_kernel (no atomics)
+          a.partial_ws[((size_t)blockIdx.x * 2 + 0) * a.D + gc] = sg;
+          a.partial_ws[((size_t)blockIdx.x * 2 + 1) * a.D + gc] = sb;
+        } else {
+          if (a.dgamma) atomicAdd(a.dgamma + gc, sg);
+          if (a.dbeta) atomicAdd(a.dbeta + gc, sb);
+        }
       }
     }
   }
+}
+
+// dgamma[c] += sum_b partial[b][0][c], dbeta[c] += sum_b partial[b][1][c]
+__global__ void ln_param_reduce_kernel(const float* __restrict__ ws, int nblk, int D, float* dgamma, float* dbeta) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 2 * D) return;
+  int which = c / D, col = c % D;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += ws[((size_t)b * 2 + which) * D + col];
+  float* dst = which ? dbeta : dgamma;
+  if (dst) dst[col] += s;
 }
 
 }  // namespace
@@ -180,7 +196,12 @@ extern "C" int ph_layernorm_bwd(const ph_layernorm_bwd_args* a, hipStream_t stre
   PH_CHECK_ARG(a->M > 0 && a->D > 0 && (a->D % 4) == 0 && a->D <= MAX_CH * 256, "ph_layernorm_bwd: D=%d unsupported", a->D);
   PH_CHECK_ARG(!a->dx_drop || !(a->drop_p > 0.f) || a->drop_seed, "ph_layernorm_bwd: dropout needs a seed");
   int grid = min(ceil_div(a->M, 4), 512);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, stream, *a);
+  ph_layernorm_bwd_args b = *a;
+  const bool need_params = a->dgamma || a->dbeta;
+  if (!need_params || (int64_t)grid * 2 * a->D * 4 > a->partial_ws_bytes) b.partial_ws = nullptr;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, stream, b);
+  if (need_params && b.partial_ws)
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ceil_div(2 * a->D, 256)), dim3(256), 0, stream, b.partial_ws, grid, a->D, a->dgamma, a->dbeta);
   PH_LAUNCH_CHECK("ln_bwd_kernel");
   return PH_OK;
 }

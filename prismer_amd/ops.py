@@ -104,6 +104,8 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, dy_map=IDENT, dy2=None, dy2_map=I
         dx_drop = None
         a.dx_drop, a.drop_p, a.drop_seed, a.drop_stream = None, 0.0, None, 0
     a.dgamma, a.dbeta, a.M, a.D = ptr(dgamma), ptr(dbeta), M, D
+    ws = _workspace(x.device)
+    a.partial_ws, a.partial_ws_bytes = ws.data_ptr(), WS_BYTES
     check(lib.ph_layernorm_bwd(C.byref(a), _stream()), 'ph_layernorm_bwd')
     return dx, (dx_drop if dx_drop is not None else dx)
 
