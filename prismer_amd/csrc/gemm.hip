@@ -24,6 +24,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <math.h>
 #include <utility>
 
 #include "common.h"
@@ -303,21 +304,38 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     });
   }
 
-  // ---- epilogue: lane holds, for tile (i,j): m = l&31 ; n = 8*(r>>2) + 4*(l>>5) + (r&3) -------------------
+  // ---- epilogue --------------------------------------------------------------------------------------------------
+  // MFMA leaves lane l with C[m = l&31][n = 8g + 4(l>>5) + e]: 32 different rows per store instruction.  Going straight
+  // to HBM from that layout costs one cache-line touch per 16 B; instead the fp32 tile is parked in LDS (re-using the
+  // stage buffers, 16-B chunks XOR-swizzled by the row so both sides are conflict-free) and re-read row-wise: 32
+  // consecutive lanes then own 256 contiguous bytes of one output row for every load/store of the fused epilogue.
   const bool splitk = gridDim.z > 1;
   DropCtx dc;
   const bool drop = p.drop_p > 0.0f;
   if (drop) dc = make_drop(p.drop_seed, p.drop_stream, p.drop_p);
+  constexpr int CH = BN / 4;                       // 16-B chunks per tile row
+  float* cl = reinterpret_cast<float*>(smem);
+  // (the main loop ended with a barrier: nobody reads the stage buffers any more)
   // acc[][] must only ever be indexed with compile-time constants (a runtime index demotes the accumulators to
   // scratch memory and the main loop then spills them every k-tile), so the tile loop is a static_for.
   static_for(std::make_integer_sequence<int, TM * TN * 4>{}, [&](auto idx) {
     constexpr int i = decltype(idx)::value / (TN * 4), j = (decltype(idx)::value / 4) % TN, g = decltype(idx)::value % 4;
-    const int m = m0 + wm * WM + i * 32 + (lane & 31);
-    const int n = n0 + wn * WN + j * 32 + g * 8 + (lane >> 5) * 4;
-    float v[4] = {acc[i][j][g * 4 + 0] * p.alpha, acc[i][j][g * 4 + 1] * p.alpha, acc[i][j][g * 4 + 2] * p.alpha,
-                  acc[i][j][g * 4 + 3] * p.alpha};
-    if (m < p.M && n < p.N) epilogue_store(p, m, n, v, splitk, drop, dc);
+    const int ml = wm * WM + i * 32 + (lane & 31);
+    const int c = (wn * WN + j * 32 + g * 8 + (lane >> 5) * 4) >> 2;
+    f32x4 v = {acc[i][j][g * 4 + 0] * p.alpha, acc[i][j][g * 4 + 1] * p.alpha, acc[i][j][g * 4 + 2] * p.alpha,
+               acc[i][j][g * 4 + 3] * p.alpha};
+    *reinterpret_cast<f32x4*>(cl + ml * BN + ((c ^ (ml & (CH - 1))) << 2)) = v;
   });
+  __syncthreads();
+#pragma unroll 4
+  for (int it = 0; it < BM * CH / 256; ++it) {
+    const int id = it * 256 + threadIdx.x;
+    const int ml = id / CH, c = id % CH;
+    const int m = m0 + ml, n = n0 + c * 4;
+    f32x4 t = *reinterpret_cast<const f32x4*>(cl + ml * BN + ((c ^ (ml & (CH - 1))) << 2));
+    float v[4] = {t[0], t[1], t[2], t[3]};
+    if (m < p.M && n < p.N) epilogue_store(p, m, n, v, splitk, drop, dc);
+  }
 }
 
 // folds the split-K partials and applies the fused epilogue (bias / activation / dropout / residual / accumulate / dtype)
@@ -337,7 +355,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
 }
 
 // prefetch depth per tile size (VGPR budget: 128x128 tiles hold 32 staging VGPRs per slot, 64x64 tiles 16)
-#define PF_DEPTH(bm) ((bm) == 128 ? 3 : 4)
+#define PF_DEPTH(bm) ((bm) == 128 ? 1 : 2)
 
 template <int BM, int BN, bool TA, bool TB>
 int launch(const GemmParams& p, int splits, hipStream_t s) {
@@ -395,23 +413,25 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
                          a->out_f32 && a->accumulate;
   auto ws_fits = [&](int sp) { return a->workspace && (int64_t)sp * a->M * ldws * 4 <= a->workspace_bytes; };
   const int64_t t128 = (int64_t)ceil_div(a->M, 128) * ceil_div(a->N, 128), t64 = (int64_t)ceil_div(a->M, 64) * ceil_div(a->N, 64);
+  // pick (tile, split) by a small cost model calibrated on the MI355X microbenchmarks (profiles/r1_*): a k-tile
+  // iteration costs ~1.5 us for co-resident 128x128 blocks (2 per CU) and ~0.5 us for 64x64 blocks (4 per CU);
+  // a split adds the reduce launch (~4 us) plus splits*M*N*4 bytes of partial traffic.
   int BM = 128, splits = 1;
-  if (a->M <= 64 || a->N <= 64) BM = 64;
   if (a->split_k > 0) {
     splits = a->split_k;
-    if (BM == 128 && t128 * splits < 128) BM = 64;
+    if (a->M <= 64 || a->N <= 64 || t128 * splits < 128) BM = 64;
   } else {
-    int64_t tiles = BM == 128 ? t128 : t64;
-    if (tiles < 200) {
-      int want = (int)min((int64_t)max(kt / 2, 1), (int64_t)ceil_div(512, (int)tiles));
-      while (want > 1 && !ws_fits(want) && !plain_acc) --want;
-      if (want > 1 && (ws_fits(want) || plain_acc)) splits = want;
-      if (BM == 128 && tiles * splits < 160) {   // K too short to split that far: smaller tiles instead
-        BM = 64;
-        tiles = t64;
-        want = (int)min((int64_t)max(kt / 2, 1), (int64_t)ceil_div(512, (int)tiles));
-        while (want > 1 && !ws_fits(want) && !plain_acc) --want;
-        splits = (want > 1 && (ws_fits(want) || plain_acc)) ? want : 1;
+    double best = 1e30;
+    const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48};
+    for (int bm = 64; bm <= 128; bm += 64) {
+      if (bm == 128 && (a->M <= 64 || a->N <= 64)) continue;
+      const double tiles = (double)(bm == 128 ? t128 : t64), cap = bm == 128 ? 512.0 : 1024.0, t_iter = bm == 128 ? 1.5 : 0.5;
+      for (int sp : cand) {
+        if (sp > 1 && (sp > kt / 2 || !(ws_fits(sp) || plain_acc))) continue;
+        double waves = ceil(tiles * sp / cap);
+        double cost = waves * (ceil((double)kt / sp) * t_iter + 3.0);
+        if (sp > 1) cost += 4.0 + (double)sp * a->M * ldws * 4.0 / 3.0e6;
+        if (cost < best) { best = cost; BM = bm; splits = sp; }
       }
     }
   }

@@ -168,15 +168,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(ph_layernorm_bwd_args a) {
   }
 }
 
-// dgamma[c] += sum_b partial[b][0][c], dbeta[c] += sum_b partial[b][1][c]
+// dgamma[c] += sum_b partial[b][0][c], dbeta[c] += sum_b partial[b][1][c]; blockIdx.y strides over the partial rows
 __global__ void ln_param_reduce_kernel(const float* __restrict__ ws, int nblk, int D, float* dgamma, float* dbeta) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= 2 * D) return;
   int which = c / D, col = c % D;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += ws[((size_t)b * 2 + which) * D + col];
+  for (int b = blockIdx.y; b < nblk; b += gridDim.y) s += ws[((size_t)b * 2 + which) * D + col];
   float* dst = which ? dbeta : dgamma;
-  if (dst) dst[col] += s;
+  if (dst) atomicAdd(dst + col, s);
 }
 
 }  // namespace
@@ -201,7 +201,7 @@ extern "C" int ph_layernorm_bwd(const ph_layernorm_bwd_args* a, hipStream_t stre
   if (!need_params || (int64_t)grid * 2 * a->D * 4 > a->partial_ws_bytes) b.partial_ws = nullptr;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, stream, b);
   if (need_params && b.partial_ws)
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ceil_div(2 * a->D, 256)), dim3(256), 0, stream, b.partial_ws, grid, a->D, a->dgamma, a->dbeta);
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ceil_div(2 * a->D, 256), min(grid, 32)), dim3(256), 0, stream, b.partial_ws, grid, a->D, a->dgamma, a->dbeta);
   PH_LAUNCH_CHECK("ln_bwd_kernel");
   return PH_OK;
 }
