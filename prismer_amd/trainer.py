@@ -24,6 +24,7 @@ import random
 import torch
 
 from . import ops
+from .dist import bucketed_all_reduce
 
 F32, BF16 = torch.float32, torch.bfloat16
 
@@ -90,8 +91,7 @@ class Trainer:
         ev.record(torch.cuda.current_stream())
         self.comm_stream.wait_event(ev)
         with torch.cuda.stream(self.comm_stream):
-            for o in range(0, n, self.bucket_elems):
-                torch.distributed.all_reduce(flat[o:min(n, o + self.bucket_elems)], group=self.pg)
+            bucketed_all_reduce(flat, n, self.bucket_elems, self.pg)
 
     def _wait_comm(self):
         if self.world > 1:
