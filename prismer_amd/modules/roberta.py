@@ -128,6 +128,8 @@ class _DecoderFn(torch.autograd.Function):
         st = mod._store
         st._grad_cur = ctx.gradbuf
         denc = mod._program().backward(ctx.sv, dloss)
+        from .. import ops as _ops
+        _ops.join_side()
         ctx.sv = None
         return (None, None, None, denc, None, None) + tuple(st.grads_for_autograd(mod._train_names))
 

@@ -67,6 +67,8 @@ class _EncoderFn(torch.autograd.Function):
         st = mod._store
         st._grad_cur = ctx.gradbuf
         mod._program().backward(ctx.sv, dout.contiguous())
+        from .. import ops as _ops
+        _ops.join_side()
         ctx.sv = None
         return (None, None, None) + tuple(st.grads_for_autograd(mod._train_names))
 

@@ -31,12 +31,60 @@ WS_BYTES = 256 << 20
 
 
 def _workspace(device):
-    """per-device fp32 scratch for split-K partial tiles (allocated once; reused by every GEMM on the stream)"""
-    ws = _WS.get(device)
+    """per-(device, stream) fp32 scratch for split-K partial tiles / LayerNorm partials: kernels on one stream are
+    serialised, so one buffer per stream is race-free (allocated once, reused by every launch on that stream)"""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
     if ws is None:
         ws = torch.empty(WS_BYTES // 4, dtype=F32, device=device)
-        _WS[device] = ws
+        _WS[key] = ws
     return ws
+
+
+class SideStream:
+    """Second HIP stream for work that is OFF the critical path of the backward pass (weight-gradient GEMMs, bias column
+    sums): the dgrad chain keeps the main stream, the side stream fills the CUs its short / narrow launches leave idle.
+    Under hipGraph capture the fork/join events become graph edges, i.e. parallel branches.  Tensors touched on the side
+    stream are kept referenced until join() so the caching allocator cannot recycle them under the side stream's feet."""
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.keep = []
+        self.dirty = False
+
+    def run(self, fn, *tensors):
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.stream.wait_event(ev)
+        with torch.cuda.stream(self.stream):
+            out = fn()
+        self.keep.append(tensors)
+        if out is not None:
+            self.keep.append(out)
+        self.dirty = True
+        return out
+
+    def join(self):
+        if self.dirty:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.dirty = False
+        self.keep.clear()
+
+
+SIDE = None          # set by the Trainer (native path); None = everything on the current stream
+
+
+def off_critical_path(fn, *tensors):
+    """run fn() on the side stream when one is active, else inline."""
+    if SIDE is None:
+        return fn()
+    return SIDE.run(fn, *tensors)
+
+
+def join_side():
+    if SIDE is not None:
+        SIDE.join()
 
 
 def gemm(a, b, out=None, *, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, pre_out=None, act_in=None,

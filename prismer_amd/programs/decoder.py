@@ -211,11 +211,14 @@ class DecoderProgram:
         dlogits = ops.ce_bwd(sv['logits'], sv['labels'], B, T, V, d.label_smoothing, sv['row_lse'], dloss.contiguous())
         wname = e + 'word_embeddings.weight'
         gw = P.g(wname)
-        if gw is not None:
-            ops.gemm(dlogits, sv['t1'], out=gw, trans_a=True, trans_b=True, out_f32=True, accumulate=True, M=V, N=d.hidden_size, K=B * T)
         gb = P.g('lm_head.bias')
-        if gb is not None:
-            ops.colsum(dlogits, gb, N=V)
+
+        def head_wgrad():
+            if gw is not None:
+                ops.gemm(dlogits, sv['t1'], out=gw, trans_a=True, trans_b=True, out_f32=True, accumulate=True, M=V, N=d.hidden_size, K=B * T)
+            if gb is not None:
+                ops.colsum(dlogits, gb, N=V)
+        ops.off_critical_path(head_wgrad, dlogits, sv['t1'])
         dt1 = ops.gemm(dlogits, P.w(wname), trans_b=True, K=V)            # [B*T, H]
         dt0, _ = self.head_ln.bwd(dt1, sv['t0'], sv['hm'], sv['hr'])
         dt0pre = ops.act_bwd(dt0, sv['t0pre'], ACT_GELU)
@@ -231,6 +234,7 @@ class DecoderProgram:
             dh = self.adaptor_bwd(L['ad'], blocks.pop(), dh)
             dh = self.cross_attn_bwd(L['ca'], blocks.pop(), dh, sv['enc'], denc, B, T, S)
             dh = self.self_attn_bwd(L['sa'], blocks.pop(), dh, B, T, sv['key_mask'])
+        ops.join_side()      # the tied word-embedding gradient: LM-head wgrad (side stream) must land before the scatter-adds
         ops.embed_bwd(dh, sv['ids'], P.f(wname), P.f(e + 'position_embeddings.weight'), P.f(e + 'token_type_embeddings.weight'),
                       P.f(e + 'LayerNorm.weight'), P.f(e + 'LayerNorm.bias'), d.layer_norm_eps, d.pad_token_id, sv['xhat'], sv['erstd'],
                       sv['dr_e'], P.g(wname), P.g(e + 'position_embeddings.weight'), P.g(e + 'token_type_embeddings.weight'),

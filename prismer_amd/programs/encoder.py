@@ -49,13 +49,18 @@ class Linear:
         return ops.gemm(dy, self.w, trans_b=True, N=self.cols, K=self.rows, **kw)
 
     def wgrad(self, dy, x):
+        """weight / bias gradients: off the critical path (side stream when the Trainer provides one)"""
         gw = self.P.g2(self.wname, self.rows, self.cols)
-        if gw is not None:
-            ops.gemm(dy, x, out=gw, trans_a=True, trans_b=True, out_f32=True, accumulate=True, M=self.rows, N=self.cols, K=dy.shape[0])
-        if self.bname:
-            gb = self.P.gvec(self.bname, self.rows)
+        gb = self.P.gvec(self.bname, self.rows) if self.bname else None
+        if gw is None and gb is None:
+            return
+
+        def work():
+            if gw is not None:
+                ops.gemm(dy, x, out=gw, trans_a=True, trans_b=True, out_f32=True, accumulate=True, M=self.rows, N=self.cols, K=dy.shape[0])
             if gb is not None:
                 ops.colsum(dy, gb, N=self.rows)
+        ops.off_critical_path(work, dy, x)
 
 
 class LN:
@@ -113,11 +118,14 @@ class EncoderProgram:
             return
         Co, Ci = self.P.shape[name][0], self.P.shape[name][1]
         Kp = col.shape[1]
-        if ks == 1 and Kp == Ci:
-            ops.gemm(dy, col, out=g.view(Co, Ci), trans_a=True, trans_b=True, out_f32=True, accumulate=True, M=Co, N=Kp, K=dy.shape[0])
-            return
-        ds = ops.gemm(dy, col, trans_a=True, trans_b=True, out_f32=True, M=Co, N=Kp, K=dy.shape[0])
-        ops.conv_grad_from_shadow(ds, g, Co, Ci, ks, Kp)
+        def work():
+            if ks == 1 and Kp == Ci:
+                ops.gemm(dy, col, out=g.view(Co, Ci), trans_a=True, trans_b=True, out_f32=True, accumulate=True, M=Co, N=Kp, K=dy.shape[0])
+                return None
+            ds = ops.gemm(dy, col, trans_a=True, trans_b=True, out_f32=True, M=Co, N=Kp, K=dy.shape[0])
+            ops.conv_grad_from_shadow(ds, g, Co, Ci, ks, Kp)
+            return ds
+        ops.off_critical_path(work, dy, col)
 
     # ---------------------------------------------------------------------------------------- positional embedding
     def expert_pos(self):
@@ -255,11 +263,14 @@ class EncoderProgram:
             wq, wkv = P.w2(blk['inw'], W, W), P.w2(blk['inw'], 3 * W, W)[W:]
             gw = P.g2(blk['inw'], 3 * W, W)
             if gw is not None:
-                ops.gemm(dq, s['qin'], out=gw[:W], trans_a=True, trans_b=True, out_f32=True, accumulate=True, M=W, N=W, K=B * L)
-                ops.gemm(dkv, s['kvin'], out=gw[W:], trans_a=True, trans_b=True, out_f32=True, accumulate=True, M=2 * W, N=W, K=B * KV)
                 gb = P.gvec(blk['inb'], 3 * W)
-                ops.colsum(dq, gb[:W])
-                ops.colsum(dkv, gb[W:])
+
+                def work(dq=dq, dkv=dkv, s=s, gw=gw, gb=gb):
+                    ops.gemm(dq, s['qin'], out=gw[:W], trans_a=True, trans_b=True, out_f32=True, accumulate=True, M=W, N=W, K=B * L)
+                    ops.gemm(dkv, s['kvin'], out=gw[W:], trans_a=True, trans_b=True, out_f32=True, accumulate=True, M=2 * W, N=W, K=B * KV)
+                    ops.colsum(dq, gb[:W])
+                    ops.colsum(dkv, gb[W:])
+                ops.off_critical_path(work, dq, dkv, s['qin'], s['kvin'])
             dqin = ops.gemm(dq, wq, trans_b=True)
             dkvin = ops.gemm(dkv, wkv, trans_b=True)
             dlat, _ = blk['ln_1'].bwd(dqin, s['lat'], s['m1'], s['r1'], dy2=dkvin, dy2_map=RowMap(L, KV, 0), dskip=dlat1)

@@ -36,7 +36,7 @@ def cosine_lr(it, total, init_lr, min_lr):
 
 class Trainer:
     def __init__(self, model, lr=5e-5, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8, min_lr=0.0, total_steps=1000,
-                 task='caption', use_graph=True, process_group=None, bucket_mb=64):
+                 task='caption', use_graph=True, process_group=None, bucket_mb=64, side_stream=True):
         self.model = model
         self.enc, self.dec = model.expert_encoder, model.text_decoder
         self.init_lr, self.min_lr, self.total_steps = lr, min_lr, total_steps
@@ -68,6 +68,8 @@ class Trainer:
         self.table = torch.zeros(256, dtype=torch.int32, device=dev)
         self.seed = self.dec.dropout_seed()
         self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
+        if side_stream:
+            ops.SIDE = ops.SideStream(dev)
         self.loss = None
         if self.world > 1:
             self.broadcast_parameters()
@@ -111,10 +113,12 @@ class Trainer:
             dloss = torch.full((B,), 1.0 / B, dtype=F32, device=loss.device)
             self.loss_buf = loss.sum() / B
         self.denc = self.dec_prog.backward(self.sv_d, dloss)
+        ops.join_side()
         self.sv_d = None
 
     def _seg_enc_backward(self):
         self.enc_prog.backward(self.sv_e, self.denc)
+        ops.join_side()
         self.sv_e = None
 
     def _seg_optimizer(self):
