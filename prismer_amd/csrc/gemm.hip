@@ -282,26 +282,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     }
   };
 
-  static_for(std::make_integer_sequence<int, D>{}, [&](auto sidx) {
-    constexpr int sl = decltype(sidx)::value;
-    if (kt_begin + sl < kt_end) gload(kt_begin + sl, ra[sl], rb[sl]);
-  });
+  // Schedule (per k-tile t, one barrier):   [LDS(cur) = tile t, registers = tile t+1 landed or landing]
+  //     write registers -> LDS(cur^1)      (tile t+1; its loads were issued a whole iteration ago)
+  //     re-issue the SAME registers <- global tile t+2      (in flight across the barrier)
+  //     MFMAs on LDS(cur)
+  //     barrier
+  // i.e. two tiles of look-ahead with one register set and two LDS buffers; the LDS write pass sits BEFORE this wave's
+  // MFMAs, where it overlaps the co-resident block's matrix work instead of trailing its own.
+  static_assert(D == 1, "ring depth > 1 is not used by this schedule");
+  gload(kt_begin, ra[0], rb[0]);
   lstore(0, ra[0], rb[0]);
+  if (kt_begin + 1 < kt_end) gload(kt_begin + 1, ra[0], rb[0]);
   __syncthreads();
   int cur = 0;
-  for (int t0 = kt_begin; t0 < kt_end; t0 += D) {
-    static_for(std::make_integer_sequence<int, D>{}, [&](auto sidx) {
-      constexpr int sl = decltype(sidx)::value;
-      constexpr int nx = (sl + 1) % D;
-      const int kt = t0 + sl;
-      if (kt < kt_end) {                                    // block-uniform
-        if (kt + D < kt_end) gload(kt + D, ra[sl], rb[sl]);  // slot sl was drained into LDS one iteration ago
-        compute(cur);
-        if (kt + 1 < kt_end) lstore(cur ^ 1, ra[nx], rb[nx]);
-        __syncthreads();
-        cur ^= 1;
-      }
-    });
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    if (kt + 1 < kt_end) lstore(cur ^ 1, ra[0], rb[0]);
+    if (kt + 2 < kt_end) gload(kt + 2, ra[0], rb[0]);
+    compute(cur);
+    __syncthreads();
+    cur ^= 1;
   }
 
   // ---- epilogue --------------------------------------------------------------------------------------------------
@@ -355,7 +354,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
 }
 
 // prefetch depth per tile size (VGPR budget: 128x128 tiles hold 32 staging VGPRs per slot, 64x64 tiles 16)
-#define PF_DEPTH(bm) ((bm) == 128 ? 1 : 2)
+#define PF_DEPTH(bm) 1
 
 template <int BM, int BN, bool TA, bool TB>
 int launch(const GemmParams& p, int splits, hipStream_t s) {
@@ -425,12 +424,14 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
     const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48};
     for (int bm = 64; bm <= 128; bm += 64) {
       if (bm == 128 && (a->M <= 64 || a->N <= 64)) continue;
-      const double tiles = (double)(bm == 128 ? t128 : t64), cap = bm == 128 ? 512.0 : 1024.0, t_iter = bm == 128 ? 1.5 : 0.5;
+      // tools/gemm_probe.py on MI355X: 8320x768 NT, K 768 -> 3072: 1.07 us per k-tile for one wave of co-resident
+      // 128x128 blocks (2 per CU), 0.83 us per k-tile and wave of 64x64 blocks (4 per CU); ~4 us fixed per block wave.
+      const double tiles = (double)(bm == 128 ? t128 : t64), cap = bm == 128 ? 512.0 : 1024.0, t_iter = bm == 128 ? 1.07 : 0.83;
       for (int sp : cand) {
         if (sp > 1 && (sp > kt / 2 || !(ws_fits(sp) || plain_acc))) continue;
         double waves = ceil(tiles * sp / cap);
-        double cost = waves * (ceil((double)kt / sp) * t_iter + 3.0);
-        if (sp > 1) cost += 4.0 + (double)sp * a->M * ldws * 4.0 / 3.0e6;
+        double cost = waves * (ceil((double)kt / sp) * t_iter + 4.0);
+        if (sp > 1) cost += 3.0 + (double)sp * a->M * ldws * 4.0 / 3.0e6;
         if (cost < best) { best = cost; BM = bm; splits = sp; }
       }
     }
