@@ -55,12 +55,13 @@ typedef struct {
   int act;                        /* PH_ACT_* */
   void* pre_out;                  /* optional bf16 [M,N] (ld = ldc): value before the activation */
   const void* act_in; int ld_act; /* optional bf16: C = acc * act'(act_in)   (backward through `act`) */
-  const void* residual; int ldr;  /* optional bf16 [M,N] added last */
+  const void* residual; int ldr;  /* optional [M,N] added last: bf16, or fp32 when residual_f32 */
   float drop_p; const uint64_t* drop_seed; uint32_t drop_stream;   /* inverted dropout on the activation */
   int out_f32;                    /* C is fp32 instead of bf16 */
   int accumulate;                 /* C += result */
   float alpha;
   int split_k;                    /* 0 = auto */
+  int residual_f32;
   void* workspace; int64_t workspace_bytes;   /* optional fp32 scratch for split-K partials (deterministic reduce + full
                                      epilogue); without it only plain fp32-accumulate GEMMs are split (atomics) */
 } ph_gemm_args;
@@ -82,6 +83,8 @@ typedef struct {
   void* y2; ph_rowmap y2_map;     /* optional second copy of the output */
   float* mean; float* rstd;       /* fp32 [M], optional */
   int M, D; float eps;
+  int x_f32;                      /* x is fp32 instead of bf16 (decoder residual stream) */
+  void* y_f32;                    /* optional fp32 copy of the output [M,D] (identity row map) */
 } ph_layernorm_fwd_args;
 int ph_layernorm_fwd(const ph_layernorm_fwd_args* args, hipStream_t stream);
 
@@ -95,6 +98,7 @@ typedef struct {
   float drop_p; const uint64_t* drop_seed; uint32_t drop_stream;
   float* dgamma; float* dbeta;    /* fp32 [D], ACCUMULATED; NULL when the affine is frozen */
   int M, D;
+  int x_f32;                      /* x is fp32 */
   float* partial_ws; int64_t partial_ws_bytes;   /* optional scratch (>= 512*2*D*4 B): per-block partials + reduce instead of atomics */
 } ph_layernorm_bwd_args;
 int ph_layernorm_bwd(const ph_layernorm_bwd_args* args, hipStream_t stream);
@@ -183,6 +187,7 @@ typedef struct {
   void* xhat;                     /* bf16 [B*T, H] normalised pre-affine value, saved for backward */
   float* rstd;                    /* fp32 [B*T] */
   float drop_p; const uint64_t* drop_seed; uint32_t drop_stream;
+  void* out_f32;                  /* optional fp32 copy of `out` */
 } ph_embed_fwd_args;
 int ph_embed_fwd(const ph_embed_fwd_args* args, hipStream_t stream);
 typedef struct {

@@ -36,13 +36,14 @@ class GemmArgs(C.Structure):
                 ('residual', c_void_p), ('ldr', c_int),
                 ('drop_p', c_float), ('drop_seed', c_void_p), ('drop_stream', c_u32),
                 ('out_f32', c_int), ('accumulate', c_int), ('alpha', c_float), ('split_k', c_int),
-                ('workspace', c_void_p), ('workspace_bytes', c_i64)]
+                ('residual_f32', c_int), ('workspace', c_void_p), ('workspace_bytes', c_i64)]
 
 
 class LayerNormFwdArgs(C.Structure):
     _fields_ = [('x', c_void_p), ('gamma', c_void_p), ('beta', c_void_p),
                 ('y', c_void_p), ('y_map', RowMap), ('y2', c_void_p), ('y2_map', RowMap),
-                ('mean', c_void_p), ('rstd', c_void_p), ('M', c_int), ('D', c_int), ('eps', c_float)]
+                ('mean', c_void_p), ('rstd', c_void_p), ('M', c_int), ('D', c_int), ('eps', c_float),
+                ('x_f32', c_int), ('y_f32', c_void_p)]
 
 
 class LayerNormBwdArgs(C.Structure):
@@ -51,7 +52,7 @@ class LayerNormBwdArgs(C.Structure):
                 ('dskip', c_void_p), ('dx', c_void_p), ('dx_drop', c_void_p),
                 ('drop_p', c_float), ('drop_seed', c_void_p), ('drop_stream', c_u32),
                 ('dgamma', c_void_p), ('dbeta', c_void_p), ('M', c_int), ('D', c_int),
-                ('partial_ws', c_void_p), ('partial_ws_bytes', c_i64)]
+                ('x_f32', c_int), ('partial_ws', c_void_p), ('partial_ws_bytes', c_i64)]
 
 
 class AttnFwdArgs(C.Structure):
@@ -76,7 +77,7 @@ class EmbedFwdArgs(C.Structure):
                 ('word', c_void_p), ('pos', c_void_p), ('type', c_void_p),
                 ('gamma', c_void_p), ('beta', c_void_p), ('eps', c_float),
                 ('out', c_void_p), ('xhat', c_void_p), ('rstd', c_void_p),
-                ('drop_p', c_float), ('drop_seed', c_void_p), ('drop_stream', c_u32)]
+                ('drop_p', c_float), ('drop_seed', c_void_p), ('drop_stream', c_u32), ('out_f32', c_void_p)]
 
 
 class EmbedBwdArgs(C.Structure):

@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(ph_embed_fwd_args a) {
       }
       bf16x4 to = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
       *reinterpret_cast<bf16x4*>(out + c * 4) = to;
+      if (a.out_f32) { f32x4 tf = {o[0], o[1], o[2], o[3]}; *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out_f32) + (int64_t)row * a.H + c * 4) = tf; }
     }
   }
 }

@@ -53,7 +53,7 @@ struct GemmParams {
   const float* bias;
   bf16* pre_out;
   const bf16* act_in; int ld_act;
-  const bf16* residual; int ldr;
+  const bf16* residual; int ldr; int res_f32;
   float drop_p; const uint64_t* drop_seed; uint32_t drop_stream;
   int act, out_f32, accumulate;
   float alpha;
@@ -183,7 +183,11 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = drop_apply(dc, r[e], v[e]);
   }
-  if (p.residual) {
+  if (p.residual && p.res_f32) {    // fp32 residual stream (decoder: LayerNorm outputs stay fp32 like under autocast)
+    const float* q = reinterpret_cast<const float*>(p.residual) + (size_t)m * p.ldr + n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += q[min(e, p.N - 1 - n)];
+  } else if (p.residual) {
     const bf16* q = p.residual + (size_t)m * p.ldr + n;
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] += bf2f(q[min(e, p.N - 1 - n)]);
@@ -399,7 +403,7 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
   p.A = (const bf16*)a->A; p.B = (const bf16*)a->B; p.C = a->C;
   p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc;
   p.bias = a->bias; p.pre_out = (bf16*)a->pre_out; p.act_in = (const bf16*)a->act_in; p.ld_act = a->ld_act;
-  p.residual = (const bf16*)a->residual; p.ldr = a->ldr;
+  p.residual = (const bf16*)a->residual; p.ldr = a->ldr; p.res_f32 = a->residual_f32;
   p.drop_p = a->drop_p; p.drop_seed = a->drop_seed; p.drop_stream = a->drop_stream;
   p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.alpha = a->alpha;
 

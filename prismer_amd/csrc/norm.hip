@@ -19,15 +19,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(ph_layernorm_fwd_args a) {
   if (row >= a.M) return;
   const int nch = a.D >> 2;
   const bf16* x = reinterpret_cast<const bf16*>(a.x) + (size_t)row * a.D;
+  const float* xf = reinterpret_cast<const float*>(a.x) + (size_t)row * a.D;
   float v[MAX_CH][4];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAX_CH; ++i) {
     int c = lane + 64 * i;
     if (c < nch) {
-      bf16x4 t = *reinterpret_cast<const bf16x4*>(x + c * 4);
+      if (a.x_f32) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(xf + c * 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v[i][e] = bf2f(t[e]); s += v[i][e]; }
+        for (int e = 0; e < 4; ++e) { v[i][e] = t[e]; s += v[i][e]; }
+      } else {
+        bf16x4 t = *reinterpret_cast<const bf16x4*>(x + c * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[i][e] = bf2f(t[e]); s += v[i][e]; }
+      }
     }
   }
   float mean = wave_sum(s) / (float)a.D;
@@ -54,9 +61,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(ph_layernorm_fwd_args a) {
       f32x4 g = *reinterpret_cast<const f32x4*>(a.gamma + c * 4);
       f32x4 b = *reinterpret_cast<const f32x4*>(a.beta + c * 4);
       bf16x4 o;
+      f32x4 of;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = f2bf((v[i][e] - mean) * rstd * g[e] + b[e]);
+      for (int e = 0; e < 4; ++e) { of[e] = (v[i][e] - mean) * rstd * g[e] + b[e]; o[e] = f2bf(of[e]); }
       *reinterpret_cast<bf16x4*>(y + c * 4) = o;
+      if (a.y_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.y_f32) + (size_t)row * a.D + c * 4) = of;
       if (y2) *reinterpret_cast<bf16x4*>(y2 + c * 4) = o;
     }
   }
@@ -79,6 +88,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(ph_layernorm_bwd_args a) {
 
   for (int row = blockIdx.x * 4 + wave; row < a.M; row += gridDim.x * 4) {
     const bf16* x = reinterpret_cast<const bf16*>(a.x) + (size_t)row * a.D;
+    const float* xf = reinterpret_cast<const float*>(a.x) + (size_t)row * a.D;
     const bf16* dy = reinterpret_cast<const bf16*>(a.dy) + (size_t)map_row(a.dy_map, row) * a.D;
     const bf16* dy2 = a.dy2 ? reinterpret_cast<const bf16*>(a.dy2) + (size_t)map_row(a.dy2_map, row) * a.D : nullptr;
     float mean = a.mean[row], rstd = a.rstd[row];
@@ -88,7 +98,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(ph_layernorm_bwd_args a) {
     for (int i = 0; i < MAX_CH; ++i) {
       int c = lane + 64 * i;
       if (c < nch) {
-        bf16x4 tx = *reinterpret_cast<const bf16x4*>(x + c * 4);
+        float xv[4];
+        if (a.x_f32) { f32x4 t = *reinterpret_cast<const f32x4*>(xf + c * 4); xv[0] = t[0]; xv[1] = t[1]; xv[2] = t[2]; xv[3] = t[3]; }
+        else { bf16x4 t = *reinterpret_cast<const bf16x4*>(x + c * 4); xv[0] = bf2f(t[0]); xv[1] = bf2f(t[1]); xv[2] = bf2f(t[2]); xv[3] = bf2f(t[3]); }
         bf16x4 td = *reinterpret_cast<const bf16x4*>(dy + c * 4);
         f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + c * 4);
         bf16x4 td2;
@@ -97,7 +109,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(ph_layernorm_bwd_args a) {
         for (int e = 0; e < 4; ++e) {
           float d = bf2f(td[e]);
           if (dy2) d += bf2f(td2[e]);
-          xh[i][e] = (bf2f(tx[e]) - mean) * rstd;
+          xh[i][e] = (xv[e] - mean) * rstd;
           dg[i][e] += d * xh[i][e];
           db[i][e] += d;
           g[i][e] = d * gm[e];

@@ -109,6 +109,7 @@ def gemm(a, b, out=None, *, trans_a=False, trans_b=False, bias=None, act=ACT_NON
     g.act_in = ptr(act_in)
     g.ld_act = act_in.stride(0) if act_in is not None else 0
     g.residual = ptr(residual)
+    g.residual_f32 = int(residual is not None and residual.dtype == F32)
     g.ldr = residual.stride(0) if residual is not None else 0
     if drop is not None and drop.p > 0.0:
         g.drop_p, g.drop_seed, g.drop_stream = drop.p, drop.seed.data_ptr(), drop.stream
@@ -121,16 +122,17 @@ def gemm(a, b, out=None, *, trans_a=False, trans_b=False, bias=None, act=ACT_NON
     return out
 
 
-def layernorm_fwd(x, gamma, beta, eps=1e-5, out=None, out_map=IDENT, out2=None, out2_map=IDENT, save_stats=True):
+def layernorm_fwd(x, gamma, beta, eps=1e-5, out=None, out_map=IDENT, out2=None, out2_map=IDENT, save_stats=True, out_f32=None):
+    """x: bf16 or fp32 [M, D]; out: bf16; out_f32: optional fp32 [M, D] copy of the output (fp32 residual stream)."""
     M, D = x.shape
     if out is None:
-        out = torch.empty_like(x)
+        out = torch.empty((M, D), dtype=BF16, device=x.device)
     mean = rstd = None
     if save_stats:
         stats = torch.empty((2, M), dtype=F32, device=x.device)
         mean, rstd = stats[0], stats[1]
     a = _lib.LayerNormFwdArgs(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), out_map, ptr(out2), out2_map,
-                              ptr(mean), ptr(rstd), M, D, eps)
+                              ptr(mean), ptr(rstd), M, D, eps, int(x.dtype == F32), ptr(out_f32))
     check(lib.ph_layernorm_fwd(C.byref(a), _stream()), 'ph_layernorm_fwd')
     return out, mean, rstd
 
@@ -139,14 +141,15 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, dy_map=IDENT, dy2=None, dy2_map=I
                   drop=None, dx=None, dx_drop=None):
     M, D = x.shape
     if dx is None:
-        dx = torch.empty_like(x)
+        dx = torch.empty((M, D), dtype=BF16, device=x.device)
     a = _lib.LayerNormBwdArgs()
+    a.x_f32 = int(x.dtype == F32)
     a.dy, a.dy_map, a.dy2, a.dy2_map = dy.data_ptr(), dy_map, ptr(dy2), dy2_map
     a.x, a.mean, a.rstd, a.gamma = x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr()
     a.dskip, a.dx = ptr(dskip), dx.data_ptr()
     if drop is not None and drop.p > 0.0:
         if dx_drop is None:
-            dx_drop = torch.empty_like(x)
+            dx_drop = torch.empty((M, D), dtype=BF16, device=x.device)
         a.dx_drop, a.drop_p, a.drop_seed, a.drop_stream = dx_drop.data_ptr(), drop.p, drop.seed.data_ptr(), drop.stream
     else:
         dx_drop = None
@@ -281,7 +284,7 @@ def scatter_taps(dout, din, idx, w, n_out, taps, D):
 
 # ---------------------------------------------------------------------------------------------- decoder ends
 
-def embed_args(ids, word, pos, typ, gamma, beta, eps, pad_id, out, xhat, rstd, drop):
+def embed_args(ids, word, pos, typ, gamma, beta, eps, pad_id, out, xhat, rstd, drop, out_f32=None):
     B, T = ids.shape
     a = _lib.EmbedFwdArgs()
     a.ids, a.B, a.T, a.H, a.pad_id = ids.data_ptr(), B, T, word.shape[1], pad_id
@@ -292,17 +295,21 @@ def embed_args(ids, word, pos, typ, gamma, beta, eps, pad_id, out, xhat, rstd, d
         a.drop_p, a.drop_seed, a.drop_stream = drop.p, drop.seed.data_ptr(), drop.stream
     else:
         a.drop_p, a.drop_seed, a.drop_stream = 0.0, None, 0
+    a.out_f32 = ptr(out_f32)
     return a
 
 
-def embed_fwd(ids, word, pos, typ, gamma, beta, eps, pad_id, drop=None):
+def embed_fwd(ids, word, pos, typ, gamma, beta, eps, pad_id, drop=None, want_f32=False):
     B, T = ids.shape
     H = word.shape[1]
     out = torch.empty((B * T, H), dtype=BF16, device=ids.device)
     xhat = torch.empty((B * T, H), dtype=BF16, device=ids.device)
     rstd = torch.empty((B * T,), dtype=F32, device=ids.device)
-    a = embed_args(ids, word, pos, typ, gamma, beta, eps, pad_id, out, xhat, rstd, drop)
+    out_f32 = torch.empty((B * T, H), dtype=F32, device=ids.device) if want_f32 else None
+    a = embed_args(ids, word, pos, typ, gamma, beta, eps, pad_id, out, xhat, rstd, drop, out_f32)
     check(lib.ph_embed_fwd(C.byref(a), _stream()), 'ph_embed_fwd')
+    if want_f32:
+        return out, xhat, rstd, out_f32
     return out, xhat, rstd
 
 

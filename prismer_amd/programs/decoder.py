@@ -6,7 +6,8 @@ RobertaEmbeddings (:66-76) -> 12 x [self-attn, cross-attn, Adaptor(norm_late), M
 Differences in FORM (not in arithmetic): the three q/k/v nn.Linear of a self-attention run as one packed GEMM
 (their parameters are adjacent in the flat store), cross-attention k/v likewise; every
 `LayerNorm(dropout(dense(x)) + residual)` is a GEMM with a fused bias+dropout+residual epilogue followed by the
-LayerNorm kernel; logits live in a [B*T, Vpad] bf16 buffer (Vpad = vocab rounded up to 64) and the backward
+LayerNorm kernel; the post-LN residual stream (LayerNorm outputs and the pre-norm sums) is kept in fp32 next to the bf16
+copies the GEMMs read -- what autocast does on the reference (its fp32 LayerNorm returns fp32 to an fp32 residual); logits live in a [B*T, Vpad] bf16 buffer (Vpad = vocab rounded up to 64) and the backward
 overwrites it with dlogits.
 """
 import torch
@@ -59,7 +60,13 @@ class DecoderProgram:
         return ops.Dropout(p, seed, site) if (seed is not None and p > 0.0) else None
 
     # ---------------------------------------------------------------------------------------- sub-blocks
-    def self_attn_fwd(self, blk, li, h, B, T, key_mask, seed, sv):
+    def post_ln(self, ln, s):
+        """LayerNorm of the fp32 pre-norm sum -> (bf16 copy for the next GEMMs, fp32 copy = residual stream)"""
+        yf = torch.empty_like(s)
+        y, m, r = ln.fwd(s, out_f32=yf)
+        return y, yf, m, r
+
+    def self_attn_fwd(self, blk, li, h, hf, B, T, key_mask, seed, sv):
         d = self.d
         H, nh = d.hidden_size, d.num_attention_heads
         dh = H // nh
@@ -69,11 +76,11 @@ class DecoderProgram:
         o, lse = ops.attention_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, nh, T, T, dh, q_strides=st, k_strides=st, v_strides=st,
                                    key_mask=key_mask, causal=True, drop=dr_a)
         dr_h = self.drop(li * 16 + 2, d.hidden_dropout_prob, seed)
-        s = blk['out'].fwd(o, drop=dr_h, residual=h)
-        y, m, r = blk['ln'].fwd(s)
+        s = blk['out'].fwd(o, drop=dr_h, residual=hf, out_f32=True)
+        y, yf, m, r = self.post_ln(blk['ln'], s)
         if sv is not None:
             sv.append(dict(h=h, qkv=qkv, o=o, lse=lse, s=s, m=m, r=r, dr_a=dr_a, dr_h=dr_h))
-        return y
+        return y, yf
 
     def self_attn_bwd(self, blk, s, dy, B, T, key_mask):
         d = self.d
@@ -91,7 +98,7 @@ class DecoderProgram:
         blk['qkv'].wgrad(dqkv, s['h'])
         return blk['qkv'].dgrad(dqkv, residual=ds)
 
-    def cross_attn_fwd(self, blk, li, h, enc, B, T, S, seed, sv):
+    def cross_attn_fwd(self, blk, li, h, hf, enc, B, T, S, seed, sv):
         d = self.d
         H, nh = d.hidden_size, d.num_attention_heads
         dh = H // nh
@@ -101,11 +108,11 @@ class DecoderProgram:
         dr_a = self.drop(li * 16 + 3, d.attention_probs_dropout_prob, seed)
         o, lse = ops.attention_fwd(q, kv[:, :H], kv[:, H:], B, nh, T, S, dh, q_strides=(T * H, H), k_strides=ks, v_strides=ks, drop=dr_a)
         dr_h = self.drop(li * 16 + 4, d.hidden_dropout_prob, seed)
-        s = blk['out'].fwd(o, drop=dr_h, residual=h)
-        y, m, r = blk['ln'].fwd(s)
+        s = blk['out'].fwd(o, drop=dr_h, residual=hf, out_f32=True)
+        y, yf, m, r = self.post_ln(blk['ln'], s)
         if sv is not None:
             sv.append(dict(h=h, q=q, kv=kv, o=o, lse=lse, s=s, m=m, r=r, dr_a=dr_a, dr_h=dr_h))
-        return y
+        return y, yf
 
     def cross_attn_bwd(self, blk, s, dy, enc, denc, B, T, S):
         d = self.d
@@ -125,14 +132,14 @@ class DecoderProgram:
         blk['kv'].dgrad(dkv, out=denc, out_f32=True, accumulate=True)     # 12 layers accumulate in fp32
         return blk['q'].dgrad(dq, residual=ds)
 
-    def adaptor_fwd(self, blk, h, sv):
+    def adaptor_fwd(self, blk, h, hf, sv):
         dpre = torch.empty_like(h)
         dact = blk['down'].fwd(h, act=ACT_RELU2, pre_out=dpre)
-        s = blk['up'].fwd(dact, residual=h)
-        y, m, r = blk['ln'].fwd(s)                                       # norm_late (utils.py:61-62)
+        s = blk['up'].fwd(dact, residual=hf, out_f32=True)
+        y, yf, m, r = self.post_ln(blk['ln'], s)                          # norm_late (utils.py:61-62)
         if sv is not None:
             sv.append(dict(h=h, dpre=dpre, dact=dact, s=s, m=m, r=r))
-        return y
+        return y, yf
 
     def adaptor_bwd(self, blk, s, dy):
         ds, _ = blk['ln'].bwd(dy, s['s'], s['m'], s['r'])
@@ -141,16 +148,16 @@ class DecoderProgram:
         blk['down'].wgrad(ddpre, s['h'])
         return blk['down'].dgrad(ddpre, residual=ds)
 
-    def mlp_fwd(self, blk, li, h, seed, sv):
+    def mlp_fwd(self, blk, li, h, hf, seed, sv):
         d = self.d
         ipre = torch.empty(h.shape[0], d.intermediate_size, dtype=BF16, device=h.device)
         iact = blk['inter'].fwd(h, act=ACT_GELU, pre_out=ipre)
         dr_h = self.drop(li * 16 + 5, d.hidden_dropout_prob, seed)
-        s = blk['out'].fwd(iact, drop=dr_h, residual=h)
-        y, m, r = blk['ln'].fwd(s)
+        s = blk['out'].fwd(iact, drop=dr_h, residual=hf, out_f32=True)
+        y, yf, m, r = self.post_ln(blk['ln'], s)
         if sv is not None:
             sv.append(dict(h=h, ipre=ipre, iact=iact, s=s, m=m, r=r, dr_h=dr_h))
-        return y
+        return y, yf
 
     def mlp_bwd(self, blk, s, dy):
         ds, dsd = blk['ln'].bwd(dy, s['s'], s['m'], s['r'], drop=s['dr_h'])
@@ -175,17 +182,17 @@ class DecoderProgram:
         enc2 = enc.reshape(B * S, enc.shape[2])
         sv = [] if save else None
         dr_e = self.drop(9000, d.hidden_dropout_prob, seed)
-        h, xhat, erstd = ops.embed_fwd(input_ids, P.f(e + 'word_embeddings.weight'), P.f(e + 'position_embeddings.weight'),
+        h, xhat, erstd, hf = ops.embed_fwd(input_ids, P.f(e + 'word_embeddings.weight'), P.f(e + 'position_embeddings.weight'),
                                        P.f(e + 'token_type_embeddings.weight'), P.f(e + 'LayerNorm.weight'), P.f(e + 'LayerNorm.bias'),
-                                       d.layer_norm_eps, d.pad_token_id, dr_e)
+                                       d.layer_norm_eps, d.pad_token_id, dr_e, want_f32=True)
         for L in self.layers:
-            h = self.self_attn_fwd(L['sa'], L['idx'], h, B, T, key_mask, seed, sv)
-            h = self.cross_attn_fwd(L['ca'], L['idx'], h, enc2, B, T, S, seed, sv)
-            h = self.adaptor_fwd(L['ad'], h, sv)
-            h = self.mlp_fwd(L['mlp'], L['idx'], h, seed, sv)
+            h, hf = self.self_attn_fwd(L['sa'], L['idx'], h, hf, B, T, key_mask, seed, sv)
+            h, hf = self.cross_attn_fwd(L['ca'], L['idx'], h, hf, enc2, B, T, S, seed, sv)
+            h, hf = self.adaptor_fwd(L['ad'], h, hf, sv)
+            h, hf = self.mlp_fwd(L['mlp'], L['idx'], h, hf, seed, sv)
         F_ = self.final
-        h = self.self_attn_fwd(F_['sa'], F_['idx'], h, B, T, key_mask, seed, sv)
-        h = self.mlp_fwd(F_['mlp'], F_['idx'], h, seed, sv)
+        h, hf = self.self_attn_fwd(F_['sa'], F_['idx'], h, hf, B, T, key_mask, seed, sv)
+        h, hf = self.mlp_fwd(F_['mlp'], F_['idx'], h, hf, seed, sv)
         t0pre = torch.empty_like(h)
         t0 = self.head_dense.fwd(h, act=ACT_GELU, pre_out=t0pre)
         t1, hm, hr = self.head_ln.fwd(t0)
