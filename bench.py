@@ -86,7 +86,9 @@ def build_trainer(batch, use_graph, rank, T=30):
 def kernel_family_pass(tr, steps):
     """instrumented eager pass: per-family HIP-event timing through the library's measurement hooks."""
     from prismer_amd._lib import lib
+    from prismer_amd import ops
     tr.use_graph = False
+    ops.join_side(); ops.SIDE = None           # single stream: per-launch durations without cross-stream contention
     tr.step(); torch.cuda.synchronize()
     lib.ph_prof_enable(1)
     for _ in range(steps):

@@ -435,7 +435,7 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
         if (sp > 1 && (sp > kt / 2 || !(ws_fits(sp) || plain_acc))) continue;
         double waves = ceil(tiles * sp / cap);
         double cost = waves * (ceil((double)kt / sp) * t_iter + 4.0);
-        if (sp > 1) cost += 3.0 + (double)sp * a->M * ldws * 4.0 / 3.0e6;
+        if (sp > 1) cost += 8.0 + (double)sp * a->M * ldws * 4.0 / 3.0e6;   // reduce launch: ~7 us measured (rocprof) + partial traffic
         if (cost < best) { best = cost; BM = bm; splits = sp; }
       }
     }
