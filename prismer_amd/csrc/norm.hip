@@ -13,6 +13,7 @@ __device__ __forceinline__ int map_row(const ph_rowmap& m, int r) {
   return m.seg_in ? (r / m.seg_in) * m.seg_out + m.seg_off + (r % m.seg_in) : r;
 }
 
+template <int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(ph_layernorm_fwd_args a) {
   int lane = threadIdx.x & 63;
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -20,10 +21,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(ph_layernorm_fwd_args a) {
   const int nch = a.D >> 2;
   const bf16* x = reinterpret_cast<const bf16*>(a.x) + (size_t)row * a.D;
   const float* xf = reinterpret_cast<const float*>(a.x) + (size_t)row * a.D;
-  float v[MAX_CH][4];
+  float v[NCH][4];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAX_CH; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     int c = lane + 64 * i;
     if (c < nch) {
       if (a.x_f32) {
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(ph_layernorm_fwd_args a) {
   float mean = wave_sum(s) / (float)a.D;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAX_CH; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     int c = lane + 64 * i;
     if (c < nch) {
 #pragma unroll
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(ph_layernorm_fwd_args a) {
   bf16* y = reinterpret_cast<bf16*>(a.y) + (size_t)map_row(a.y_map, row) * a.D;
   bf16* y2 = a.y2 ? reinterpret_cast<bf16*>(a.y2) + (size_t)map_row(a.y2_map, row) * a.D : nullptr;
 #pragma unroll
-  for (int i = 0; i < MAX_CH; ++i) {
+  for (int i = 0; i < NCH; ++i) {
     int c = lane + 64 * i;
     if (c < nch) {
       f32x4 g = *reinterpret_cast<const f32x4*>(a.gamma + c * 4);
@@ -73,13 +74,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(ph_layernorm_fwd_args a) {
 
 // Backward.  Each wave walks rows (grid-stride) keeping its dgamma / dbeta partials in registers; the block
 // folds its 4 waves through LDS and issues one fp32 atomic per column.
+template <int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(ph_layernorm_bwd_args a) {
   __shared__ float red_flat[2 * 4 * 512];   // [dgamma|dbeta][wave][512 columns]: 16 KB, D is folded in passes of 512
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = a.D >> 2;
-  float dg[MAX_CH][4], db[MAX_CH][4];
+  float dg[NCH][4], db[NCH][4];
 #pragma unroll
-  for (int i = 0; i < MAX_CH; ++i)
+  for (int i = 0; i < NCH; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
   DropCtx dc;
@@ -92,10 +94,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(ph_layernorm_bwd_args a) {
     const bf16* dy = reinterpret_cast<const bf16*>(a.dy) + (size_t)map_row(a.dy_map, row) * a.D;
     const bf16* dy2 = a.dy2 ? reinterpret_cast<const bf16*>(a.dy2) + (size_t)map_row(a.dy2_map, row) * a.D : nullptr;
     float mean = a.mean[row], rstd = a.rstd[row];
-    float xh[MAX_CH][4], g[MAX_CH][4];
+    float xh[NCH][4], g[NCH][4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAX_CH; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       int c = lane + 64 * i;
       if (c < nch) {
         float xv[4];
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(ph_layernorm_bwd_args a) {
     const bf16* dsk = a.dskip ? reinterpret_cast<const bf16*>(a.dskip) + (size_t)row * a.D : nullptr;
     bf16* dxd = drop ? reinterpret_cast<bf16*>(a.dx_drop) + (size_t)row * a.D : nullptr;
 #pragma unroll
-    for (int i = 0; i < MAX_CH; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       int c = lane + 64 * i;
       if (c < nch) {
         float o[4];
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(ph_layernorm_bwd_args a) {
   for (int pass = 0; pass < (a.D + 511) / 512; ++pass) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < MAX_CH; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       int c = lane + 64 * i;
       int cl = c - pass * 128;
       if (c < nch && cl >= 0 && cl < 128) {
@@ -197,7 +199,14 @@ extern "C" int ph_layernorm_fwd(const ph_layernorm_fwd_args* a, hipStream_t stre
   PH_CHECK_ARG(a && a->x && a->y && a->gamma && a->beta, "ph_layernorm_fwd: null pointer");
   ProfScope prof__(PH_FAM_LAYERNORM, 0.0, 4.0 * a->M * (double)a->D, stream);
   PH_CHECK_ARG(a->M > 0 && a->D > 0 && (a->D % 4) == 0 && a->D <= MAX_CH * 256, "ph_layernorm_fwd: D=%d unsupported (need D%%4==0, D<=%d)", a->D, MAX_CH * 256);
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(a->M, 4)), dim3(256), 0, stream, *a);
+  // chunks of 4 elements per lane: the row lives in NCH*4 registers per lane (templated so D=768 does not pay for 2048)
+  const int nch = ceil_div(a->D, 256);
+  dim3 grid(ceil_div(a->M, 4));
+  if (nch <= 1) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, dim3(256), 0, stream, *a);
+  else if (nch <= 2) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, dim3(256), 0, stream, *a);
+  else if (nch <= 3) hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, dim3(256), 0, stream, *a);
+  else if (nch <= 4) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, dim3(256), 0, stream, *a);
+  else hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, dim3(256), 0, stream, *a);
   PH_LAUNCH_CHECK("ln_fwd_kernel");
   return PH_OK;
 }
@@ -211,7 +220,12 @@ extern "C" int ph_layernorm_bwd(const ph_layernorm_bwd_args* a, hipStream_t stre
   ph_layernorm_bwd_args b = *a;
   const bool need_params = a->dgamma || a->dbeta;
   if (!need_params || (int64_t)grid * 2 * a->D * 4 > a->partial_ws_bytes) b.partial_ws = nullptr;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, stream, b);
+  const int nch = ceil_div(a->D, 256);
+  if (nch <= 1) hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(grid), dim3(256), 0, stream, b);
+  else if (nch <= 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(grid), dim3(256), 0, stream, b);
+  else if (nch <= 3) hipLaunchKernelGGL(ln_bwd_kernel<3>, dim3(grid), dim3(256), 0, stream, b);
+  else if (nch <= 4) hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(grid), dim3(256), 0, stream, b);
+  else hipLaunchKernelGGL(ln_bwd_kernel<8>, dim3(grid), dim3(256), 0, stream, b);
   if (need_params && b.partial_ws)
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ceil_div(2 * a->D, 256), min(grid, 32)), dim3(256), 0, stream, b.partial_ws, grid, a->D, a->dgamma, a->dbeta);
   PH_LAUNCH_CHECK("ln_bwd_kernel");
