@@ -68,17 +68,28 @@ def make_inputs(dims, batch, T, seed, device):
     return x, ids, mask, labels
 
 
-def build_trainer(batch, use_graph, rank, T=30):
+def build_trainer(batch, use_graph, rank, T=30, workload='base_caption'):
     from prismer_amd import config as pcfg
     from prismer_amd.model.prismer_caption import PrismerCaption
+    from prismer_amd.model.prismer_vqa import PrismerVQA
     from prismer_amd.trainer import Trainer
-    dims = pcfg.prismer_base()
-    cfg = {'experts': pcfg.CAPTION_EXPERTS, 'image_resolution': 224, 'prismer_model': 'prismer_base', 'freeze': 'freeze_vision'}
     torch.manual_seed(0)                                   # identical random-init weights on every rank
-    model = PrismerCaption(cfg).cuda()
+    if workload == 'large_vqa':                            # BASELINE config 5: Prismer-LARGE VQA, 480^2, T = 35 + 5
+        dims = pcfg.prismer_large()
+        cfg = {'experts': pcfg.CAPTION_EXPERTS, 'image_resolution': 480, 'prismer_model': 'prismer_large', 'freeze': 'freeze_vision'}
+        model = PrismerVQA(cfg).cuda()
+        T = 40
+    else:
+        dims = pcfg.prismer_base()
+        cfg = {'experts': pcfg.CAPTION_EXPERTS, 'image_resolution': 224, 'prismer_model': 'prismer_base', 'freeze': 'freeze_vision'}
+        model = PrismerCaption(cfg).cuda()
     tr = Trainer(model, lr=5e-5, weight_decay=0.05, total_steps=10000, task='caption', use_graph=use_graph)
     x, ids, mask, labels = make_inputs(dims, batch, T, 1234 + rank, torch.device('cuda'))
-    tr.set_batch(x, ids, mask, labels)
+    weights = None
+    if workload == 'large_vqa':
+        labels[:, :35] = -100                              # only the answer span is scored (prismer_vqa.py:32-33)
+        weights = torch.rand(batch, device='cuda') * 0.8 + 0.2
+    tr.set_batch(x, ids, mask, labels, weights)
     n_train = sum(st.n_train for st in tr.stores)
     return tr, dims, n_train
 
@@ -152,6 +163,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--workload', default='base_caption', choices=['base_caption', 'large_vqa'],
+                    help='base_caption = the headline metric (BASELINE config 3/4); large_vqa = config 5 (secondary; use --batch 16)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -168,7 +181,8 @@ def main():
         torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
-    tr, dims, n_train = build_trainer(args.batch, not args.no_graph, rank)
+    tr, dims, n_train = build_trainer(args.batch, not args.no_graph, rank, workload=args.workload)
+    gf_img = TRAIN_GF_PER_IMG if args.workload == 'base_caption' else 2987.8
 
     def barrier():
         if world > 1:
@@ -192,18 +206,21 @@ def main():
     final_loss = float(loss.item())
 
     out = {
-        'metric': 'images/sec Prismer-BASE caption train, 224^2 + 6 experts, bs32/GPU',
+        'metric': 'images/sec Prismer-BASE caption train, 224^2 + 6 experts, bs32/GPU' if args.workload == 'base_caption' else
+                  'images/sec Prismer-LARGE VQAv2 fine-tune, 480^2 + 6 experts, bs16/GPU',
         'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
         'data': 'synthetic',
         'config': {'workload': 'Prismer-BASE caption fine-tune step (fwd+bwd+allreduce+AdamW), 224^2, 6 experts + Resampler, T=30, '
                                'freeze_vision, dropout 0.1, train-mode BatchNorm',
-                   'model': 'prismer_base', 'global_batch': world * args.batch, 'seq_len': dims.seq_len, 'text_len': 30,
+                   'model': 'prismer_base' if args.workload == 'base_caption' else 'prismer_large (VQA, 480^2, T=40)', 'global_batch': world * args.batch, 'seq_len': dims.seq_len, 'text_len': 30,
                    'parallelism': f'dp{world}', 'trainable_params': n_train, 'hip_graph': not args.no_graph,
                    'final_loss': round(final_loss, 4)},
-        'step_tflops': round(value / world * TRAIN_GF_PER_IMG / 1e3, 2),
-        'step_mfma_frac': round(value / world * TRAIN_GF_PER_IMG / 1e3 / PEAK_TFLOPS, 4),
+        'step_tflops': round(value / world * gf_img / 1e3, 2),
+        'step_mfma_frac': round(value / world * gf_img / 1e3 / PEAK_TFLOPS, 4),
     }
+    if rank == 0 and world == 1 and args.workload != 'base_caption':
+        args.no_cpu_baseline = True                        # the CPU leg is defined on the headline workload only
     if rank == 0 and world == 1:
         if not args.no_roofline:
             fam = kernel_family_pass(tr, min(args.steps, 5))

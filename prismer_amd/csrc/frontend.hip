@@ -351,7 +351,7 @@ inline int grid_for(int64_t work_items) { return (int)std::min<int64_t>(ceil_div
 }  // namespace
 
 extern "C" int ph_patchify(const float* img, void* col, int B, int C, int R, int p, int Kp, hipStream_t stream) {
-  PH_CHECK_ARG(img && col && B > 0 && R % p == 0 && Kp >= C * p * p && Kp % 8 == 0, "ph_patchify: bad args");
+  PH_CHECK_ARG(img && col && B > 0 && R >= p && Kp >= C * p * p && Kp % 8 == 0, "ph_patchify: bad args");   // g = floor(R/p) like Conv2d(stride=p)
   ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream, "ph_patchify");
   int g = R / p;
   hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((int64_t)B * g * g * (Kp / 2))), dim3(256), 0, stream, img, (bf16*)col, B, C, R, p, Kp);

@@ -262,3 +262,76 @@ def test_dropout_training_forward_is_reproducible_and_unbiased():
     assert abs(losses[0] - losses[1]) < 1e-5 * losses[0]      # same masks; fp32 atomics make the last bits order-dependent
     assert len(set(losses[1:])) == 5
     assert abs(np.mean(losses[1:]) - ref) / ref < 0.1
+
+
+def test_large_vqa_geometry_matches_oracle():
+    """BASELINE config 5 geometry (Prismer-LARGE VQA): width 1024 / 16 heads, patch 14 at 480^2 (34x34 rgb tokens), expert maps
+    224 -> 256 -> 16x16 tokens (bicubic positional re-grid 34^2 -> 16^2), resampler head dim 128, T = 40 -- with 2 ViT and 2
+    decoder layers so the CPU oracle finishes in seconds.  HIP forward + VQA loss + probe gradients vs the oracle."""
+    d = config.prismer_large()
+    d.vit_layers = 2; d.num_hidden_layers = 2
+    enc = VisionTransformer(d.image_resolution, d.patch_size, d.width, d.vit_layers, d.vit_heads, dict(d.experts))
+    dec = RobertaForCausalLMModified(_Cfg(d.roberta_config_dict()))
+    esd, dsd = synth.synth_encoder_state(d, 5), synth.synth_decoder_state(d, 5)
+    enc.load_state_dict(esd); dec.load_state_dict(dsd)
+    enc.cuda().eval(); dec.cuda().eval()
+    B, T = 1, 40
+    x = synth.synth_experts(d, B, seed=9)
+    ids, mask, labels = synth.synth_text(d, B, T, seed=9, ragged=False, prompt_length=1)
+    labels[:, :35] = -100                                     # prismer_vqa.py:32-33: only the answer span is scored
+    weights = torch.tensor([0.7])
+    tab = [random.Random(11).randint(0, 127) for _ in range(256)]
+    enc.instance_table = torch.tensor(tab, dtype=torch.int32).cuda()
+    for p in list(enc.parameters()) + list(dec.parameters()):
+        p.requires_grad = False
+    probe = ['positional_embedding', 'resampler.latents', 'conv1.depth.13.weight']
+    for n in probe:
+        dict(enc.named_parameters())[n].requires_grad = True
+    e = enc(to_dev(x))
+    assert e.shape == (34 * 34 + 64, B, 1024)
+    out = dec(ids.cuda(), attention_mask=mask.cuda(), encoder_hidden_states=e.permute(1, 0, 2), labels=labels.cuda(), return_dict=True)
+    logits_hip = out.logits.float().cpu()
+    (weights.cuda() * out.loss).mean().backward()
+    for n in probe:
+        esd[n].requires_grad_(True)
+    eo = O.vision_encoder(esd, x, d.patch_size, d.vit_heads, False, tab)
+    lg, ls = O.text_decoder(dsd, ids, mask, eo.transpose(0, 1), d.num_attention_heads, labels)
+    (weights * ls).mean().backward()
+    assert rel_fro(e.float(), eo) < TOL_ACT
+    assert rel_fro(logits_hip, lg) < TOL_ACT
+    assert rel_fro(out.loss, ls) < TOL_LOSS
+    for n in probe:
+        assert rel_fro(dict(enc.named_parameters())[n].grad, esd[n].grad) < 2 * TOL_GRAD, n
+
+
+def test_heads_generate_rank_and_vqa_run():
+    """next-row smoke: caption generate (beam 3) / rank and the VQA training loss run end-to-end on the HIP
+    forward with pre-tokenised ids (no vocabulary on disk), on the tiny geometry."""
+    from prismer_amd.model.prismer_caption import PrismerCaption
+    from prismer_amd.model.prismer_vqa import PrismerVQA
+    case = C.Case('tiny_vqa')
+    d = case.dims
+    x, ids, mask, labels, weights = case.inputs()
+
+    def make(cls):
+        m = cls.__new__(cls)
+        torch.nn.Module.__init__(m)
+        m.tokenizer = None
+        m.expert_encoder, m.text_decoder, _, _ = build(case)
+        m.expert_encoder.eval(); m.text_decoder.eval()
+        return m
+    cap = make(PrismerCaption)
+    xs = to_dev(x)
+    B = ids.shape[0]
+    prefix = (torch.tensor([[0, 83, 2170, 9, 2]] * B), torch.ones(B, 5, dtype=torch.long))          # "<s> A picture of </s>"
+    outs = cap(xs, train=False, prefix=prefix, inference='generate')
+    assert len(outs) == B and all(4 <= len(o) <= 20 for o in outs)
+    answers = (torch.randint(3, d.vocab_size, (6, 3)), torch.ones(6, 3, dtype=torch.long))
+    best = cap(xs, answer=answers, train=False, prefix=prefix, inference='rank', k_test=4)
+    assert best.shape == (B,) and int(best.max()) < 6
+    vqa = make(PrismerVQA)
+    vqa.expert_encoder.train()
+    q = (ids[:, :8], mask[:, :8]); a = (ids[:, 8:], mask[:, 8:])
+    loss = vqa(xs, q, a, weights=weights.cuda(), train=True)
+    loss.backward()
+    assert torch.isfinite(loss) and vqa.text_decoder.lm_head.dense.weight.grad is not None
