@@ -217,6 +217,67 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
   }
 }
 
+// 8 consecutive outputs C[m][n..n+7] with 16-B vector loads/stores (interior tiles, 16-B aligned leading dimensions)
+__device__ __forceinline__ void epilogue_store8(const GemmParams& p, int m, int n, float (&v)[8], bool drop, const DropCtx& dc) {
+  if (p.bias) {
+    f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+  }
+  if (p.pre_out) {
+    bf16x8 t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = f2bf(v[e]);
+    *reinterpret_cast<bf16x8*>(p.pre_out + (size_t)m * p.ldc + n) = t;
+  }
+  if (p.act_in) {
+    bf16x8 t = *reinterpret_cast<const bf16x8*>(p.act_in + (size_t)m * p.ld_act + n);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= act_grad(p.act, bf2f(t[e]));
+  } else if (p.act != PH_ACT_NONE) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = act_fwd(p.act, v[e]);
+  }
+  if (drop) {
+    uint64_t i4 = ((uint64_t)m * (uint64_t)p.N + (uint64_t)n) >> 2;
+    u32x4 r0 = drop_rand4(dc, i4), r1 = drop_rand4(dc, i4 + 1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = drop_apply(dc, r0[e], v[e]); v[4 + e] = drop_apply(dc, r1[e], v[4 + e]); }
+  }
+  if (p.residual && p.res_f32) {
+    const float* q = reinterpret_cast<const float*>(p.residual) + (size_t)m * p.ldr + n;
+    f32x4 r0 = *reinterpret_cast<const f32x4*>(q), r1 = *reinterpret_cast<const f32x4*>(q + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+  } else if (p.residual) {
+    bf16x8 t = *reinterpret_cast<const bf16x8*>(p.residual + (size_t)m * p.ldr + n);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += bf2f(t[e]);
+  }
+  if (p.out_f32) {
+    float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+    if (p.accumulate) {
+      f32x4 c0 = *reinterpret_cast<const f32x4*>(c), c1 = *reinterpret_cast<const f32x4*>(c + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] += c0[e]; v[4 + e] += c1[e]; }
+    }
+    f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+    *reinterpret_cast<f32x4*>(c) = o0;
+    *reinterpret_cast<f32x4*>(c + 4) = o1;
+  } else {
+    bf16* c = reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n;
+    if (p.accumulate) {
+      bf16x8 t = *reinterpret_cast<const bf16x8*>(c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bf2f(t[e]);
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+    *reinterpret_cast<bf16x8*>(c) = o;
+  }
+}
+
 template <int BM, int BN, bool TA, bool TB, int PF>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   constexpr int WM = BM / 2, WN = BN / 2;   // wave tile
@@ -338,6 +399,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     *reinterpret_cast<f32x4*>(cl + ml * BN + ((c ^ (ml & (CH - 1))) << 2)) = v;
   });
   __syncthreads();
+  // fast path: 8 outputs per thread per step (16-B loads/stores) when every leading dimension / pointer allows it
+  const bool vec8 = !(splitk) && (p.ldc % 8) == 0 && (!p.act_in || (p.ld_act % 8) == 0) && (!p.residual || (p.ldr % 8) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.pre_out) | reinterpret_cast<uintptr_t>(p.act_in) |
+                      reinterpret_cast<uintptr_t>(p.residual) | reinterpret_cast<uintptr_t>(p.bias)) & 15) == 0;
+  if (vec8) {
+#pragma unroll 2
+    for (int it = 0; it < BM * CH / 512; ++it) {
+      const int id = it * 256 + threadIdx.x;
+      const int ml = id / (CH / 2), c = (id % (CH / 2)) * 2;
+      const int m = m0 + ml, n = n0 + c * 4;
+      const int sw = ml & (CH - 1);
+      f32x4 t0 = *reinterpret_cast<const f32x4*>(cl + ml * BN + ((c ^ sw) << 2));
+      f32x4 t1 = *reinterpret_cast<const f32x4*>(cl + ml * BN + (((c + 1) ^ sw) << 2));
+      if (m < p.M && n + 8 <= p.N) {
+        float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+        epilogue_store8(p, m, n, v, drop, dc);
+      } else if (m < p.M) {
+        float v0[4] = {t0[0], t0[1], t0[2], t0[3]}, v1[4] = {t1[0], t1[1], t1[2], t1[3]};
+        if (n < p.N) epilogue_store(p, m, n, v0, false, drop, dc);
+        if (n + 4 < p.N) epilogue_store(p, m, n + 4, v1, false, drop, dc);
+      }
+    }
+    return;
+  }
 #pragma unroll 4
   for (int it = 0; it < BM * CH / 256; ++it) {
     const int id = it * 256 + threadIdx.x;
