@@ -72,6 +72,40 @@ class SideStream:
         self.keep.clear()
 
 
+class BranchPool:
+    """N extra HIP streams for INDEPENDENT sub-graphs (the six expert stems): each branch forks from the current stream,
+    runs on its own stream (parallel branches of the hipGraph) and join() makes the current stream wait for all of them.
+    Tensors created inside a branch must stay referenced until join() (the callers keep them in their saved state)."""
+
+    def __init__(self, device, n):
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(n)]
+        self.used = set()
+
+    def branch(self, i):
+        s = self.streams[i % len(self.streams)]
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        s.wait_event(ev)
+        self.used.add(s)
+        return torch.cuda.stream(s)
+
+    def join(self):
+        cur = torch.cuda.current_stream()
+        for s in self.used:
+            cur.wait_stream(s)
+        self.used.clear()
+
+
+class _NoPool:
+    def branch(self, i):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def join(self):
+        pass
+
+
+POOL = _NoPool()     # set by the Trainer (native path)
 SIDE = None          # set by the Trainer (native path); None = everything on the current stream
 
 

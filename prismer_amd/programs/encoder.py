@@ -350,20 +350,25 @@ class EncoderProgram:
             assert Mx == d.num_expert_tokens, 'expert dict does not match the configured experts'
             xf = torch.empty(B * Mx, W, dtype=BF16, device=dev)
             pos_e = self.expert_pos()
-            for ei, name in enumerate(names):
-                dom = 'seg' if 'seg' in name else name
-                val = x[name]
-                inp = val['label'] if name == 'obj_detection' else val
-                f = self.stem_fwd(dom, inp.contiguous().float(), training, sv)
-                if f.shape[0] != B * G:
-                    raise RuntimeError(f'expert map {name}: stem produced {f.shape[0] // B} tokens per image, program expects {G} '
-                                       f'(expert_resolution={d.expert_resolution})')
-                if name == 'obj_detection':
-                    inst = val['instance'].contiguous()
-                    ops.tokens_finalize(f, pos_e, xf, B, G, W, Mx, ei * G, inst, inst.shape[-1], d.expert_grid, inst_table,
-                                        P.f('instance_embedding'))
-                else:
-                    ops.tokens_finalize(f, pos_e, xf, B, G, W, Mx, ei * G)
+            keep = []
+            for ei, name in enumerate(names):                  # the stems are independent: parallel graph branches
+                with ops.POOL.branch(ei):
+                    dom = 'seg' if 'seg' in name else name
+                    val = x[name]
+                    inp = val['label'] if name == 'obj_detection' else val
+                    f = self.stem_fwd(dom, inp.contiguous().float(), training, sv)
+                    if f.shape[0] != B * G:
+                        raise RuntimeError(f'expert map {name}: stem produced {f.shape[0] // B} tokens per image, program expects {G} '
+                                           f'(expert_resolution={d.expert_resolution})')
+                    if name == 'obj_detection':
+                        inst = val['instance'].contiguous()
+                        ops.tokens_finalize(f, pos_e, xf, B, G, W, Mx, ei * G, inst, inst.shape[-1], d.expert_grid, inst_table,
+                                            P.f('instance_embedding'))
+                    else:
+                        ops.tokens_finalize(f, pos_e, xf, B, G, W, Mx, ei * G)
+                    keep.append(f)
+            ops.POOL.join()
+            del keep
             self.resampler_fwd(xf, B, h, sv)
         h0, mp, rp = self.ln_pre.fwd(h)
         blocks_sv = [] if save else None
@@ -395,16 +400,21 @@ class EncoderProgram:
             dxf = self.resampler_bwd(dlat, B, sv)
             same = d.expert_grid == d.rgb_grid
             dpos_e = gpos if same else torch.zeros(G, W, dtype=F32, device=dh.device)
+            keep = []
             for ei, name in enumerate(names):
                 dom = 'seg' if 'seg' in name else name
                 dfeat = torch.empty(B * G, W, dtype=BF16, device=dh.device)
-                if name == 'obj_detection':
+                if name == 'obj_detection':                    # dpos_e is shared (atomics): token gradients stay on the main stream
                     inst = sv['inst']
                     ops.tokens_finalize_bwd(dxf, dfeat, dpos_e, B, G, W, Mx, ei * G, inst, inst.shape[-1], d.expert_grid, sv['inst_table'],
                                             P.g('instance_embedding'))
                 else:
                     ops.tokens_finalize_bwd(dxf, dfeat, dpos_e, B, G, W, Mx, ei * G)
-                self.stem_bwd(dom, dfeat, sv)
+                keep.append(dfeat)
+                with ops.POOL.branch(ei):                      # the six stem backward chains are independent
+                    self.stem_bwd(dom, dfeat, sv)
+            ops.POOL.join()
+            del keep
             if not same and gpos is not None:
                 self.expert_pos_bwd(dpos_e)
         drgb = torch.empty(B * N, W, dtype=BF16, device=dh.device)

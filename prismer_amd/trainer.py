@@ -70,6 +70,7 @@ class Trainer:
         self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
         if side_stream:
             ops.SIDE = ops.SideStream(dev)
+            ops.POOL = ops.BranchPool(dev, 3)
         self.loss = None
         if self.world > 1:
             self.broadcast_parameters()
