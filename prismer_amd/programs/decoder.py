@@ -98,12 +98,15 @@ class DecoderProgram:
         blk['qkv'].wgrad(dqkv, s['h'])
         return blk['qkv'].dgrad(dqkv, residual=ds)
 
-    def cross_attn_fwd(self, blk, li, h, hf, enc, B, T, S, seed, sv):
+    def cross_attn_fwd(self, blk, li, h, hf, enc, B, T, S, seed, sv, kv=None, kv_ready=None):
         d = self.d
         H, nh = d.hidden_size, d.num_attention_heads
         dh = H // nh
         q = blk['q'].fwd(h)
-        kv = blk['kv'].fwd(enc)
+        if kv is None:
+            kv = blk['kv'].fwd(enc)
+        elif kv_ready is not None:
+            torch.cuda.current_stream().wait_event(kv_ready)       # K/V projection of this layer ran on the branch stream
         ks = (S * 2 * H, 2 * H)
         dr_a = self.drop(li * 16 + 3, d.attention_probs_dropout_prob, seed)
         o, lse = ops.attention_fwd(q, kv[:, :H], kv[:, H:], B, nh, T, S, dh, q_strides=(T * H, H), k_strides=ks, v_strides=ks, drop=dr_a)
@@ -129,7 +132,9 @@ class DecoderProgram:
                           drop=s['dr_a'])
         blk['q'].wgrad(dq, s['h'])
         blk['kv'].wgrad(dkv, enc)
-        blk['kv'].dgrad(dkv, out=denc, out_f32=True, accumulate=True)     # 12 layers accumulate in fp32
+        # d(enc) is only needed after the last layer: its 12 accumulating GEMMs leave the critical path (fp32 accumulate,
+        # serialised on the side stream)
+        ops.off_critical_path(lambda: blk['kv'].dgrad(dkv, out=denc, out_f32=True, accumulate=True), dkv)
         return blk['q'].dgrad(dq, residual=ds)
 
     def adaptor_fwd(self, blk, h, hf, sv):
@@ -185,9 +190,19 @@ class DecoderProgram:
         h, xhat, erstd, hf = ops.embed_fwd(input_ids, P.f(e + 'word_embeddings.weight'), P.f(e + 'position_embeddings.weight'),
                                        P.f(e + 'token_type_embeddings.weight'), P.f(e + 'LayerNorm.weight'), P.f(e + 'LayerNorm.bias'),
                                        d.layer_norm_eps, d.pad_token_id, dr_e, want_f32=True)
-        for L in self.layers:
+        # the K/V projections of all cross-attention layers depend on `enc` only: issue them up front on a branch stream
+        # (12 x [B*S, 2H] GEMMs that overlap the latency-bound decoder chain); each layer waits on its own event.
+        kvs, kv_evs = [None] * len(self.layers), [None] * len(self.layers)
+        if isinstance(ops.POOL, ops.BranchPool):
+            with ops.POOL.branch(0):
+                for i, L in enumerate(self.layers):
+                    kvs[i] = L['ca']['kv'].fwd(enc2)
+                    kv_evs[i] = torch.cuda.Event()
+                    kv_evs[i].record(torch.cuda.current_stream())
+            ops.POOL.used.clear()        # joined through the per-layer events below (the last one covers the whole branch)
+        for i, L in enumerate(self.layers):
             h, hf = self.self_attn_fwd(L['sa'], L['idx'], h, hf, B, T, key_mask, seed, sv)
-            h, hf = self.cross_attn_fwd(L['ca'], L['idx'], h, hf, enc2, B, T, S, seed, sv)
+            h, hf = self.cross_attn_fwd(L['ca'], L['idx'], h, hf, enc2, B, T, S, seed, sv, kvs[i], kv_evs[i])
             h, hf = self.adaptor_fwd(L['ad'], h, hf, sv)
             h, hf = self.mlp_fwd(L['mlp'], L['idx'], h, hf, seed, sv)
         F_ = self.final
