@@ -23,6 +23,7 @@
 //   * block ids are remapped so that consecutive tiles along N share an XCD (and its L2 copy of the A panel).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <math.h>
 #include <utility>
@@ -455,7 +456,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
 
 template <int BM, int BN, bool TA, bool TB>
 int launch(const GemmParams& p, int splits, hipStream_t s) {
-  constexpr int smem = 2 * ((TA ? TileBytes<BM>::ks : TileBytes<BM>::kc) + (TB ? TileBytes<BN>::ks : TileBytes<BN>::kc));
+  constexpr int smem_min = 2 * ((TA ? TileBytes<BM>::ks : TileBytes<BM>::kc) + (TB ? TileBytes<BN>::ks : TileBytes<BN>::kc));
+  static int extra = -1;            // PH_GEMM_EXTRA_LDS=<bytes>: occupancy experiments only (pads the dynamic LDS request)
+  if (extra < 0) { const char* e = getenv("PH_GEMM_EXTRA_LDS"); extra = e ? atoi(e) : 0; }
+  const int smem = smem_min + extra;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, TA, TB, PF_DEPTH(BM)>),
