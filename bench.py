@@ -112,8 +112,18 @@ def kernel_family_pass(tr, steps):
     fam = {}
     for i, name in enumerate(FAMILIES):
         ms, fl, by, n = out[4 * i:4 * i + 4]
-        fam[name] = dict(ms_per_step=ms / steps, tflop_per_step=fl / steps / 1e12, launches_per_step=n / steps)
+        fam[name] = dict(ms_per_step=ms / steps, tflop_per_step=fl / steps / 1e12, launches_per_step=n / steps, gbytes_per_step=by / steps / 1e9)
     return fam
+
+
+def pmc_traffic():
+    """HBM bytes per GEMM launch from the committed PMC passes (profiles/r1_pmc_gemm.json: rocprofv3 --pmc FETCH_SIZE and
+    WRITE_SIZE in separate runs, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md); counters cannot be read from
+    inside the process, so this is null when the file is absent."""
+    p = os.path.join(ROOT, 'profiles', 'r1_pmc_gemm.json')
+    if not os.path.isfile(p):
+        return None
+    return round(json.load(open(p))['hbm_bytes_per_launch'])
 
 
 def cpu_baseline(seconds_budget=20.0):
@@ -228,7 +238,8 @@ def main():
             ach = g['tflop_per_step'] / (g['ms_per_step'] / 1e3) if g['ms_per_step'] > 0 else 0.0
             out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_kernel<*> (all bf16 MFMA GEMM launches of one step)',
                                'achieved': round(ach, 1), 'peak': PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_TFLOPS, 4),
-                               'traffic': None, 'avg_launch_us': round(g['ms_per_step'] * 1e3 / max(g['launches_per_step'], 1), 2),
+                               'traffic': pmc_traffic(), 'algorithmic_bytes_per_launch': round(g['gbytes_per_step'] * 1e9 / max(g['launches_per_step'], 1)),
+                               'avg_launch_us': round(g['ms_per_step'] * 1e3 / max(g['launches_per_step'], 1), 2),
                                'launches_per_step': g['launches_per_step'], 'gemm_tflop_per_step': round(g['tflop_per_step'], 3)}
             out['kernel_families_ms_per_step'] = {k: round(v['ms_per_step'], 3) for k, v in fam.items()}
         if not args.no_cpu_baseline:
