@@ -9,18 +9,17 @@
 // reference call sites: vit.py:41-47,53 (ViT), resampler.py:18-24, utils.py:50-56 (Adaptor),
 // roberta.py:86-92,134,163,177,415-421 (decoder), vit.py:86-120 (convs lowered to im2col GEMMs).
 //
-// Design (wave64, MFMA 32x32x16 bf16, fp32 accumulate):
-//   * block = 256 threads = 4 waves in a 2x2 grid; block tile BMxBN (128x128 or 64x64), BK = 64.
-//   * operands are staged global -> VGPR -> LDS, double-buffered: the loads of k-tile t+1 are issued before
-//     the MFMAs of tile t and written to the other LDS buffer after them (one barrier per k-tile).
-//   * K-contiguous operand: LDS image [rows][64] bf16 (128 B rows), 16-B chunk index XOR-swizzled with
-//     (row>>1)&7 so that the ds_read_b128 fragment reads of a 16-lane group hit 16 distinct 16-B slots.
-//   * K-strided operand (stored [K][rows]): LDS image [64][rows] with a 64-B row pad, fragments fetched with
-//     the gfx950 transposing LDS read ds_read_b64_tr_b16 (two per 8-element fragment).
-//   * the MFMA is issued as D = W_frag x X_frag so each lane ends with 4 CONSECUTIVE n for one m:
-//     epilogue stores are 8-B (bf16) / 16-B (fp32) vectors along n.
-//   * split-K (grid.z) with fp32 atomics for the tall-skinny weight-gradient GEMMs.
-//   * block ids are remapped so that consecutive tiles along N share an XCD (and its L2 copy of the A panel).
+// Design (wave64, MFMA 32x32x16 bf16, fp32 accumulate) -- details and measurements in DESIGN.md section 3:
+//   * block = 256 threads = 4 waves in a 2x2 grid; block tile 128x128 or 64x64 (cost model on the host), BK = 64.
+//   * operands staged global -> VGPR -> LDS (double buffer, one barrier per k-tile); the registers of tile t+1 are
+//     written to LDS right after the barrier and immediately re-issued for tile t+2 (two tiles of look-ahead).
+//   * K-contiguous operand: LDS image [rows][64] bf16 (128-B rows), 16-B chunk index XOR-swizzled with (row>>1)&7 so
+//     the ds_read_b128 fragment reads of a 16-lane group hit 16 distinct 16-B slots.
+//   * K-strided operand (stored [K][rows]): LDS image [64][rows] with a 64-B row pad, fragments fetched with the gfx950
+//     transposing LDS read ds_read_b64_tr_b16 (two per 8-element fragment) -- no transposed copies anywhere.
+//   * epilogue through LDS (row-contiguous 16-B vectors), fused bias / activation / act' / dropout / residual / accumulate.
+//   * split-K (grid.z): partial tiles to an fp32 workspace + splitk_reduce_kernel (which runs the same epilogue).
+//   * XCD-aware, grouped tile rasterisation (each XCD walks 8-row-panel groups, rows fastest).
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
