@@ -203,7 +203,14 @@ class Trainer:
         """one optimisation step on the bound batch; returns the (device) scalar loss tensor without synchronising."""
         assert self.static is not None, 'call set_batch() first'
         if self.use_graph and self.graphs is None:
-            self._capture()
+            try:
+                self._capture()
+            except Exception as e:                      # capture is an optimisation: fall back to eager launches of the same kernels
+                import sys
+                print(f'[prismer_amd] hipGraph capture failed ({type(e).__name__}: {e}); continuing with eager launches', file=sys.stderr)
+                torch.cuda.synchronize()
+                self.graphs, self.use_graph = None, False
+                ops.join_side()
         self._host_prologue()
         if self.use_graph:
             g1, g2, g3 = self.graphs
