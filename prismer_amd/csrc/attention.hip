@@ -32,18 +32,20 @@ struct Cfg {
   static constexpr int NLD = 64 * CPR / 256 > 0 ? 64 * CPR / 256 : 1;   // chunks per thread per tile
 };
 
-// ---- tile staging: 64 rows x DH of a strided [token][head*dh] tensor -> registers -> LDS (zero beyond n_rows)
+// ---- tile staging: 64 rows x DH of a strided [token][head*dh] tensor -> registers -> LDS.
+// Rows beyond n_rows re-read the last valid row (finite data; every consumer masks them by index): the loads carry no
+// predicate, so the prefetch is straight-line code and the compiler's vmcnt bookkeeping stays exact around the tile loop.
 template <int DH>
 __device__ __forceinline__ void tile_gload(const bf16* __restrict__ base, int64_t ts, int row0, int n_rows,
                                            u32x4 (&regs)[Cfg<DH>::NLD]) {
   constexpr int CPR = Cfg<DH>::CPR;
+  static_assert(64 * CPR % 256 == 0, "tile chunks must divide over 256 threads");
 #pragma unroll
   for (int i = 0; i < Cfg<DH>::NLD; ++i) {
     int id = threadIdx.x + 256 * i;
     int r = id / CPR, c = id % CPR;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (id < 64 * CPR && row0 + r < n_rows) v = *reinterpret_cast<const u32x4*>(base + (int64_t)(row0 + r) * ts + c * 8);
-    regs[i] = v;
+    int row = min(row0 + r, n_rows - 1);
+    regs[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)row * ts + c * 8);
   }
 }
 template <int DH>
@@ -53,7 +55,7 @@ __device__ __forceinline__ void tile_lstore(bf16* lds, const u32x4 (&regs)[Cfg<D
   for (int i = 0; i < Cfg<DH>::NLD; ++i) {
     int id = threadIdx.x + 256 * i;
     int r = id / CPR, c = id % CPR;
-    if (id < 64 * CPR) *reinterpret_cast<u32x4*>(lds + r * Cfg<DH>::RS + c * 8) = regs[i];
+    *reinterpret_cast<u32x4*>(lds + r * Cfg<DH>::RS + c * 8) = regs[i];
   }
 }
 
@@ -92,27 +94,49 @@ __device__ __forceinline__ float xor_sum(float v) {
 
 #define NEG_MASK (-FLT_MAX)
 
-// masked / scaled score for (query qi, key ki); `valid_key` false => key beyond Sk (excluded: -inf)
-__device__ __forceinline__ float mask_score(float s, float scale, int qi, int ki, int Sk, const uint8_t* km, int causal) {
+// Values fetched from global memory BEFORE a tile loop (the resident Q / dO / K / V fragments, lse): passing them through
+// an empty asm once makes them plain register values.  Without it the compiler keeps "may still be in flight" state for
+// them around the loop back-edge and emits s_waitcnt vmcnt(0..1) in front of the first MFMAs of every iteration, i.e. it
+// drains the next tile's prefetch right after issuing it (seen in the ISA: the prefetch never overlapped the math).
+__device__ __forceinline__ void settle(bf16x8& v) {
+  u32x4 t = __builtin_bit_cast(u32x4, v);
+  asm volatile("" : "+v"(t));
+  v = __builtin_bit_cast(bf16x8, t);
+}
+__device__ __forceinline__ void settle(float& v) { asm volatile("" : "+v"(v)); }
+
+// per-key state of a 64-key tile, staged through LDS with the tile (one float per key, handled by threads 0..63):
+//   0 = live key, NEG_MASK = excluded by key_mask, -inf = beyond Sk
+// The raw mask byte is prefetched with the tile and only interpreted at staging time (no dependent use -> no early wait).
+__device__ __forceinline__ uint32_t key_raw(const uint8_t* km, int ki, int Sk) { return km ? (uint32_t)km[min(ki, Sk - 1)] : 1u; }
+__device__ __forceinline__ float key_state(uint32_t raw, int ki, int Sk) {
   if (ki >= Sk) return -INFINITY;
-  if ((km && !km[ki]) || (causal && ki > qi)) return NEG_MASK;
-  return s * scale;
+  return raw ? 0.f : NEG_MASK;
+}
+__device__ __forceinline__ float score_of(float s, float scale, float kstate, bool causal_cut) {
+  float sc = causal_cut ? NEG_MASK : s * scale;
+  return kstate == 0.f ? sc : kstate;
 }
 
 // =====================================================================================================
 // forward
 // =====================================================================================================
+// LDS image (all three kernels): [stage 0: tile X, tile Y][stage 1: tile X, tile Y][per-row fp32 side data, 2 x 128]
+//   forward / dQ : X = K, Y = V, side = key state (64 floats per stage)
+//   dK/dV        : X = Q, Y = dO, side = lse (64) + delta (64) per stage
 template <int DH>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(ph_attn_fwd_args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 4 : 2))) void attn_fwd_kernel(ph_attn_fwd_args a) {
   using C = Cfg<DH>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16* smem = reinterpret_cast<bf16*>(smem_raw);
+  float* side = reinterpret_cast<float*>(smem + 4 * C::TILE);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
   const int q0 = blockIdx.x * 64 + wave * 16;
   const int qi = q0 + c;
+  const bool wave_live = q0 < a.Sq;                 // a wave whose 16 queries are all padding only helps staging
   const bf16* Q = reinterpret_cast<const bf16*>(a.q) + b * a.q_bs + (int64_t)h * DH;
   const bf16* K = reinterpret_cast<const bf16*>(a.k) + b * a.k_bs + (int64_t)h * DH;
   const bf16* V = reinterpret_cast<const bf16*>(a.v) + b * a.v_bs + (int64_t)h * DH;
@@ -136,10 +160,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(ph_attn_fwd_args a) {
 
   const int ntiles = (a.Sk + 63) / 64;
   u32x4 rk[C::NLD], rv[C::NLD];
+  uint32_t kraw = 1u;
+  int kraw_i = threadIdx.x;
   tile_gload<DH>(K, a.k_ts, 0, a.Sk, rk);
   tile_gload<DH>(V, a.v_ts, 0, a.Sk, rv);
+  if (threadIdx.x < 64) kraw = key_raw(km, kraw_i, a.Sk);
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) settle(qf[ks]);
   tile_lstore<DH>(smem, rk);
   tile_lstore<DH>(smem + C::TILE, rv);
+  if (threadIdx.x < 64) side[threadIdx.x] = key_state(kraw, kraw_i, a.Sk);
   __syncthreads();
   int cur = 0;
   for (int t = 0; t < ntiles; ++t) {
@@ -147,61 +177,75 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(ph_attn_fwd_args a) {
     if (more) {
       tile_gload<DH>(K, a.k_ts, (t + 1) * 64, a.Sk, rk);
       tile_gload<DH>(V, a.v_ts, (t + 1) * 64, a.Sk, rv);
+      kraw_i = (t + 1) * 64 + threadIdx.x;
+      if (threadIdx.x < 64) kraw = key_raw(km, kraw_i, a.Sk);
     }
     const bf16* kl = smem + cur * 2 * C::TILE;
     const bf16* vl = kl + C::TILE;
-    f32x4 s[4];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks)
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(kl, nt * 16, ks, lane), qf[ks], acc, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int ki = t * 64 + nt * 16 + g * 4 + r;
-        acc[r] = mask_score(acc[r], a.scale, qi, ki, a.Sk, km, a.causal);
-        mx = fmaxf(mx, acc[r]);
-      }
-      s[nt] = acc;
-    }
-    mx = xor_max(mx);
-    float m_new = fmaxf(m, mx);
-    float alpha = __expf(m - m_new);
-    float rs = 0.f;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float p = __expf(s[nt][r] - m_new);
-        rs += p;
-        s[nt][r] = p;
-      }
-    rs = xor_sum(rs);
-    lsum = lsum * alpha + rs;
-    m = m_new;
-#pragma unroll
-    for (int d = 0; d < C::DT; ++d) o[d] *= alpha;
-    if (drop) {
+    const float* kst = side + cur * 128;
+    const int kbase = t * 64;
+    if (wave_live) {
+      f32x4 s[4];
+      float mx = -INFINITY;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        int k4 = (t * 64 + nt * 16 + g * 4) >> 2;
-        u32x4 rnd = philox4x32((uint32_t)k4, rowid, dc.stream, 0xa77eu, dc.k0, dc.k1);
+        if (kbase + nt * 16 < a.Sk) {                 // 16-key sub-tiles entirely beyond Sk cost nothing
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[nt][r] = drop_apply(dc, rnd[r], s[nt][r]);
+          for (int ks = 0; ks < C::KS; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(kl, nt * 16, ks, lane), qf[ks], acc, 0, 0, 0);
+          const f32x4 st = *reinterpret_cast<const f32x4*>(kst + nt * 16 + g * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int ki = kbase + nt * 16 + g * 4 + r;
+            acc[r] = score_of(acc[r], a.scale, st[r], a.causal && ki > qi);
+            mx = fmaxf(mx, acc[r]);
+          }
+          s[nt] = acc;
+        } else {
+          s[nt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
       }
-    }
+      mx = xor_max(mx);
+      float m_new = fmaxf(m, mx);
+      float alpha = __expf(m - m_new);
+      float rs = 0.f;
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) {
-      bf16x8 pf = pack2(s[2 * k2], s[2 * k2 + 1]);
+      for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int d = 0; d < C::DT; ++d)
-        o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(vl, k2 * 32, d * 16, lane), pf, o[d], 0, 0, 0);
+        for (int r = 0; r < 4; ++r) {
+          float p = __expf(s[nt][r] - m_new);
+          rs += p;
+          s[nt][r] = p;
+        }
+      rs = xor_sum(rs);
+      lsum = lsum * alpha + rs;
+      m = m_new;
+#pragma unroll
+      for (int d = 0; d < C::DT; ++d) o[d] *= alpha;
+      if (drop) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          int k4 = (kbase + nt * 16 + g * 4) >> 2;
+          u32x4 rnd = philox4x32((uint32_t)k4, rowid, dc.stream, 0xa77eu, dc.k0, dc.k1);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[nt][r] = drop_apply(dc, rnd[r], s[nt][r]);
+        }
+      }
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        if (kbase + k2 * 32 < a.Sk) {
+          bf16x8 pf = pack2(s[2 * k2], s[2 * k2 + 1]);
+#pragma unroll
+          for (int d = 0; d < C::DT; ++d)
+            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(vl, k2 * 32, d * 16, lane), pf, o[d], 0, 0, 0);
+        }
+      }
     }
     if (more) {
       tile_lstore<DH>(smem + (cur ^ 1) * 2 * C::TILE, rk);
       tile_lstore<DH>(smem + (cur ^ 1) * 2 * C::TILE + C::TILE, rv);
+      if (threadIdx.x < 64) side[(cur ^ 1) * 128 + threadIdx.x] = key_state(kraw, kraw_i, a.Sk);
     }
     __syncthreads();
     cur ^= 1;
@@ -222,17 +266,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(ph_attn_fwd_args a) {
 // backward: dQ  (same streaming structure as forward)
 // =====================================================================================================
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(ph_attn_bwd_args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 4 : 2))) void attn_bwd_dq_kernel(ph_attn_bwd_args a) {
   using C = Cfg<DH>;
   const ph_attn_fwd_args& f = a.f;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16* smem = reinterpret_cast<bf16*>(smem_raw);
+  float* side = reinterpret_cast<float*>(smem + 4 * C::TILE);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int b = blockIdx.y / f.H, h = blockIdx.y % f.H;
   const int q0 = blockIdx.x * 64 + wave * 16;
   const int qi = q0 + c;
   const int qr = qi < f.Sq ? qi : f.Sq - 1;
+  const bool wave_live = q0 < f.Sq;
   const bf16* Q = reinterpret_cast<const bf16*>(f.q) + b * f.q_bs + (int64_t)h * DH;
   const bf16* K = reinterpret_cast<const bf16*>(f.k) + b * f.k_bs + (int64_t)h * DH;
   const bf16* V = reinterpret_cast<const bf16*>(f.v) + b * f.v_bs + (int64_t)h * DH;
@@ -246,7 +292,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(ph_attn_bwd_args a) {
     dof[ks] = *reinterpret_cast<const bf16x8*>(dO + (int64_t)qr * a.do_ts + ks * 32 + g * 8);
   }
   const int64_t ridx = (int64_t)(b * f.H + h) * f.Sq + qr;
-  const float lse = f.lse[ridx];
+  float lse = f.lse[ridx];
   DropCtx dc;
   const bool drop = f.drop_p > 0.f;
   if (drop) dc = make_drop(f.drop_seed, f.drop_stream, f.drop_p);
@@ -256,69 +302,92 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(ph_attn_bwd_args a) {
 #pragma unroll
   for (int d = 0; d < C::DT; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // Two passes over the K/V tiles.  Pass 0 computes delta_i = sum_j P_ij * dP_ij in fp32 from the SAME recomputed P
-  // and dP the second pass uses (softmax backward needs dP_ij - delta_i, which cancels to ~0 on peaked rows; taking
-  // delta from the bf16-rounded forward output O, rowsum(dO*O), leaves a 2^-9 relative inconsistency that shows up as
-  // 10 %-level noise in dQ/dK of peaked attention rows).  Pass 1 forms dS and accumulates dQ.
+  // Two sweeps over the K/V tiles, run as ONE loop of 2*ntiles steps so that the prefetch never drains in between.
+  // Sweep 0 computes delta_i = sum_j P_ij * dP_ij in fp32 from the SAME recomputed P and dP sweep 1 uses (softmax backward
+  // needs dP_ij - delta_i, which cancels to ~0 on peaked rows; taking delta from the bf16-rounded forward output O,
+  // rowsum(dO*O), leaves a 2^-9 relative inconsistency that shows up as 10 %-level noise in dQ/dK of peaked attention
+  // rows).  Sweep 1 forms dS and accumulates dQ.
   const int ntiles = (f.Sk + 63) / 64;
+  const int nsteps = 2 * ntiles;
   u32x4 rk[C::NLD], rv[C::NLD];
-  float delta = 0.f;
-  for (int pass = 0; pass < 2; ++pass) {
-    tile_gload<DH>(K, f.k_ts, 0, f.Sk, rk);
-    tile_gload<DH>(V, f.v_ts, 0, f.Sk, rv);
-    tile_lstore<DH>(smem, rk);
-    tile_lstore<DH>(smem + C::TILE, rv);
-    __syncthreads();
-    int cur = 0;
-    float dsum = 0.f;
-    for (int t = 0; t < ntiles; ++t) {
-      const bool more = t + 1 < ntiles;
-      if (more) {
-        tile_gload<DH>(K, f.k_ts, (t + 1) * 64, f.Sk, rk);
-        tile_gload<DH>(V, f.v_ts, (t + 1) * 64, f.Sk, rv);
-      }
-      const bf16* kl = smem + cur * 2 * C::TILE;
-      const bf16* vl = kl + C::TILE;
+  uint32_t kraw = 1u;
+  int kraw_i = threadIdx.x;
+  tile_gload<DH>(K, f.k_ts, 0, f.Sk, rk);
+  tile_gload<DH>(V, f.v_ts, 0, f.Sk, rv);
+  if (threadIdx.x < 64) kraw = key_raw(km, kraw_i, f.Sk);
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) { settle(qf[ks]); settle(dof[ks]); }
+  settle(lse);
+  tile_lstore<DH>(smem, rk);
+  tile_lstore<DH>(smem + C::TILE, rv);
+  if (threadIdx.x < 64) side[threadIdx.x] = key_state(kraw, kraw_i, f.Sk);
+  __syncthreads();
+  int cur = 0;
+  float delta = 0.f, dsum = 0.f;
+  for (int u = 0; u < nsteps; ++u) {
+    const bool sweep1 = u >= ntiles;
+    const int t = sweep1 ? u - ntiles : u;
+    const bool more = u + 1 < nsteps;
+    if (more) {
+      const int tn = (t + 1 == ntiles) ? 0 : t + 1;
+      tile_gload<DH>(K, f.k_ts, tn * 64, f.Sk, rk);
+      tile_gload<DH>(V, f.v_ts, tn * 64, f.Sk, rv);
+      kraw_i = tn * 64 + threadIdx.x;
+      if (threadIdx.x < 64) kraw = key_raw(km, kraw_i, f.Sk);
+    }
+    const bf16* kl = smem + cur * 2 * C::TILE;
+    const bf16* vl = kl + C::TILE;
+    const float* kst = side + cur * 128;
+    const int kbase = t * 64;
+    if (wave_live) {
       f32x4 ds[4];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        if (kbase + nt * 16 < f.Sk) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < C::KS; ++ks) {
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(kl, nt * 16, ks, lane), qf[ks], acc, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(vl, nt * 16, ks, lane), dof[ks], dp, 0, 0, 0);
-        }
-        u32x4 rnd;
-        if (drop) rnd = philox4x32((uint32_t)((t * 64 + nt * 16 + g * 4) >> 2), rowid, dc.stream, 0xa77eu, dc.k0, dc.k1);
+          for (int ks = 0; ks < C::KS; ++ks) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(kl, nt * 16, ks, lane), qf[ks], acc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(vl, nt * 16, ks, lane), dof[ks], dp, 0, 0, 0);
+          }
+          const f32x4 st = *reinterpret_cast<const f32x4*>(kst + nt * 16 + g * 4);
+          u32x4 rnd;
+          if (drop) rnd = philox4x32((uint32_t)((kbase + nt * 16 + g * 4) >> 2), rowid, dc.stream, 0xa77eu, dc.k0, dc.k1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int ki = t * 64 + nt * 16 + g * 4 + r;
-          float p = __expf(mask_score(acc[r], f.scale, qi, ki, f.Sk, km, f.causal) - lse);
-          float dpe = drop ? drop_apply(dc, rnd[r], dp[r]) : dp[r];
-          dsum += p * dpe;
-          ds[nt][r] = p * (dpe - delta);
+          for (int r = 0; r < 4; ++r) {
+            int ki = kbase + nt * 16 + g * 4 + r;
+            float p = __expf(score_of(acc[r], f.scale, st[r], f.causal && ki > qi) - lse);
+            float dpe = drop ? drop_apply(dc, rnd[r], dp[r]) : dp[r];
+            dsum += p * dpe;
+            ds[nt][r] = p * (dpe - delta);
+          }
+        } else {
+          ds[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
-      if (pass == 1) {
+      if (sweep1) {
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
-          bf16x8 dsf = pack2(ds[2 * k2], ds[2 * k2 + 1]);
+          if (kbase + k2 * 32 < f.Sk) {
+            bf16x8 dsf = pack2(ds[2 * k2], ds[2 * k2 + 1]);
 #pragma unroll
-          for (int d = 0; d < C::DT; ++d)
-            dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(kl, k2 * 32, d * 16, lane), dsf, dq[d], 0, 0, 0);
+            for (int d = 0; d < C::DT; ++d)
+              dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(kl, k2 * 32, d * 16, lane), dsf, dq[d], 0, 0, 0);
+          }
         }
       }
-      if (more) {
-        tile_lstore<DH>(smem + (cur ^ 1) * 2 * C::TILE, rk);
-        tile_lstore<DH>(smem + (cur ^ 1) * 2 * C::TILE + C::TILE, rv);
+      if (u == ntiles - 1) {
+        delta = xor_sum(dsum);
+        if (g == 0 && qi < f.Sq) a.delta[ridx] = delta;    // consumed by the dK/dV kernel (launched after this one)
       }
-      __syncthreads();
-      cur ^= 1;
     }
-    if (pass == 0) {
-      delta = xor_sum(dsum);
-      if (g == 0 && qi < f.Sq) a.delta[ridx] = delta;      // consumed by the dK/dV kernel (launched after this one)
+    if (more) {
+      tile_lstore<DH>(smem + (cur ^ 1) * 2 * C::TILE, rk);
+      tile_lstore<DH>(smem + (cur ^ 1) * 2 * C::TILE + C::TILE, rv);
+      if (threadIdx.x < 64) side[(cur ^ 1) * 128 + threadIdx.x] = key_state(kraw, kraw_i, f.Sk);
     }
+    __syncthreads();
+    cur ^= 1;
   }
   if (qi < f.Sq) {
     bf16* dQ = reinterpret_cast<bf16*>(a.dq) + b * a.dq_bs + (int64_t)qi * a.dq_ts + (int64_t)h * DH;
@@ -334,23 +403,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(ph_attn_bwd_args a) {
 // backward: dK, dV  (one key per lane; Q / dO streamed in 64-query tiles)
 // =====================================================================================================
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(ph_attn_bwd_args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 3 : 2))) void attn_bwd_dkv_kernel(ph_attn_bwd_args a) {
   using C = Cfg<DH>;
   const ph_attn_fwd_args& f = a.f;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16* smem = reinterpret_cast<bf16*>(smem_raw);
+  float* side = reinterpret_cast<float*>(smem + 4 * C::TILE);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int b = blockIdx.y / f.H, h = blockIdx.y % f.H;
   const int k0 = blockIdx.x * 64 + wave * 16;
   const int ki = k0 + c;
   const int kr = ki < f.Sk ? ki : f.Sk - 1;
+  const bool wave_live = k0 < f.Sk;
   const bf16* Q = reinterpret_cast<const bf16*>(f.q) + b * f.q_bs + (int64_t)h * DH;
   const bf16* K = reinterpret_cast<const bf16*>(f.k) + b * f.k_bs + (int64_t)h * DH;
   const bf16* V = reinterpret_cast<const bf16*>(f.v) + b * f.v_bs + (int64_t)h * DH;
   const bf16* dO = reinterpret_cast<const bf16*>(a.d_o) + b * a.do_bs + (int64_t)h * DH;
   const uint8_t* km = f.key_mask ? f.key_mask + (int64_t)b * f.Sk : nullptr;
-  const bool key_masked = km && !km[kr];
 
   bf16x8 kf[C::KS], vf[C::KS];
 #pragma unroll
@@ -363,6 +433,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(ph_attn_bwd_args a) {
   if (drop) dc = make_drop(f.drop_seed, f.drop_stream, f.drop_p);
   const float* lse_base = f.lse + (int64_t)(b * f.H + h) * f.Sq;
   const float* delta_base = a.delta + (int64_t)(b * f.H + h) * f.Sq;
+  // per-query softmax statistics of a tile travel with it: threads 0..63 fetch lse, 64..127 delta
+  const float* stat_base = threadIdx.x < 64 ? lse_base : delta_base;
+  const int stat_row = threadIdx.x & 63;
 
   f32x4 dk[C::DT], dv[C::DT];
 #pragma unroll
@@ -370,10 +443,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(ph_attn_bwd_args a) {
 
   const int ntiles = (f.Sq + 63) / 64;
   u32x4 rq[C::NLD], rd[C::NLD];
+  float sreg = 0.f;
   tile_gload<DH>(Q, f.q_ts, 0, f.Sq, rq);
   tile_gload<DH>(dO, a.do_ts, 0, f.Sq, rd);
+  if (threadIdx.x < 128) sreg = stat_base[min(stat_row, f.Sq - 1)];
+  float kstate = key_raw(km, kr, f.Sk) ? 0.f : 1.f;   // this lane's key: excluded by key_mask?
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) { settle(kf[ks]); settle(vf[ks]); }
+  settle(kstate);
+  const bool key_masked = kstate != 0.f;
   tile_lstore<DH>(smem, rq);
   tile_lstore<DH>(smem + C::TILE, rd);
+  if (threadIdx.x < 128) side[threadIdx.x] = sreg;
   __syncthreads();
   int cur = 0;
   for (int t = 0; t < ntiles; ++t) {
@@ -381,54 +462,69 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(ph_attn_bwd_args a) {
     if (more) {
       tile_gload<DH>(Q, f.q_ts, (t + 1) * 64, f.Sq, rq);
       tile_gload<DH>(dO, a.do_ts, (t + 1) * 64, f.Sq, rd);
+      if (threadIdx.x < 128) sreg = stat_base[min((t + 1) * 64 + stat_row, f.Sq - 1)];
     }
     const bf16* ql = smem + cur * 2 * C::TILE;
     const bf16* dl = ql + C::TILE;
-    f32x4 pd[4], ds[4];
+    const float* stl = side + cur * 128;
+    const int qbase = t * 64;
+    if (wave_live) {
+      f32x4 pd[4], ds[4];
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      for (int qt = 0; qt < 4; ++qt) {
+        if (qbase + qt * 16 < f.Sq) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(ql, qt * 16, ks, lane), kf[ks], acc, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(dl, qt * 16, ks, lane), vf[ks], dp, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int qi = t * 64 + qt * 16 + g * 4 + r;          // C layout here: row = query, col (lane & 15) = key
-        float p = 0.f, dpe = dp[r];
-        if (qi < f.Sq && ki < f.Sk) {
-          float sc = (key_masked || (f.causal && ki > qi)) ? NEG_MASK : acc[r] * f.scale;
-          p = __expf(sc - lse_base[qi]);
-          float pdrop = p;
-          if (drop) {
-            uint32_t rowid = (uint32_t)((b * f.H + h) * f.Sq + qi);
-            u32x4 rnd = philox4x32((uint32_t)(ki >> 2), rowid, dc.stream, 0xa77eu, dc.k0, dc.k1);
-            uint32_t rr = rnd[ki & 3];
-            pdrop = drop_apply(dc, rr, p);
-            dpe = drop_apply(dc, rr, dp[r]);
+          for (int ks = 0; ks < C::KS; ++ks) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(ql, qt * 16, ks, lane), kf[ks], acc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(dl, qt * 16, ks, lane), vf[ks], dp, 0, 0, 0);
           }
-          pd[qt][r] = pdrop;
-          ds[qt][r] = p * (dpe - delta_base[qi]);
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(stl + qt * 16 + g * 4);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(stl + 64 + qt * 16 + g * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int qi = qbase + qt * 16 + g * 4 + r;         // C layout here: row = query, col (lane & 15) = key
+            float p = 0.f, dpe = dp[r];
+            if (qi < f.Sq && ki < f.Sk) {
+              float sc = (key_masked || (f.causal && ki > qi)) ? NEG_MASK : acc[r] * f.scale;
+              p = __expf(sc - l4[r]);
+              float pdrop = p;
+              if (drop) {
+                uint32_t rowid = (uint32_t)((b * f.H + h) * f.Sq + qi);
+                u32x4 rnd = philox4x32((uint32_t)(ki >> 2), rowid, dc.stream, 0xa77eu, dc.k0, dc.k1);
+                uint32_t rr = rnd[ki & 3];
+                pdrop = drop_apply(dc, rr, p);
+                dpe = drop_apply(dc, rr, dp[r]);
+              }
+              pd[qt][r] = pdrop;
+              ds[qt][r] = p * (dpe - d4[r]);
+            } else {
+              pd[qt][r] = 0.f;
+              ds[qt][r] = 0.f;
+            }
+          }
         } else {
-          pd[qt][r] = 0.f;
-          ds[qt][r] = 0.f;
+          pd[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          ds[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
-    }
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) {
-      bf16x8 pf = pack2(pd[2 * k2], pd[2 * k2 + 1]);
-      bf16x8 dsf = pack2(ds[2 * k2], ds[2 * k2 + 1]);
+      for (int k2 = 0; k2 < 2; ++k2) {
+        if (qbase + k2 * 32 < f.Sq) {
+          bf16x8 pf = pack2(pd[2 * k2], pd[2 * k2 + 1]);
+          bf16x8 dsf = pack2(ds[2 * k2], ds[2 * k2 + 1]);
 #pragma unroll
-      for (int d = 0; d < C::DT; ++d) {
-        dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(dl, k2 * 32, d * 16, lane), pf, dv[d], 0, 0, 0);
-        dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(ql, k2 * 32, d * 16, lane), dsf, dk[d], 0, 0, 0);
+          for (int d = 0; d < C::DT; ++d) {
+            dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(dl, k2 * 32, d * 16, lane), pf, dv[d], 0, 0, 0);
+            dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(ql, k2 * 32, d * 16, lane), dsf, dk[d], 0, 0, 0);
+          }
+        }
       }
     }
     if (more) {
       tile_lstore<DH>(smem + (cur ^ 1) * 2 * C::TILE, rq);
       tile_lstore<DH>(smem + (cur ^ 1) * 2 * C::TILE + C::TILE, rd);
+      if (threadIdx.x < 128) side[(cur ^ 1) * 128 + threadIdx.x] = sreg;
     }
     __syncthreads();
     cur ^= 1;
@@ -471,7 +567,7 @@ extern "C" int ph_attention_fwd(const ph_attn_fwd_args* a, hipStream_t stream) {
   dim3 grid(ceil_div(a->Sq, 64), a->B * a->H);
 #define PH_FWD(DHV)                                                                        \
   case DHV: {                                                                              \
-    int smem = set_smem(attn_fwd_kernel<DHV>, 4 * Cfg<DHV>::TILE * 2);                      \
+    int smem = set_smem(attn_fwd_kernel<DHV>, 4 * Cfg<DHV>::TILE * 2 + 1024);                      \
     hipLaunchKernelGGL(attn_fwd_kernel<DHV>, grid, dim3(256), smem, stream, *a);           \
   } break;
   switch (a->dh) { PH_FWD(32) PH_FWD(64) PH_FWD(96) PH_FWD(128) }
@@ -491,7 +587,7 @@ extern "C" int ph_attention_bwd(const ph_attn_bwd_args* a, hipStream_t stream) {
   dim3 gq(ceil_div(f.Sq, 64), f.B * f.H), gk(ceil_div(f.Sk, 64), f.B * f.H);
 #define PH_BWD(DHV)                                                                          \
   case DHV: {                                                                                \
-    int smem = set_smem(attn_bwd_dq_kernel<DHV>, 4 * Cfg<DHV>::TILE * 2);                     \
+    int smem = set_smem(attn_bwd_dq_kernel<DHV>, 4 * Cfg<DHV>::TILE * 2 + 1024);                     \
     set_smem(attn_bwd_dkv_kernel<DHV>, smem);                                                \
     hipLaunchKernelGGL(attn_bwd_dq_kernel<DHV>, gq, dim3(256), smem, stream, *a);            \
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<DHV>, gk, dim3(256), smem, stream, *a);           \

@@ -74,7 +74,38 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(ph_layernorm_fwd_args a) {
 
 // Backward.  Each wave walks rows (grid-stride) keeping its dgamma / dbeta partials in registers; the block
 // folds its 4 waves through LDS and issues one fp32 atomic per column.
-template <int NCH>
+// One row's HBM operands, requested a whole row ahead of their use (rows beyond M re-read row M-1: no predicate, so
+// the prefetch is straight-line code and the waits in front of the math leave the next row's loads in flight).
+template <int NCH, bool XF32>
+struct LnBwdRow {
+  bf16x4 x[XF32 ? 1 : NCH];
+  f32x4 xf[XF32 ? NCH : 1];
+  bf16x4 dy[NCH], dy2[NCH], dsk[NCH];
+  float mean, rstd;
+};
+
+template <int NCH, bool XF32>
+__device__ __forceinline__ void ln_bwd_fetch(const ph_layernorm_bwd_args& a, int row, int lane, int nch, LnBwdRow<NCH, XF32>& r) {
+  row = min(row, a.M - 1);
+  const bf16* x = reinterpret_cast<const bf16*>(a.x) + (size_t)row * a.D;
+  const float* xf = reinterpret_cast<const float*>(a.x) + (size_t)row * a.D;
+  const bf16* dy = reinterpret_cast<const bf16*>(a.dy) + (size_t)map_row(a.dy_map, row) * a.D;
+  const bf16* dy2 = a.dy2 ? reinterpret_cast<const bf16*>(a.dy2) + (size_t)map_row(a.dy2_map, row) * a.D : nullptr;
+  const bf16* dsk = a.dskip ? reinterpret_cast<const bf16*>(a.dskip) + (size_t)row * a.D : nullptr;
+  r.mean = a.mean[row];
+  r.rstd = a.rstd[row];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    int c = min(lane + 64 * i, nch - 1);
+    if (XF32) r.xf[i] = *reinterpret_cast<const f32x4*>(xf + c * 4);
+    else r.x[i] = *reinterpret_cast<const bf16x4*>(x + c * 4);
+    r.dy[i] = *reinterpret_cast<const bf16x4*>(dy + c * 4);
+    if (dy2) r.dy2[i] = *reinterpret_cast<const bf16x4*>(dy2 + c * 4);
+    if (dsk) r.dsk[i] = *reinterpret_cast<const bf16x4*>(dsk + c * 4);
+  }
+}
+
+template <int NCH, bool XF32>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(ph_layernorm_bwd_args a) {
   __shared__ float red_flat[2 * 4 * 512];   // [dgamma|dbeta][wave][512 columns]: 16 KB, D is folded in passes of 512
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -87,34 +118,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(ph_layernorm_bwd_args a) {
   DropCtx dc;
   const bool drop = a.dx_drop && a.drop_p > 0.f;
   if (drop) dc = make_drop(a.drop_seed, a.drop_stream, a.drop_p);
+  const bool has_dy2 = a.dy2 != nullptr, has_dsk = a.dskip != nullptr;
 
-  for (int row = blockIdx.x * 4 + wave; row < a.M; row += gridDim.x * 4) {
-    const bf16* x = reinterpret_cast<const bf16*>(a.x) + (size_t)row * a.D;
-    const float* xf = reinterpret_cast<const float*>(a.x) + (size_t)row * a.D;
-    const bf16* dy = reinterpret_cast<const bf16*>(a.dy) + (size_t)map_row(a.dy_map, row) * a.D;
-    const bf16* dy2 = a.dy2 ? reinterpret_cast<const bf16*>(a.dy2) + (size_t)map_row(a.dy2_map, row) * a.D : nullptr;
-    float mean = a.mean[row], rstd = a.rstd[row];
+  const int stride = gridDim.x * 4;
+  int row = blockIdx.x * 4 + wave;
+  LnBwdRow<NCH, XF32> cur, nxt;
+  f32x4 gm[NCH];
+  if (row < a.M) {
+    ln_bwd_fetch<NCH, XF32>(a, row, lane, nch, cur);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) gm[i] = *reinterpret_cast<const f32x4*>(a.gamma + min(lane + 64 * i, nch - 1) * 4);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) asm volatile("" : "+v"(gm[i]));      // loop-invariant: settle before the row loop
+  }
+  // Ping-pong over two register sets (no copies): row i+1's operands are requested before row i is reduced and stored,
+  // and the wait in front of row i's math leaves them in flight.
+  auto process = [&](const LnBwdRow<NCH, XF32>& r, int row) {
+    const float mean = r.mean, rstd = r.rstd;
     float xh[NCH][4], g[NCH][4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       int c = lane + 64 * i;
       if (c < nch) {
-        float xv[4];
-        if (a.x_f32) { f32x4 t = *reinterpret_cast<const f32x4*>(xf + c * 4); xv[0] = t[0]; xv[1] = t[1]; xv[2] = t[2]; xv[3] = t[3]; }
-        else { bf16x4 t = *reinterpret_cast<const bf16x4*>(x + c * 4); xv[0] = bf2f(t[0]); xv[1] = bf2f(t[1]); xv[2] = bf2f(t[2]); xv[3] = bf2f(t[3]); }
-        bf16x4 td = *reinterpret_cast<const bf16x4*>(dy + c * 4);
-        f32x4 gm = *reinterpret_cast<const f32x4*>(a.gamma + c * 4);
-        bf16x4 td2;
-        if (dy2) td2 = *reinterpret_cast<const bf16x4*>(dy2 + c * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float d = bf2f(td[e]);
-          if (dy2) d += bf2f(td2[e]);
-          xh[i][e] = (xv[e] - mean) * rstd;
+          float xv = XF32 ? r.xf[i][e] : bf2f(r.x[i][e]);
+          float d = bf2f(r.dy[i][e]);
+          if (has_dy2) d += bf2f(r.dy2[i][e]);
+          xh[i][e] = (xv - mean) * rstd;
           dg[i][e] += d * xh[i][e];
           db[i][e] += d;
-          g[i][e] = d * gm[e];
+          g[i][e] = d * gm[i][e];
           s1 += g[i][e];
           s2 += g[i][e] * xh[i][e];
         }
@@ -122,7 +157,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(ph_layernorm_bwd_args a) {
     }
     float m1 = wave_sum(s1) / (float)a.D, m2 = wave_sum(s2) / (float)a.D;
     bf16* dx = reinterpret_cast<bf16*>(a.dx) + (size_t)row * a.D;
-    const bf16* dsk = a.dskip ? reinterpret_cast<const bf16*>(a.dskip) + (size_t)row * a.D : nullptr;
     bf16* dxd = drop ? reinterpret_cast<bf16*>(a.dx_drop) + (size_t)row * a.D : nullptr;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -130,11 +164,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(ph_layernorm_bwd_args a) {
       if (c < nch) {
         float o[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rstd * (g[i][e] - m1 - xh[i][e] * m2);
-        if (dsk) {
-          bf16x4 t = *reinterpret_cast<const bf16x4*>(dsk + c * 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] += bf2f(t[e]);
+        for (int e = 0; e < 4; ++e) {
+          o[e] = rstd * (g[i][e] - m1 - xh[i][e] * m2);
+          if (has_dsk) o[e] += bf2f(r.dsk[i][e]);
         }
         bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
         *reinterpret_cast<bf16x4*>(dx + c * 4) = ob;
@@ -146,6 +178,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(ph_layernorm_bwd_args a) {
         }
       }
     }
+  };
+  for (; row < a.M; row += 2 * stride) {
+    ln_bwd_fetch<NCH, XF32>(a, row + stride, lane, nch, nxt);
+    process(cur, row);
+    if (row + stride >= a.M) break;
+    ln_bwd_fetch<NCH, XF32>(a, row + 2 * stride, lane, nch, cur);
+    process(nxt, row + stride);
   }
   if (!a.dgamma && !a.dbeta) return;
   // fold the 4 waves: column passes of 512 columns (128 chunks) to keep LDS at 16 KB
@@ -216,16 +255,22 @@ extern "C" int ph_layernorm_bwd(const ph_layernorm_bwd_args* a, hipStream_t stre
   ProfScope prof__(PH_FAM_LAYERNORM, 0.0, 6.0 * a->M * (double)a->D, stream);
   PH_CHECK_ARG(a->M > 0 && a->D > 0 && (a->D % 4) == 0 && a->D <= MAX_CH * 256, "ph_layernorm_bwd: D=%d unsupported", a->D);
   PH_CHECK_ARG(!a->dx_drop || !(a->drop_p > 0.f) || a->drop_seed, "ph_layernorm_bwd: dropout needs a seed");
-  int grid = min(ceil_div(a->M, 4), 512);
+  int grid = min(ceil_div(a->M, 4), 768);
   ph_layernorm_bwd_args b = *a;
   const bool need_params = a->dgamma || a->dbeta;
   if (!need_params || (int64_t)grid * 2 * a->D * 4 > a->partial_ws_bytes) b.partial_ws = nullptr;
   const int nch = ceil_div(a->D, 256);
-  if (nch <= 1) hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(grid), dim3(256), 0, stream, b);
-  else if (nch <= 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(grid), dim3(256), 0, stream, b);
-  else if (nch <= 3) hipLaunchKernelGGL(ln_bwd_kernel<3>, dim3(grid), dim3(256), 0, stream, b);
-  else if (nch <= 4) hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(grid), dim3(256), 0, stream, b);
-  else hipLaunchKernelGGL(ln_bwd_kernel<8>, dim3(grid), dim3(256), 0, stream, b);
+#define PH_LN_BWD(N)                                                                                          \
+  do {                                                                                                       \
+    if (b.x_f32) hipLaunchKernelGGL((ln_bwd_kernel<N, true>), dim3(grid), dim3(256), 0, stream, b);          \
+    else hipLaunchKernelGGL((ln_bwd_kernel<N, false>), dim3(grid), dim3(256), 0, stream, b);                 \
+  } while (0)
+  if (nch <= 1) PH_LN_BWD(1);
+  else if (nch <= 2) PH_LN_BWD(2);
+  else if (nch <= 3) PH_LN_BWD(3);
+  else if (nch <= 4) PH_LN_BWD(4);
+  else PH_LN_BWD(8);
+#undef PH_LN_BWD
   if (need_params && b.partial_ws)
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ceil_div(2 * a->D, 256), min(grid, 32)), dim3(256), 0, stream, b.partial_ws, grid, a->D, a->dgamma, a->dbeta);
   PH_LAUNCH_CHECK("ln_bwd_kernel");

@@ -238,7 +238,7 @@ class EncoderProgram:
             sv['resampler'] = layers
             sv['xf'] = xf
 
-    def resampler_bwd(self, dlat, B, sv):
+    def resampler_bwd(self, dlat, B, sv, dxf_out=None):
         d, P = self.d, self.P
         W, L, Mx = d.width, d.num_latents, d.num_expert_tokens
         KV = L + Mx
@@ -274,7 +274,9 @@ class EncoderProgram:
             dqin = ops.gemm(dq, wq, trans_b=True)
             dkvin = ops.gemm(dkv, wkv, trans_b=True)
             dlat, _ = blk['ln_1'].bwd(dqin, s['lat'], s['m1'], s['r1'], dy2=dkvin, dy2_map=RowMap(L, KV, 0), dskip=dlat1)
-            dxf, _ = blk['ln_2'].bwd(dkvin, xf, s['m2'], s['r2'], dy_map=RowMap(Mx, KV, L), dskip=dxf)
+            last = blk is self.rblocks[0]
+            dxf, _ = blk['ln_2'].bwd(dkvin, xf, s['m2'], s['r2'], dy_map=RowMap(Mx, KV, L), dskip=dxf,
+                                     dx=(dxf_out if last else None))
         g = P.g('resampler.latents')
         if g is not None:                                                # sum over the batch of d(repeat(latents))
             ops.colsum(dlat.view(B, L * W), g.view(-1))
@@ -330,7 +332,10 @@ class EncoderProgram:
         return dx
 
     # ---------------------------------------------------------------------------------------- whole encoder
-    def forward(self, x, inst_table, training, save):
+    # The encoder is split in two so that the Trainer can pipeline micro-batches:
+    #   front  = patch embed + six expert stems (train-mode BatchNorm needs the WHOLE batch)  -> token buffers h, xf
+    #   trunk  = resampler + ln_pre + ViT blocks + ln_post (sample-independent: any contiguous slice of the batch)
+    def forward_front(self, x, inst_table, training, save):
         d, P = self.d, self.P
         W, p = d.width, d.patch_size
         rgb = x['rgb']
@@ -344,6 +349,7 @@ class EncoderProgram:
         feat = ops.gemm(col, shadow)
         ops.tokens_finalize(feat, P.f('positional_embedding'), h, B, N, W, S, 0)
         names = [k for k in x if k != 'rgb']
+        xf = None
         if names:
             G = d.expert_grid ** 2
             Mx = len(names) * G
@@ -369,6 +375,17 @@ class EncoderProgram:
                     keep.append(f)
             ops.POOL.join()
             del keep
+        if save:
+            sv.update(B=B, names=names, rgb_col=col,
+                      inst=(x['obj_detection']['instance'].contiguous() if 'obj_detection' in x else None), inst_table=inst_table)
+        return h, xf, sv
+
+    def forward_trunk(self, h, xf, B, save):
+        """h: [B*S, W] rows of B images (rgb tokens filled; the latent rows are written here); xf: [B*Mx, W] or None."""
+        d = self.d
+        S, W = d.seq_len, d.width
+        sv = {} if save else None
+        if xf is not None:
             self.resampler_fwd(xf, B, h, sv)
         h0, mp, rp = self.ln_pre.fwd(h)
         blocks_sv = [] if save else None
@@ -377,27 +394,34 @@ class EncoderProgram:
             t = self.block_fwd(blk, t, B, S, blocks_sv)
         out, mo, ro = self.ln_post.fwd(t)
         if save:
-            sv.update(B=B, names=names, rgb_col=col, h=h, mp=mp, rp=rp, blocks=blocks_sv, t=t, mo=mo, ro=ro,
-                      inst=(x['obj_detection']['instance'].contiguous() if 'obj_detection' in x else None), inst_table=inst_table)
+            sv.update(B=B, h=h, mp=mp, rp=rp, blocks=blocks_sv, t=t, mo=mo, ro=ro, has_x=xf is not None)
         return out.view(B, S, W), sv
 
-    def backward(self, sv, dout):
-        """dout: [B, S, W] bf16 (batch-major). Accumulates every trainable gradient into the store's buffer."""
-        d, P = self.d, self.P
+    def backward_trunk(self, sv, dout, dh_out, dxf_out):
+        """dout [B,S,W] -> dh_out [B*S, W] (gradient of the token buffer) and dxf_out [B*Mx, W] (expert tokens), both given
+        as (slices of) preallocated buffers."""
+        d = self.d
         W = d.width
         B, S, N = sv['B'], d.seq_len, d.num_rgb_tokens
         dt, _ = self.ln_post.bwd(dout.reshape(B * S, W), sv['t'], sv['mo'], sv['ro'])
         for blk, s in zip(reversed(self.blocks), reversed(sv['blocks'])):
             dt = self.block_bwd(blk, s, dt, B, S)
-        dh, _ = self.ln_pre.bwd(dt, sv['h'], sv['mp'], sv['rp'])
+        self.ln_pre.bwd(dt, sv['h'], sv['mp'], sv['rp'], dx=dh_out)
+        if sv['has_x']:
+            L = d.num_latents
+            dlat = torch.empty(B * L, W, dtype=BF16, device=dt.device)
+            ops.copy_rows(dh_out, dlat, B * L, W, src_map=RowMap(L, S, N))
+            self.resampler_bwd(dlat, B, sv, dxf_out)
+
+    def backward_front(self, sv, dh, dxf):
+        d, P = self.d, self.P
+        W = d.width
+        B, S, N = sv['B'], d.seq_len, d.num_rgb_tokens
         gpos = P.g('positional_embedding')
         names = sv['names']
         if names:
-            L, G = d.num_latents, d.expert_grid ** 2
+            G = d.expert_grid ** 2
             Mx = len(names) * G
-            dlat = torch.empty(B * L, W, dtype=BF16, device=dh.device)
-            ops.copy_rows(dh, dlat, B * L, W, src_map=RowMap(L, S, N))
-            dxf = self.resampler_bwd(dlat, B, sv)
             same = d.expert_grid == d.rgb_grid
             dpos_e = gpos if same else torch.zeros(G, W, dtype=F32, device=dh.device)
             keep = []
@@ -420,3 +444,18 @@ class EncoderProgram:
         drgb = torch.empty(B * N, W, dtype=BF16, device=dh.device)
         ops.tokens_finalize_bwd(dh, drgb, gpos, B, N, W, S, 0)
         self.conv_wgrad('conv1.rgb.weight', d.patch_size, drgb, sv['rgb_col'])
+
+    def forward(self, x, inst_table, training, save):
+        h, xf, svf = self.forward_front(x, inst_table, training, save)
+        out, svt = self.forward_trunk(h, xf, x['rgb'].shape[0], save)
+        return out, ((svf, svt) if save else None)
+
+    def backward(self, sv, dout):
+        """dout: [B, S, W] bf16 (batch-major). Accumulates every trainable gradient into the store's buffer."""
+        svf, svt = sv
+        d = self.d
+        B = svt['B']
+        dh = torch.empty(B * d.seq_len, d.width, dtype=BF16, device=dout.device)
+        dxf = torch.empty(B * d.num_expert_tokens, d.width, dtype=BF16, device=dout.device) if svt['has_x'] else None
+        self.backward_trunk(svt, dout, dh, dxf)
+        self.backward_front(svf, dh, dxf)
