@@ -63,11 +63,26 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // ---- activations --------------------------------------------------------------------------------
 // reference: QuickGELU utils.py:23-25, SquaredReLU utils.py:28-30, erf-GELU roberta.py:164,423
+// Activation math runs inside GEMM epilogues (64 outputs per thread per tile): exact IEEE division / erff there cost more
+// VALU time than the tile's global stores.  v_rcp_f32 / v_exp_f32 are 1-ulp instructions; erf uses Abramowitz-Stegun
+// 7.1.26 (|abs err| <= 1.5e-7), far below the bf16 rounding every result of these functions goes through.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.0f + __expf(-x)); }
+// returns erf(|u|) given e = exp(-u*u)
+__device__ __forceinline__ float erf_abs_from_exp(float au, float e) {
+  float t = fast_rcp(fmaf(0.3275911f, au, 1.0f));
+  float poly = fmaf(fmaf(fmaf(fmaf(1.061405429f, t, -1.453152027f), t, 1.421413741f), t, -0.284496736f), t, 0.254829592f) * t;
+  return 1.0f - poly * e;
+}
 __device__ __forceinline__ float act_fwd(int act, float x) {
   switch (act) {
-    case PH_ACT_QUICKGELU: return x / (1.0f + __expf(-1.702f * x));
+    case PH_ACT_QUICKGELU: return x * fast_sigmoid(1.702f * x);
     case PH_ACT_RELU2: { float r = fmaxf(x, 0.0f); return r * r; }
-    case PH_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    case PH_ACT_GELU: {
+      float u = x * 0.70710678118654752f;
+      float er = erf_abs_from_exp(fabsf(u), __expf(-u * u));
+      return 0.5f * x * (1.0f + copysignf(er, x));
+    }
     case PH_ACT_RELU: return fmaxf(x, 0.0f);
     default: return x;
   }
@@ -75,13 +90,15 @@ __device__ __forceinline__ float act_fwd(int act, float x) {
 __device__ __forceinline__ float act_grad(int act, float x) {
   switch (act) {
     case PH_ACT_QUICKGELU: {
-      float s = 1.0f / (1.0f + __expf(-1.702f * x));
+      float s = fast_sigmoid(1.702f * x);
       return s * (1.0f + 1.702f * x * (1.0f - s));
     }
     case PH_ACT_RELU2: return 2.0f * fmaxf(x, 0.0f);
     case PH_ACT_GELU: {
-      float c = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-      return c + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+      float u = x * 0.70710678118654752f;
+      float e = __expf(-u * u);                                   // = exp(-x^2 / 2)
+      float c = 0.5f * (1.0f + copysignf(erf_abs_from_exp(fabsf(u), e), x));
+      return c + x * 0.3989422804014327f * e;
     }
     case PH_ACT_RELU: return x > 0.0f ? 1.0f : 0.0f;
     default: return 1.0f;

@@ -311,6 +311,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int wm = wave >> 1, wn = wave & 1;
+#ifdef PH_GEMM_STAGGER   // experiment: put the two co-resident blocks of a CU in anti-phase (one computes while the other stores)
+  if (nt > 2 * 512 && blockIdx.x < 512 && gridDim.z == 1) {
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_ID.WAVE_ID
+    if (slot & 1) {
+      const long long t0 = __builtin_readcyclecounter();
+      const long long wait = (long long)(kt_end - kt_begin) * PH_GEMM_STAGGER;      // shader clocks per k-tile
+      while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
+  }
+#endif
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -338,6 +348,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   auto compute = [&](int buf) {
     const char* la = smem + buf * STAGE;
     const char* lb = la + A_BYTES;
+#ifdef PH_GEMM_FRAG_PIPE   // experiment: fragments of step kk+1 are requested before the MFMAs of step kk
+    bf16x8 fx[2][TM], fw[2][TN];
+    auto frags = [&](int kk, bf16x8 (&ox)[TM], bf16x8 (&ow)[TN]) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        ox[i] = TA ? frag_ks<BM>(la, wm * WM + i * 32, kk, lane) : frag_kc(la, wm * WM + i * 32, kk, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        ow[j] = TB ? frag_ks<BN>(lb, wn * WN + j * 32, kk, lane) : frag_kc(lb, wn * WN + j * 32, kk, lane);
+    };
+    frags(0, fx[0], fw[0]);
+    static_for(std::make_integer_sequence<int, BK / 16>{}, [&](auto idx) {
+      constexpr int kk = decltype(idx)::value;
+      if constexpr (kk + 1 < BK / 16) frags(kk + 1, fx[(kk + 1) & 1], fw[(kk + 1) & 1]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[kk & 1][j], fx[kk & 1][i], acc[i][j], 0, 0, 0);
+    });
+    return;
+#endif
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
       bf16x8 fx[TM], fw[TN];
@@ -376,6 +408,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     cur ^= 1;
   }
 
+#ifdef PH_GEMM_DIAG_NOEPI   // diagnostics build (tools/build_variant.py): main loop only, nothing written unless a sentinel hits
+  {
+    float chk = 0.f;
+    static_for(std::make_integer_sequence<int, TM * TN>{}, [&](auto idx) {
+      constexpr int i = decltype(idx)::value / TN, j = decltype(idx)::value % TN;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) chk += acc[i][j][e];
+    });
+    if (chk == 123456.789f) reinterpret_cast<float*>(p.C)[threadIdx.x] = chk;
+    return;
+  }
+#endif
   // ---- epilogue --------------------------------------------------------------------------------------------------
   // MFMA leaves lane l with C[m = l&31][n = 8g + 4(l>>5) + e]: 32 different rows per store instruction.  Going straight
   // to HBM from that layout costs one cache-line touch per 16 B; instead the fp32 tile is parked in LDS (re-using the
@@ -414,6 +458,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       f32x4 t1 = *reinterpret_cast<const f32x4*>(cl + ml * BN + (((c + 1) ^ sw) << 2));
       if (m < p.M && n + 8 <= p.N) {
         float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+#ifdef PH_GEMM_DIAG_NOSTORE  // diagnostics build: staging + LDS reads, no HBM traffic from the epilogue
+        if (v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] != 123456.789f) continue;
+#endif
         epilogue_store8(p, m, n, v, drop, dc);
       } else if (m < p.M) {
         float v0[4] = {t0[0], t0[1], t0[2], t0[3]}, v1[4] = {t1[0], t1[1], t1[2], t1[3]};

@@ -95,6 +95,17 @@ def gemm_case(name, M, N, K, layout='nt', **kw):
     ab(f'gemm {name} {layout} {M}x{N}x{K}', lambda: ops.gemm(a, b, out=out, **lk, **args), flops=2.0 * M * N * K)
 
 
+def epi_suite():
+    gemm_case('plain', 8320, 3072, 768)
+    gemm_case('bias', 8320, 3072, 768, bias=True)
+    gemm_case('bias+qgelu', 8320, 3072, 768, bias=True, act=ACT_QUICKGELU)
+    gemm_case('bias+pre', 8320, 3072, 768, bias=True, pre_out=True)
+    gemm_case('bias+qgelu+pre', 8320, 3072, 768, bias=True, act=ACT_QUICKGELU, pre_out=True)
+    gemm_case('res bf16', 8320, 3072, 768, residual='bf16')
+    gemm_case('act_in', 8320, 3072, 768, act=ACT_QUICKGELU, act_in=True)
+    gemm_case('f32 out acc', 8320, 3072, 768, out_f32=True)
+
+
 def gemm_suite():
     gemm_case('plain', 8320, 3072, 768)
     gemm_case('c_fc b+qgelu+pre', 8320, 3072, 768, bias=True, act=ACT_QUICKGELU, pre_out=True)
@@ -165,3 +176,5 @@ if __name__ == '__main__':
         ln_suite()
     if 'gemm' in which:
         gemm_suite()
+    if 'epi' in which:
+        epi_suite()
