@@ -67,6 +67,13 @@ typedef struct {
 } ph_gemm_args;
 int ph_gemm_bf16(const ph_gemm_args* args, hipStream_t stream);
 
+/* Grouped GEMM: n <= PH_GEMM_GROUP_MAX independent problems with the SAME trans_a / trans_b in one launch (no split-K;
+ * split_k / workspace fields are ignored).  Used for the weight gradients, which the reference's autograd emits as one
+ * small GEMM per nn.Linear (dW = dY^T X, e.g. model/modules/roberta.py:79-183 has nine per decoder layer): their outputs
+ * cover 18..144 tiles each, far fewer than the chip holds, so the host side defers them and issues each layer's set at once. */
+#define PH_GEMM_GROUP_MAX 16
+int ph_gemm_grouped_bf16(const ph_gemm_args* args, int n, hipStream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm (fp32 math, eps inside the sqrt).  Replaces model/modules/utils.py:14-19 (F.layer_norm in
  * fp32 + casts) at every call site: vit.py:50-59,130-131,169-171; resampler.py:26-36; utils.py:57-64;
@@ -220,6 +227,9 @@ int ph_cast_f32_to_bf16(const float* x, void* y, int64_t n, hipStream_t stream);
 int ph_cast_bf16_to_f32(const void* x, float* y, int64_t n, hipStream_t stream);
 /* out[n] += sum_m x[m,n]  (bias gradients) */
 int ph_colsum_bf16(const void* x, int M, int N, int ld, float* out, hipStream_t stream);
+/* the same for n <= PH_GEMM_GROUP_MAX tensors in one launch (the bias gradients that go with ph_gemm_grouped_bf16) */
+typedef struct { const void* x; float* out; int M, N, ld; } ph_colsum_item;
+int ph_colsum_grouped_bf16(const ph_colsum_item* items, int n, hipStream_t stream);
 /* dx = dy * act'(pre)  (bf16, n elements): backward through an activation that is not fused into a GEMM
  * (LM head: dense -> gelu -> LayerNorm, roberta.py:421-425) */
 int ph_act_bwd_bf16(const void* dy, const void* pre, void* dx, int64_t n, int act, hipStream_t stream);

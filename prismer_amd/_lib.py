@@ -39,6 +39,13 @@ class GemmArgs(C.Structure):
                 ('residual_f32', c_int), ('workspace', c_void_p), ('workspace_bytes', c_i64)]
 
 
+class ColsumItem(C.Structure):
+    _fields_ = [('x', c_void_p), ('out', c_void_p), ('M', c_int), ('N', c_int), ('ld', c_int)]
+
+
+GEMM_GROUP_MAX = 16      # PH_GEMM_GROUP_MAX
+
+
 class LayerNormFwdArgs(C.Structure):
     _fields_ = [('x', c_void_p), ('gamma', c_void_p), ('beta', c_void_p),
                 ('y', c_void_p), ('y_map', RowMap), ('y2', c_void_p), ('y2_map', RowMap),
@@ -116,6 +123,8 @@ _SIGS = {
     'ph_cast_f32_to_bf16': (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     'ph_cast_bf16_to_f32': (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     'ph_colsum_bf16': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'ph_colsum_grouped_bf16': (c_int, [c_void_p, c_int, c_void_p]),
+    'ph_gemm_grouped_bf16': (c_int, [c_void_p, c_int, c_void_p]),
     'ph_add_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     'ph_act_bwd_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     'ph_copy_rows_bf16': (c_int, [c_void_p, c_int, RowMap, c_void_p, c_int, RowMap, c_int, c_int, c_int, c_void_p]),

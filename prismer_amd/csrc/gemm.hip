@@ -64,7 +64,9 @@ struct GemmParams {
 
 // ---- global -> register staging ------------------------------------------------------------------------
 // K-contiguous operand: tile = R rows x 64 k. chunk id -> (row = id/8, c = id%8), 16 B each.
-template <int R>
+// KFULL: K is a multiple of BK, so no k predicate -> straight-line loads (the compiler's vmcnt bookkeeping stays exact,
+// which the deep prefetch ring depends on).
+template <int R, bool KFULL = false>
 __device__ __forceinline__ void load_kc(const bf16* __restrict__ base, int ld, int row0, int rows, int k0, int K,
                                         u32x4 (&regs)[R * 8 / 256]) {
 #pragma unroll
@@ -74,9 +76,13 @@ __device__ __forceinline__ void load_kc(const bf16* __restrict__ base, int ld, i
     int row = row0 + r;
     row = row < rows ? row : rows - 1;          // clamp: out-of-range rows only feed out-of-range outputs
     int k = k0 + c * 8;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (k < K) v = *reinterpret_cast<const u32x4*>(base + (size_t)row * ld + k);
-    regs[i] = v;
+    if (KFULL) {
+      regs[i] = *reinterpret_cast<const u32x4*>(base + (size_t)row * ld + k);
+    } else {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (k < K) v = *reinterpret_cast<const u32x4*>(base + (size_t)row * ld + k);
+      regs[i] = v;
+    }
   }
 }
 template <int R>
@@ -90,7 +96,7 @@ __device__ __forceinline__ void store_kc(char* lds, const u32x4 (&regs)[R * 8 / 
   }
 }
 // K-strided operand: memory [K][rows] (rows contiguous). tile = 64 k-rows x R. chunk id -> (kr = id/(R/8), c = id%(R/8)).
-template <int R>
+template <int R, bool KFULL = false>
 __device__ __forceinline__ void load_ks(const bf16* __restrict__ base, int ld, int row0, int rows, int k0, int K,
                                         u32x4 (&regs)[R * 8 / 256]) {
   constexpr int CPR = R / 8;
@@ -100,9 +106,14 @@ __device__ __forceinline__ void load_ks(const bf16* __restrict__ base, int ld, i
     int kr = id / CPR, c = id % CPR;
     int k = k0 + kr;
     int r = row0 + c * 8;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (k < K && r < rows) v = *reinterpret_cast<const u32x4*>(base + (size_t)k * ld + r);
-    regs[i] = v;
+    if (KFULL) {                                 // chunks beyond `rows` re-read the last chunk (they only feed out-of-range outputs)
+      r = r < rows ? r : ((rows - 1) & ~7);
+      regs[i] = *reinterpret_cast<const u32x4*>(base + (size_t)k * ld + r);
+    } else {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (k < K && r < rows) v = *reinterpret_cast<const u32x4*>(base + (size_t)k * ld + r);
+      regs[i] = v;
+    }
   }
 }
 template <int R>
@@ -279,7 +290,7 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int m, int 
 }
 
 template <int BM, int BN, bool TA, bool TB, int PF>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+__device__ __forceinline__ void gemm_body(const GemmParams& p, const int block_id, const int split_id, const int nsplits) {
   constexpr int WM = BM / 2, WN = BN / 2;   // wave tile
   constexpr int TM = WM / 32, TN = WN / 32; // 32x32 MFMA tiles per wave
   constexpr int A_BYTES = TA ? TileBytes<BM>::ks : TileBytes<BM>::kc;
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 
   // XCD-aware tile mapping: hardware places block b on XCD b % 8; give each XCD a contiguous run of tiles.
   int nt = p.tiles_m * p.tiles_n;
-  int bid = blockIdx.x;
+  int bid = block_id;
   {
     int q = nt / 8, r = nt % 8, xcd = bid % 8, idx = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const int rin = bid % group_sz;
   int tm = first_m + rin % gm, tn = rin / gm;
   int m0 = tm * BM, n0 = tn * BN;
-  int kt_begin = blockIdx.z * p.k_tiles_per_split;
+  int kt_begin = split_id * p.k_tiles_per_split;
   int kt_total = (p.K + BK - 1) / BK;
   int kt_end = min(kt_begin + p.k_tiles_per_split, kt_total);
   if (kt_begin >= kt_end) return;
@@ -312,7 +323,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int wm = wave >> 1, wn = wave & 1;
 #ifdef PH_GEMM_STAGGER   // experiment: put the two co-resident blocks of a CU in anti-phase (one computes while the other stores)
-  if (nt > 2 * 512 && blockIdx.x < 512 && gridDim.z == 1) {
+  if (nt > 2 * 512 && block_id < 512 && nsplits == 1) {
     const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_ID.WAVE_ID
     if (slot & 1) {
       const long long t0 = __builtin_readcyclecounter();
@@ -336,8 +347,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   u32x4 ra[D][BM * 8 / 256], rb[D][BN * 8 / 256];
   auto gload = [&](int kt, u32x4 (&xa)[BM * 8 / 256], u32x4 (&xb)[BN * 8 / 256]) {
     int k0 = kt * BK;
-    if (TA) load_ks<BM>(p.A, p.lda, m0, p.M, k0, p.K, xa); else load_kc<BM>(p.A, p.lda, m0, p.M, k0, p.K, xa);
-    if (TB) load_ks<BN>(p.B, p.ldb, n0, p.N, k0, p.K, xb); else load_kc<BN>(p.B, p.ldb, n0, p.N, k0, p.K, xb);
+    constexpr bool KF = PF > 1;                 // ring kernels are only launched when K % BK == 0
+    if (TA) load_ks<BM, KF>(p.A, p.lda, m0, p.M, k0, p.K, xa); else load_kc<BM, KF>(p.A, p.lda, m0, p.M, k0, p.K, xa);
+    if (TB) load_ks<BN, KF>(p.B, p.ldb, n0, p.N, k0, p.K, xb); else load_kc<BN, KF>(p.B, p.ldb, n0, p.N, k0, p.K, xb);
   };
   auto lstore = [&](int buf, const u32x4 (&xa)[BM * 8 / 256], const u32x4 (&xb)[BN * 8 / 256]) {
     char* sa = smem + buf * STAGE;
@@ -394,18 +406,50 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   //     barrier
   // i.e. two tiles of look-ahead with one register set and two LDS buffers; the LDS write pass sits BEFORE this wave's
   // MFMAs, where it overlaps the co-resident block's matrix work instead of trailing its own.
-  static_assert(D == 1, "ring depth > 1 is not used by this schedule");
-  gload(kt_begin, ra[0], rb[0]);
-  lstore(0, ra[0], rb[0]);
-  if (kt_begin + 1 < kt_end) gload(kt_begin + 1, ra[0], rb[0]);
-  __syncthreads();
-  int cur = 0;
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    if (kt + 1 < kt_end) lstore(cur ^ 1, ra[0], rb[0]);
-    if (kt + 2 < kt_end) gload(kt + 2, ra[0], rb[0]);
-    compute(cur);
+  if constexpr (D == 1) {
+    gload(kt_begin, ra[0], rb[0]);
+    lstore(0, ra[0], rb[0]);
+    if (kt_begin + 1 < kt_end) gload(kt_begin + 1, ra[0], rb[0]);
     __syncthreads();
-    cur ^= 1;
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      if (kt + 1 < kt_end) lstore(cur ^ 1, ra[0], rb[0]);
+      if (kt + 2 < kt_end) gload(kt + 2, ra[0], rb[0]);
+      compute(cur);
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    // Ring of D register sets: the loads of tile i+1+D are issued in iteration i and written to LDS in iteration i+D, so a
+    // load has D iterations to land (one is not enough when a CU holds a single block, i.e. every GEMM with few tiles).
+    // Loads are unconditional (tile index clamped to the last one) and slots are compile-time constants.
+    const int nk = kt_end - kt_begin;
+    auto gl = [&](int i, u32x4 (&xa)[BM * 8 / 256], u32x4 (&xb)[BN * 8 / 256]) { gload(kt_begin + min(i, nk - 1), xa, xb); };
+    static_for(std::make_integer_sequence<int, D>{}, [&](auto dd) { gl(decltype(dd)::value, ra[decltype(dd)::value], rb[decltype(dd)::value]); });
+    lstore(0, ra[0], rb[0]);
+    gl(D, ra[0], rb[0]);
+    __syncthreads();
+    int cur = 0;
+    int i0 = 0;
+    for (; i0 + D <= nk; i0 += D) {             // full groups: no predicate anywhere (the store after the last tile lands in the
+      static_for(std::make_integer_sequence<int, D>{}, [&](auto dd) {      // idle buffer and is never read)
+        constexpr int d = decltype(dd)::value, slot = (d + 1) % D;
+        lstore(cur ^ 1, ra[slot], rb[slot]);
+        gl(i0 + d + 1 + D, ra[slot], rb[slot]);
+        compute(cur);
+        __syncthreads();
+        cur ^= 1;
+      });
+    }
+    static_for(std::make_integer_sequence<int, D - 1>{}, [&](auto dd) {    // remainder: nk % D tiles
+      constexpr int d = decltype(dd)::value, slot = (d + 1) % D;
+      if (i0 + d < nk) {
+        lstore(cur ^ 1, ra[slot], rb[slot]);
+        compute(cur);
+        __syncthreads();
+        cur ^= 1;
+      }
+    });
   }
 
 #ifdef PH_GEMM_DIAG_NOEPI   // diagnostics build (tools/build_variant.py): main loop only, nothing written unless a sentinel hits
@@ -425,7 +469,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   // to HBM from that layout costs one cache-line touch per 16 B; instead the fp32 tile is parked in LDS (re-using the
   // stage buffers, 16-B chunks XOR-swizzled by the row so both sides are conflict-free) and re-read row-wise: 32
   // consecutive lanes then own 256 contiguous bytes of one output row for every load/store of the fused epilogue.
-  const bool splitk = gridDim.z > 1;
+  const bool splitk = nsplits > 1;
   DropCtx dc;
   const bool drop = p.drop_p > 0.0f;
   if (drop) dc = make_drop(p.drop_seed, p.drop_stream, p.drop_p);
@@ -481,6 +525,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   }
 }
 
+template <int BM, int BN, bool TA, bool TB, int PF>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+  gemm_body<BM, BN, TA, TB, PF>(p, blockIdx.x, blockIdx.z, gridDim.z);
+}
+
+// Grouped launch: up to PH_GEMM_GROUP_MAX independent problems of one layout in ONE grid (block -> (problem, tile) through a
+// prefix table in the kernel arguments).  The deferred weight-gradient GEMMs of a layer (outputs of 18..144 tiles each, far
+// below the 512 block slots of the chip) are issued this way instead of one under-filled launch + split-K reduce apiece.
+struct GroupParams {
+  int n;
+  int tile_start[PH_GEMM_GROUP_MAX + 1];
+  GemmParams p[PH_GEMM_GROUP_MAX];
+};
+template <int BM, int BN, bool TA, bool TB, int PF>
+__global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupParams g) {
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.tile_start[i + 1]) ++i;
+  gemm_body<BM, BN, TA, TB, PF>(g.p[i], (int)blockIdx.x - g.tile_start[i], 0, 1);
+}
+
 // folds the split-K partials and applies the fused epilogue (bias / activation / dropout / residual / accumulate / dtype)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int splits) {
   const int n4 = (p.N + 3) / 4;
@@ -498,24 +562,40 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
 }
 
 // prefetch depth per tile size (VGPR budget: 128x128 tiles hold 32 staging VGPRs per slot, 64x64 tiles 16)
-#define PF_DEPTH(bm) 1
+// A/B on MI355X (tools/ab_probe.py, graph replay): depth 2 on 128x128 tiles +2..10 % on the NT / NN layouts (TN: -4 %, kept
+// at 1); depth 3 on 64x64 tiles +7..11 % on the one-block-per-CU decoder GEMMs; split-K launches keep depth 1.
+#ifndef PH_RING128
+#define PH_RING128 2
+#endif
+#ifndef PH_RING64
+#define PH_RING64 3
+#endif
+#define PF_DEPTH(bm) ((bm) == 128 ? PH_RING128 : PH_RING64)
 
-template <int BM, int BN, bool TA, bool TB>
-int launch(const GemmParams& p, int splits, hipStream_t s) {
+template <int BM, int BN, bool TA, bool TB, int PF>
+int launch_pf(const GemmParams& p, int splits, hipStream_t s) {
   constexpr int smem_min = 2 * ((TA ? TileBytes<BM>::ks : TileBytes<BM>::kc) + (TB ? TileBytes<BN>::ks : TileBytes<BN>::kc));
   static int extra = -1;            // PH_GEMM_EXTRA_LDS=<bytes>: occupancy experiments only (pads the dynamic LDS request)
   if (extra < 0) { const char* e = getenv("PH_GEMM_EXTRA_LDS"); extra = e ? atoi(e) : 0; }
   const int smem = smem_min + extra;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, TA, TB, PF_DEPTH(BM)>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, TA, TB, PF>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, TA, TB, PF_DEPTH(BM)>), grid, dim3(256), smem, s, p);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, TA, TB, PF>), grid, dim3(256), smem, s, p);
   PH_LAUNCH_CHECK("gemm_kernel");
   return PH_OK;
+}
+
+template <int BM, int BN, bool TA, bool TB>
+int launch(const GemmParams& p, int splits, hipStream_t s) {
+  if constexpr (PF_DEPTH(BM) > 1 && !(BM == 128 && TA)) {
+    if (p.K % BK == 0 && splits == 1) return launch_pf<BM, BN, TA, TB, PF_DEPTH(BM)>(p, splits, s);   // the ring needs unpredicated k loads
+  }
+  return launch_pf<BM, BN, TA, TB, 1>(p, splits, s);
 }
 
 template <int BM, int BN>
@@ -528,11 +608,9 @@ int dispatch_layout(const GemmParams& p, int ta, int tb, int splits, hipStream_t
 
 }  // namespace
 
-extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
+// argument validation + kernel parameter block shared by the single and the grouped entry point
+static int fill_params(const ph_gemm_args* a, GemmParams& p) {
   PH_CHECK_ARG(a && a->A && a->B && a->C, "ph_gemm_bf16: null pointer");
-  char desc__[96];
-  if (g_ph_prof_enabled) snprintf(desc__, sizeof(desc__), "gemm M=%d N=%d K=%d ta=%d tb=%d f32=%d acc=%d", a->M, a->N, a->K, a->trans_a, a->trans_b, a->out_f32, a->accumulate);
-  ProfScope prof__(PH_FAM_GEMM, 2.0 * a->M * (double)a->N * a->K, 2.0 * ((double)a->M * a->K + (double)a->N * a->K + (double)a->M * a->N), stream, desc__);
   PH_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "ph_gemm_bf16: bad dims M=%d N=%d K=%d", a->M, a->N, a->K);
   PH_CHECK_ARG((a->lda % 8) == 0 && (a->ldb % 8) == 0, "ph_gemm_bf16: lda/ldb must be multiples of 8 (16-B rows)");
   PH_CHECK_ARG((((uintptr_t)a->A | (uintptr_t)a->B) & 15) == 0, "ph_gemm_bf16: A/B must be 16-B aligned");
@@ -541,14 +619,85 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
                "ph_gemm_bf16: leading dimension too small");
   PH_CHECK_ARG(!(a->drop_p > 0.0f) || ((a->N % 4) == 0 && a->drop_seed), "ph_gemm_bf16: dropout needs N %% 4 == 0 and a seed");
   PH_CHECK_ARG(a->drop_p >= 0.0f && a->drop_p < 1.0f, "ph_gemm_bf16: bad dropout p");
-
-  GemmParams p;
   p.A = (const bf16*)a->A; p.B = (const bf16*)a->B; p.C = a->C;
   p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc;
   p.bias = a->bias; p.pre_out = (bf16*)a->pre_out; p.act_in = (const bf16*)a->act_in; p.ld_act = a->ld_act;
   p.residual = (const bf16*)a->residual; p.ldr = a->ldr; p.res_f32 = a->residual_f32;
   p.drop_p = a->drop_p; p.drop_seed = a->drop_seed; p.drop_stream = a->drop_stream;
   p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.alpha = a->alpha;
+  p.ws = nullptr; p.ldws = (a->N + 3) / 4 * 4;
+  return PH_OK;
+}
+
+template <int BM, bool TA, bool TB, int PF>
+static int launch_grouped(const GroupParams& g, int total, hipStream_t s) {
+  constexpr int smem = 2 * ((TA ? TileBytes<BM>::ks : TileBytes<BM>::kc) + (TB ? TileBytes<BM>::ks : TileBytes<BM>::kc));
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<BM, BM, TA, TB, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_grouped_kernel<BM, BM, TA, TB, PF>), dim3(total), dim3(256), smem, s, g);
+  PH_LAUNCH_CHECK("gemm_grouped_kernel");
+  return PH_OK;
+}
+template <int BM, int PF>
+static int launch_grouped_layout(const GroupParams& g, int total, int ta, int tb, hipStream_t s) {
+  if (!ta && !tb) return launch_grouped<BM, false, false, PF>(g, total, s);
+  if (!ta && tb) return launch_grouped<BM, false, true, PF>(g, total, s);
+  if (ta && tb) return launch_grouped<BM, true, true, PF>(g, total, s);
+  return launch_grouped<BM, true, false, PF>(g, total, s);
+}
+
+extern "C" int ph_gemm_grouped_bf16(const ph_gemm_args* args, int n, hipStream_t stream) {
+  PH_CHECK_ARG(args && n >= 1 && n <= PH_GEMM_GROUP_MAX, "ph_gemm_grouped_bf16: need 1..%d problems, got %d", PH_GEMM_GROUP_MAX, n);
+  double flops = 0.0, bytes = 0.0;
+  int64_t t128 = 0;
+  bool kfull = true;
+  for (int i = 0; i < n; ++i) {
+    PH_CHECK_ARG(args[i].trans_a == args[0].trans_a && args[i].trans_b == args[0].trans_b, "ph_gemm_grouped_bf16: mixed layouts in one group");
+    flops += 2.0 * args[i].M * (double)args[i].N * args[i].K;
+    bytes += 2.0 * ((double)args[i].M * args[i].K + (double)args[i].N * args[i].K + (double)args[i].M * args[i].N);
+    t128 += (int64_t)ceil_div(args[i].M, 128) * ceil_div(args[i].N, 128);
+    kfull = kfull && (args[i].K % BK) == 0;
+    if (args[i].M <= 64 || args[i].N <= 64) t128 = -(1 << 30);          // thin outputs: 64x64 tiles
+  }
+  char desc__[96];
+  if (g_ph_prof_enabled) snprintf(desc__, sizeof(desc__), "gemm grouped n=%d ta=%d tb=%d K0=%d", n, args[0].trans_a, args[0].trans_b, args[0].K);
+  ProfScope prof__(PH_FAM_GEMM, flops, bytes, stream, desc__);
+  // 128x128 tiles once they fill the chip (2 blocks per CU = 512 slots), else 64x64 (4 per CU)
+  const int BMsel = t128 >= 384 ? 128 : 64;
+  GroupParams g;                             // ~2.3 KB: copied into the kernel arguments by the launch
+  g.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    int rc = fill_params(&args[i], g.p[i]);
+    if (rc) return rc;
+    g.p[i].tiles_m = ceil_div(args[i].M, BMsel); g.p[i].tiles_n = ceil_div(args[i].N, BMsel);
+    g.p[i].k_tiles_per_split = ceil_div(args[i].K, BK);
+    g.tile_start[i] = total;
+    total += g.p[i].tiles_m * g.p[i].tiles_n;
+  }
+  g.tile_start[n] = total;
+  const int ta = args[0].trans_a, tb = args[0].trans_b;
+  if (BMsel == 128) {
+    if (kfull && PH_RING128 > 1 && !ta) return launch_grouped_layout<128, PH_RING128>(g, total, ta, tb, stream);
+    return launch_grouped_layout<128, 1>(g, total, ta, tb, stream);
+  }
+  if (kfull && PH_RING64 > 1) return launch_grouped_layout<64, PH_RING64>(g, total, ta, tb, stream);
+  return launch_grouped_layout<64, 1>(g, total, ta, tb, stream);
+}
+
+extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
+  PH_CHECK_ARG(a && a->A && a->B && a->C, "ph_gemm_bf16: null pointer");
+  char desc__[96];
+  if (g_ph_prof_enabled) snprintf(desc__, sizeof(desc__), "gemm M=%d N=%d K=%d ta=%d tb=%d f32=%d acc=%d", a->M, a->N, a->K, a->trans_a, a->trans_b, a->out_f32, a->accumulate);
+  ProfScope prof__(PH_FAM_GEMM, 2.0 * a->M * (double)a->N * a->K, 2.0 * ((double)a->M * a->K + (double)a->N * a->K + (double)a->M * a->N), stream, desc__);
+  GemmParams p;
+  {
+    int rc = fill_params(a, p);
+    if (rc) return rc;
+  }
 
   // ---- tile shape and split-K selection -------------------------------------------------------------------------
   // 128x128 tiles when they fill the chip; otherwise split the K loop (partials -> workspace -> reduce+epilogue) so

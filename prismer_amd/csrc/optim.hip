@@ -228,6 +228,71 @@ extern "C" int ph_cast_bf16_to_f32(const void* x, float* y, int64_t n, hipStream
   PH_LAUNCH_CHECK("cast_b2f_kernel");
   return PH_OK;
 }
+namespace {
+struct ColsumGroup {
+  int n;
+  int blk_start[PH_GEMM_GROUP_MAX + 1];
+  struct Item { const bf16* x; float* out; int M, N, ld, ncb; } it[PH_GEMM_GROUP_MAX];
+};
+// several bias-gradient column sums in one grid (block -> (problem, column block, row strip))
+__global__ __launch_bounds__(256) void colsum_grouped_kernel(ColsumGroup g) {
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.blk_start[i + 1]) ++i;
+  const ColsumGroup::Item& t = g.it[i];
+  const int lid = (int)blockIdx.x - g.blk_start[i];
+  const int strips = (g.blk_start[i + 1] - g.blk_start[i]) / t.ncb;
+  const int cb = lid % t.ncb, strip = lid / t.ncb;
+  __shared__ float red[8][256];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c0 = cb * 256 + cl * 8;
+  const int rows_per = (t.M + strips - 1) / strips;
+  const int r0 = strip * rows_per, r1 = min(t.M, r0 + rows_per);
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (c0 + 8 <= t.N) {
+    for (int r = r0 + rl; r < r1; r += 8) {
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(t.x + (int64_t)r * t.ld + c0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+    }
+  } else if (c0 < t.N) {
+    for (int r = r0 + rl; r < r1; r += 8)
+      for (int e = 0; e < 8 && c0 + e < t.N; ++e) acc[e] += bf2f(t.x[(int64_t)r * t.ld + c0 + e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][cl * 8 + e] = acc[e];
+  __syncthreads();
+  int col = cb * 256 + threadIdx.x;
+  if (col < t.N) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][threadIdx.x];
+    atomicAdd(t.out + col, s);
+  }
+}
+}  // namespace
+
+extern "C" int ph_colsum_grouped_bf16(const ph_colsum_item* items, int n, hipStream_t stream) {
+  PH_CHECK_ARG(items && n >= 1 && n <= PH_GEMM_GROUP_MAX, "ph_colsum_grouped_bf16: need 1..%d items, got %d", PH_GEMM_GROUP_MAX, n);
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_colsum_grouped_bf16");
+  ColsumGroup g;
+  g.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    const ph_colsum_item& a = items[i];
+    PH_CHECK_ARG(a.x && a.out && a.M > 0 && a.N > 0 && a.ld % 8 == 0 && (((uintptr_t)a.x) & 15) == 0, "ph_colsum_grouped_bf16: bad item %d", i);
+    int strips = std::max(1, std::min(64, a.M / 64));
+    g.it[i].x = (const bf16*)a.x; g.it[i].out = a.out; g.it[i].M = a.M; g.it[i].N = a.N; g.it[i].ld = a.ld; g.it[i].ncb = ceil_div(a.N, 256);
+    g.blk_start[i] = total;
+    total += g.it[i].ncb * strips;
+  }
+  g.blk_start[n] = total;
+  hipLaunchKernelGGL(colsum_grouped_kernel, dim3(total), dim3(256), 0, stream, g);
+  PH_LAUNCH_CHECK("colsum_grouped_kernel");
+  return PH_OK;
+}
+
 extern "C" int ph_colsum_bf16(const void* x, int M, int N, int ld, float* out, hipStream_t stream) {
   PH_CHECK_ARG(x && out && M > 0 && N > 0 && ld % 8 == 0 && (((uintptr_t)x) & 15) == 0, "ph_colsum_bf16: bad args");
   ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_colsum_bf16");

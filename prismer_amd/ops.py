@@ -65,6 +65,11 @@ class SideStream:
         self.dirty = True
         return out
 
+    def wait(self):
+        """current stream waits for everything queued on the side stream so far; keeps the tensor references (used inside
+        micro-batch branches, where another branch's side work may still be pending)."""
+        torch.cuda.current_stream().wait_stream(self.stream)
+
     def join(self):
         if self.dirty:
             torch.cuda.current_stream().wait_stream(self.stream)
@@ -106,6 +111,7 @@ class _NoPool:
 
 
 POOL = _NoPool()     # set by the Trainer (native path)
+MICRO = _NoPool()    # set by the Trainer: one stream per micro-batch (independent halves of the batch as parallel branches)
 SIDE = None          # set by the Trainer (native path); None = everything on the current stream
 
 
@@ -116,9 +122,84 @@ def off_critical_path(fn, *tensors):
     return SIDE.run(fn, *tensors)
 
 
+class WgradQueue:
+    """Deferred weight gradients.  Nothing inside a step reads dW / db before the optimizer, so the wgrad GEMMs
+    (dW += dY^T X: outputs of 18..144 tiles, alone they fill a fraction of the chip and need split-K + a reduce pass) and
+    the bias column sums are queued and issued per reduction length K as ONE grouped launch each
+    (ph_gemm_grouped_bf16 / ph_colsum_grouped_bf16).  join_side() flushes, so every existing synchronisation point of the
+    programs still sees complete gradients.  Operand tensors stay referenced until their launch."""
+
+    def __init__(self):
+        self.enabled = True
+        self.gemms = {}          # K -> [(dy, x, gw, M, N, K)]
+        self.cols = []           # [(dy, gb, M, N)]
+
+    def add_gemm(self, dy, x, gw, M, N, K):
+        """gw[M, N] (fp32) += dy[K, M]^T . x[K, N]"""
+        if not self.enabled:
+            gemm(dy, x, out=gw, trans_a=True, trans_b=True, out_f32=True, accumulate=True, M=M, N=N, K=K)
+            return
+        q = self.gemms.setdefault(K, [])
+        if any(e[2].data_ptr() == gw.data_ptr() for e in q):      # two read-modify-writes of one output never share a launch
+            self._flush_gemms(K)
+            q = self.gemms.setdefault(K, [])
+        q.append((dy, x, gw, M, N, K))
+        if len(q) == _lib.GEMM_GROUP_MAX:
+            self._flush_gemms(K)
+
+    def add_colsum(self, dy, gb, N):
+        if not self.enabled:
+            colsum(dy, gb, N=N)
+            return
+        self.cols.append((dy, gb, dy.shape[0], N))
+        if len(self.cols) == _lib.GEMM_GROUP_MAX:
+            self._flush_cols()
+
+    def _flush_gemms(self, K):
+        q = self.gemms.pop(K, [])
+        if not q:
+            return
+
+        def work():
+            arr = (_lib.GemmArgs * len(q))()
+            for g, (dy, x, gw, M, N, Kk) in zip(arr, q):
+                g.A, g.B, g.C = dy.data_ptr(), x.data_ptr(), gw.data_ptr()
+                g.M, g.N, g.K = M, N, Kk
+                g.lda, g.ldb, g.ldc = dy.stride(0), x.stride(0), gw.stride(0)
+                g.trans_a, g.trans_b, g.out_f32, g.accumulate, g.alpha = 1, 1, 1, 1, 1.0
+            check(lib.ph_gemm_grouped_bf16(arr, len(q), _stream()), 'ph_gemm_grouped_bf16')
+        off_critical_path(work, *[t for e in q for t in e[:3]])
+
+    def _flush_cols(self):
+        q, self.cols = self.cols, []
+        if not q:
+            return
+
+        def work():
+            arr = (_lib.ColsumItem * len(q))()
+            for it, (dy, gb, M, N) in zip(arr, q):
+                it.x, it.out, it.M, it.N, it.ld = dy.data_ptr(), gb.data_ptr(), M, N, dy.stride(0)
+            check(lib.ph_colsum_grouped_bf16(arr, len(q), _stream()), 'ph_colsum_grouped_bf16')
+        off_critical_path(work, *[t for e in q for t in e[:2]])
+
+    def flush(self):
+        for K in list(self.gemms):
+            self._flush_gemms(K)
+        self._flush_cols()
+
+
+WQ = WgradQueue()
+
+
 def join_side():
+    WQ.flush()
     if SIDE is not None:
         SIDE.join()
+
+
+def wait_side():
+    if SIDE is not None:
+        SIDE.wait()
 
 
 def gemm(a, b, out=None, *, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, pre_out=None, act_in=None,

@@ -56,8 +56,11 @@ class DecoderProgram:
         assert o[n + 'key.weight'] - o[n + 'query.weight'] == H * H and o[n + 'value.weight'] - o[n + 'key.weight'] == H * H
         assert o[n + 'key.bias'] - o[n + 'query.bias'] == H, 'q/k/v biases must be adjacent (H % 64 == 0 required)'
 
+    site_base = 0      # added to every dropout call-site id: the Trainer gives each micro-batch its own Philox streams
+    kv_prefetch = True # pre-issue the cross-attention K/V projections on a branch stream (off inside micro-batch branches)
+
     def drop(self, site, p, seed):
-        return ops.Dropout(p, seed, site) if (seed is not None and p > 0.0) else None
+        return ops.Dropout(p, seed, self.site_base + site) if (seed is not None and p > 0.0) else None
 
     # ---------------------------------------------------------------------------------------- sub-blocks
     def post_ln(self, ln, s):
@@ -193,7 +196,7 @@ class DecoderProgram:
         # the K/V projections of all cross-attention layers depend on `enc` only: issue them up front on a branch stream
         # (12 x [B*S, 2H] GEMMs that overlap the latency-bound decoder chain); each layer waits on its own event.
         kvs, kv_evs = [None] * len(self.layers), [None] * len(self.layers)
-        if isinstance(ops.POOL, ops.BranchPool):
+        if self.kv_prefetch and isinstance(ops.POOL, ops.BranchPool):
             with ops.POOL.branch(0):
                 for i, L in enumerate(self.layers):
                     kvs[i] = L['ca']['kv'].fwd(enc2)
@@ -256,9 +259,16 @@ class DecoderProgram:
             dh = self.adaptor_bwd(L['ad'], blocks.pop(), dh)
             dh = self.cross_attn_bwd(L['ca'], blocks.pop(), dh, sv['enc'], denc, B, T, S)
             dh = self.self_attn_bwd(L['sa'], blocks.pop(), dh, B, T, sv['key_mask'])
-        ops.join_side()      # the tied word-embedding gradient: LM-head wgrad (side stream) must land before the scatter-adds
-        ops.embed_bwd(dh, sv['ids'], P.f(wname), P.f(e + 'position_embeddings.weight'), P.f(e + 'token_type_embeddings.weight'),
-                      P.f(e + 'LayerNorm.weight'), P.f(e + 'LayerNorm.bias'), d.layer_norm_eps, d.pad_token_id, sv['xhat'], sv['erstd'],
-                      sv['dr_e'], P.g(wname), P.g(e + 'position_embeddings.weight'), P.g(e + 'token_type_embeddings.weight'),
-                      P.g(e + 'LayerNorm.weight'), P.g(e + 'LayerNorm.bias'))
-        return ops.cast_to_bf16(denc).view(B, S, d.vision_hidden_size)
+        # The tied word-embedding gradient has two writers, the LM-head wgrad GEMM (read-modify-write tiles) and these
+        # scatter-adds: both live on the side stream, whose order serialises them (also across micro-batches).
+        ops.off_critical_path(lambda: ops.embed_bwd(
+            dh, sv['ids'], P.f(wname), P.f(e + 'position_embeddings.weight'), P.f(e + 'token_type_embeddings.weight'),
+            P.f(e + 'LayerNorm.weight'), P.f(e + 'LayerNorm.bias'), d.layer_norm_eps, d.pad_token_id, sv['xhat'], sv['erstd'],
+            sv['dr_e'], P.g(wname), P.g(e + 'position_embeddings.weight'), P.g(e + 'token_type_embeddings.weight'),
+            P.g(e + 'LayerNorm.weight'), P.g(e + 'LayerNorm.bias')), dh, sv['xhat'], sv['erstd'], sv['ids'])
+        # denc was accumulated on the side stream: its bf16 copy is produced there too.  The result is valid after the
+        # caller's ops.join_side() -- this program never makes its own stream wait for the side stream (under stream capture
+        # a forked stream that re-joins work it forked itself crashes this ROCm's capture_end; only the origin may join).
+        denc_b = torch.empty(B * S, d.vision_hidden_size, dtype=BF16, device=dh.device)
+        ops.off_critical_path(lambda: ops.cast_to_bf16(denc, out=denc_b), denc, denc_b)
+        return denc_b.view(B, S, d.vision_hidden_size)

@@ -49,18 +49,16 @@ class Linear:
         return ops.gemm(dy, self.w, trans_b=True, N=self.cols, K=self.rows, **kw)
 
     def wgrad(self, dy, x):
-        """weight / bias gradients: off the critical path (side stream when the Trainer provides one)"""
+        """weight / bias gradients: deferred into the grouped-launch queue (ops.WgradQueue)"""
         gw = self.P.g2(self.wname, self.rows, self.cols)
         gb = self.P.gvec(self.bname, self.rows) if self.bname else None
         if gw is None and gb is None:
             return
 
-        def work():
-            if gw is not None:
-                ops.gemm(dy, x, out=gw, trans_a=True, trans_b=True, out_f32=True, accumulate=True, M=self.rows, N=self.cols, K=dy.shape[0])
-            if gb is not None:
-                ops.colsum(dy, gb, N=self.rows)
-        ops.off_critical_path(work, dy, x)
+        if gw is not None:
+            ops.WQ.add_gemm(dy, x, gw, self.rows, self.cols, dy.shape[0])
+        if gb is not None:
+            ops.WQ.add_colsum(dy, gb, self.rows)
 
 
 class LN:
@@ -265,12 +263,10 @@ class EncoderProgram:
             if gw is not None:
                 gb = P.gvec(blk['inb'], 3 * W)
 
-                def work(dq=dq, dkv=dkv, s=s, gw=gw, gb=gb):
-                    ops.gemm(dq, s['qin'], out=gw[:W], trans_a=True, trans_b=True, out_f32=True, accumulate=True, M=W, N=W, K=B * L)
-                    ops.gemm(dkv, s['kvin'], out=gw[W:], trans_a=True, trans_b=True, out_f32=True, accumulate=True, M=2 * W, N=W, K=B * KV)
-                    ops.colsum(dq, gb[:W])
-                    ops.colsum(dkv, gb[W:])
-                ops.off_critical_path(work, dq, dkv, s['qin'], s['kvin'])
+                ops.WQ.add_gemm(dq, s['qin'], gw[:W], W, W, B * L)
+                ops.WQ.add_gemm(dkv, s['kvin'], gw[W:], 2 * W, W, B * KV)
+                ops.WQ.add_colsum(dq, gb[:W], W)
+                ops.WQ.add_colsum(dkv, gb[W:], 2 * W)
             dqin = ops.gemm(dq, wq, trans_b=True)
             dkvin = ops.gemm(dkv, wkv, trans_b=True)
             dlat, _ = blk['ln_1'].bwd(dqin, s['lat'], s['m1'], s['r1'], dy2=dkvin, dy2_map=RowMap(L, KV, 0), dskip=dlat1)

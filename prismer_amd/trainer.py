@@ -17,6 +17,7 @@ world size (folded into the AdamW kernel as grad_scale), BatchNorm uses per-rank
 reference).  DDP's per-step buffer broadcast from rank 0 is replaced by rank-local BN running statistics
 (documented deviation).
 """
+import contextlib
 import math
 import os
 import random
@@ -36,7 +37,7 @@ def cosine_lr(it, total, init_lr, min_lr):
 
 class Trainer:
     def __init__(self, model, lr=5e-5, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8, min_lr=0.0, total_steps=1000,
-                 task='caption', use_graph=True, process_group=None, bucket_mb=64, side_stream=True):
+                 task='caption', use_graph=True, process_group=None, bucket_mb=64, side_stream=True, micro_batches=1):
         self.model = model
         self.enc, self.dec = model.expert_encoder, model.text_decoder
         self.init_lr, self.min_lr, self.total_steps = lr, min_lr, total_steps
@@ -68,9 +69,19 @@ class Trainer:
         self.table = torch.zeros(256, dtype=torch.int32, device=dev)
         self.seed = self.dec.dropout_seed()
         self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
+        # Micro-batches (optional, default off): the stems see the whole batch (train-mode BatchNorm statistics), everything
+        # after them is sample-independent, so the batch can be cut into `micro_batches` contiguous slices that run as
+        # parallel branches (one stream each).  Motivation: at bs32 the phase times shrink only ~0.7x when the batch is
+        # halved, i.e. most kernels under-fill the 256 CUs.  Measured on MI355X / ROCm 7.2 (same box, bs32): hipGraph replay
+        # 33.2 ms with 1 slice vs 44.7 ms with 2 (this runtime's graph executor handles wide parallel branches poorly;
+        # eager launches with 2 slices: 38.5 ms, host-bound) -- so the default stays 1.  Weight-gradient accumulation is
+        # race-free either way because every read-modify-write of the gradient buffer lives on the single side stream, and
+        # forked streams never re-join work they forked themselves (capture_end crashes on such diamonds here).
+        self.micro = micro_batches if (side_stream and micro_batches > 1) else 1
         if side_stream:
             ops.SIDE = ops.SideStream(dev)
             ops.POOL = ops.BranchPool(dev, 3)
+            ops.MICRO = ops.BranchPool(dev, self.micro) if self.micro > 1 else ops._NoPool()
         self.loss = None
         if self.world > 1:
             self.broadcast_parameters()
@@ -101,26 +112,61 @@ class Trainer:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
     # ------------------------------------------------------------------------------------------ step pieces
+    def _slices(self, B):
+        n = self.micro if (self.micro > 1 and B >= 2 * self.micro) else 1
+        cuts = [B * i // n for i in range(n + 1)]
+        return [(cuts[i], cuts[i + 1]) for i in range(n)]
+
     def _seg_forward_dec_backward(self, s):
         for st in self.stores:
             st.grad.zero_()                                    # optimizer.zero_grad()
-        enc_out, self.sv_e = self.enc_prog.forward(s['experts'], self.table, True, True)
-        logits, loss, self.sv_d = self.dec_prog.forward(s['input_ids'], s['attention_mask'], enc_out, s['labels'], self.seed, True)
-        B = loss.shape[0]
-        if s.get('weights') is not None:                       # VQA: (weights * loss).mean()  (prismer_vqa.py:40-41)
-            dloss = s['weights'].to(F32) / B
-            self.loss_buf = (loss * s['weights']).sum() / B
-        else:                                                  # caption: loss.mean()          (prismer_caption.py:33)
-            dloss = torch.full((B,), 1.0 / B, dtype=F32, device=loss.device)
-            self.loss_buf = loss.sum() / B
-        self.denc = self.dec_prog.backward(self.sv_d, dloss)
+        ep, dp = self.enc_prog, self.dec_prog
+        d = ep.d
+        S, Mx = d.seq_len, d.num_expert_tokens
+        h, xf, self.sv_f = ep.forward_front(s['experts'], self.table, True, True)
+        B = s['input_ids'].shape[0]
+        parts = self._slices(B)
+        self.sv_t, self.denc, losses = [None] * len(parts), [None] * len(parts), [None] * len(parts)
+        dp.kv_prefetch = len(parts) == 1
+        for mi, (b0, b1) in enumerate(parts):
+            with (ops.MICRO.branch(mi) if len(parts) > 1 else contextlib.nullcontext()):
+                Bh = b1 - b0
+                enc_out, self.sv_t[mi] = ep.forward_trunk(h[b0 * S:b1 * S], None if xf is None else xf[b0 * Mx:b1 * Mx], Bh, True)
+                dp.site_base = mi << 20
+                _, loss, sv_d = dp.forward(s['input_ids'][b0:b1], s['attention_mask'][b0:b1], enc_out, s['labels'][b0:b1], self.seed, True)
+                if s.get('weights') is not None:               # VQA: (weights * loss).mean()  (prismer_vqa.py:40-41)
+                    w = s['weights'][b0:b1].to(F32)
+                    dloss, losses[mi] = w / B, (loss * w).sum()
+                else:                                          # caption: loss.mean()          (prismer_caption.py:33)
+                    dloss, losses[mi] = torch.full((Bh,), 1.0 / B, dtype=F32, device=loss.device), loss.sum()
+                self.denc[mi] = dp.backward(sv_d, dloss)       # (valid after the join_side below)
+                del sv_d
+        dp.site_base = 0
+        if len(parts) > 1:
+            ops.MICRO.join()
         ops.join_side()
-        self.sv_d = None
+        self.loss_buf = torch.stack(losses).sum() / B
 
     def _seg_enc_backward(self):
-        self.enc_prog.backward(self.sv_e, self.denc)
+        ep = self.enc_prog
+        d = ep.d
+        S, Mx = d.seq_len, d.num_expert_tokens
+        parts = [(sv['B']) for sv in self.sv_t]
+        B = sum(parts)
+        dev = self.denc[0].device
+        dh = torch.empty(B * S, d.width, dtype=BF16, device=dev)
+        dxf = torch.empty(B * Mx, d.width, dtype=BF16, device=dev) if self.sv_t[0]['has_x'] else None
+        b0 = 0
+        for mi, Bh in enumerate(parts):
+            b1 = b0 + Bh
+            with (ops.MICRO.branch(mi) if len(parts) > 1 else contextlib.nullcontext()):
+                ep.backward_trunk(self.sv_t[mi], self.denc[mi], dh[b0 * S:b1 * S], None if dxf is None else dxf[b0 * Mx:b1 * Mx])
+            b0 = b1
+        if len(parts) > 1:
+            ops.MICRO.join()
+        ep.backward_front(self.sv_f, dh, dxf)
         ops.join_side()
-        self.sv_e = None
+        self.sv_t = self.sv_f = self.denc = None
 
     def _seg_optimizer(self):
         for st, m, v in zip(self.stores, self.m, self.v):

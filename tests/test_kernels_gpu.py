@@ -127,6 +127,42 @@ def test_gemm_f32_accumulate_splitk(ops):
     assert rel_fro(cb, cb0.float() + 0.5 * ref) < 6e-3
 
 
+@pytest.mark.parametrize('shapes', [
+    [(768, 768, 960), (2304, 768, 960), (384, 768, 960), (768, 3072, 960), (3072, 768, 960)],      # one decoder layer: 128x128 tiles
+    [(384, 768, 1984), (768, 384, 1984), (100, 200, 1984)],                                        # few tiles: 64x64 path, ragged edge
+    [(64, 72, 130)],                                                                               # K tail (K % 64 != 0)
+])
+def test_wgrad_queue_grouped_launch(ops, shapes):
+    """deferred weight gradients: ph_gemm_grouped_bf16 / ph_colsum_grouped_bf16 == the one-by-one launches."""
+    probs = []
+    for i, (M, N, K) in enumerate(shapes):
+        Mp, Np = (M + 7) // 8 * 8, (N + 7) // 8 * 8
+        dy = torch.zeros(K, Mp, dtype=BF, device='cuda'); dy[:, :M] = rnd(K, M, scale=0.3, seed=100 + i)
+        x = torch.zeros(K, Np, dtype=BF, device='cuda'); x[:, :N] = rnd(K, N, scale=0.3, seed=200 + i)
+        gw0 = torch.randn(M, N, device='cuda')
+        gb0 = torch.randn(M, device='cuda')
+        probs.append((dy, x, gw0, gb0, M, N, K))
+    q = ops.WgradQueue()
+    outs = []
+    for dy, x, gw0, gb0, M, N, K in probs:
+        gw, gb = gw0.clone(), gb0.clone()
+        q.add_gemm(dy, x, gw, M, N, K)
+        q.add_colsum(dy, gb, M)
+        outs.append((gw, gb))
+    assert any(q.gemms.values()) and q.cols, 'nothing was deferred'
+    q.flush()
+    torch.cuda.synchronize()
+    for (dy, x, gw0, gb0, M, N, K), (gw, gb) in zip(probs, outs):
+        ref = dy[:, :M].float().t() @ x[:, :N].float()
+        assert rel_fro(gw - gw0, ref) < 3e-4, (M, N, K, rel_fro(gw - gw0, ref))
+        assert rel_fro(gb - gb0, dy[:, :M].float().sum(0)) < 1e-4
+    # a second read-modify-write of the same output must not share a launch with the first
+    dy, x, gw0, gb0, M, N, K = probs[0]
+    gw = gw0.clone()
+    q.add_gemm(dy, x, gw, M, N, K); q.add_gemm(dy, x, gw, M, N, K); q.flush()
+    assert rel_fro(gw - gw0, 2 * (dy[:, :M].float().t() @ x[:, :N].float())) < 3e-4
+
+
 def test_gemm_dropout_mask(ops):
     M, N, K = 96, 128, 64
     a = torch.eye(M, K, dtype=BF, device='cuda')                    # out = dropout(B^T rows) on the first 64 rows
