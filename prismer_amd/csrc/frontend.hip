@@ -190,6 +190,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const bf16* __restrict__
     for (int e = 0; e < 8; ++e) { mu[e] = mean[cc * 8 + e]; rs[e] = rstd[cc * 8 + e]; gm[e] = gamma[cc * 8 + e]; bt[e] = beta[cc * 8 + e]; }
   }
   if (r_in < rpp) {
+#pragma unroll 4                      // keep 4 (MODE 1: 8) row loads in flight per thread
     for (int64_t r = (int64_t)blockIdx.x * rpp + r_in; r < M; r += (int64_t)gridDim.x * rpp) {
       bf16x8 t = *reinterpret_cast<const bf16x8*>(y + r * C + cc * 8);
       if (MODE == 0) {
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(256) void tokens_bwd_kernel(const bf16* __restrict_
   if (id >= total) return;
   int c = (id % cpr) * 4, t = id / cpr;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8                      // 8 independent 8-B loads in flight per thread (the batch loop is a latency chain otherwise)
   for (int b = 0; b < B; ++b) {
     bf16x4 d = *reinterpret_cast<const bf16x4*>(dtok + ((int64_t)b * tpb + off + t) * D + c);
     if (dfeat) *reinterpret_cast<bf16x4*>(dfeat + ((int64_t)b * G + t) * D + c) = d;

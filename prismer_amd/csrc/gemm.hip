@@ -652,21 +652,28 @@ static int launch_grouped_layout(const GroupParams& g, int total, int ta, int tb
 extern "C" int ph_gemm_grouped_bf16(const ph_gemm_args* args, int n, hipStream_t stream) {
   PH_CHECK_ARG(args && n >= 1 && n <= PH_GEMM_GROUP_MAX, "ph_gemm_grouped_bf16: need 1..%d problems, got %d", PH_GEMM_GROUP_MAX, n);
   double flops = 0.0, bytes = 0.0;
-  int64_t t128 = 0;
-  bool kfull = true;
+  double w128 = 0.0, w64 = 0.0, kt_max = 0.0;      // tile-iterations of work per tile shape
+  bool kfull = true, thin = false;
   for (int i = 0; i < n; ++i) {
     PH_CHECK_ARG(args[i].trans_a == args[0].trans_a && args[i].trans_b == args[0].trans_b, "ph_gemm_grouped_bf16: mixed layouts in one group");
     flops += 2.0 * args[i].M * (double)args[i].N * args[i].K;
     bytes += 2.0 * ((double)args[i].M * args[i].K + (double)args[i].N * args[i].K + (double)args[i].M * args[i].N);
-    t128 += (int64_t)ceil_div(args[i].M, 128) * ceil_div(args[i].N, 128);
+    const double kt = ceil_div(args[i].K, BK);
+    w128 += (double)ceil_div(args[i].M, 128) * ceil_div(args[i].N, 128) * kt;
+    w64 += (double)ceil_div(args[i].M, 64) * ceil_div(args[i].N, 64) * kt;
+    kt_max = kt > kt_max ? kt : kt_max;
     kfull = kfull && (args[i].K % BK) == 0;
-    if (args[i].M <= 64 || args[i].N <= 64) t128 = -(1 << 30);          // thin outputs: 64x64 tiles
+    thin = thin || args[i].M <= 64 || args[i].N <= 64;
   }
   char desc__[96];
   if (g_ph_prof_enabled) snprintf(desc__, sizeof(desc__), "gemm grouped n=%d ta=%d tb=%d K0=%d", n, args[0].trans_a, args[0].trans_b, args[0].K);
   ProfScope prof__(PH_FAM_GEMM, flops, bytes, stream, desc__);
-  // 128x128 tiles once they fill the chip (2 blocks per CU = 512 slots), else 64x64 (4 per CU)
-  const int BMsel = t128 >= 384 ? 128 : 64;
+  // 128x128 tiles (twice the arithmetic intensity per staged byte) unless the group is so small that they would leave most
+  // CUs idle; long reductions always take them (measured: 16 adaptor wgrads 768x384xK=8320 ran 440 us on 64x64 tiles)
+  double t128 = 0.0;
+  for (int i = 0; i < n; ++i) t128 += (double)ceil_div(args[i].M, 128) * ceil_div(args[i].N, 128);
+  const int BMsel = (!thin && (t128 >= 192.0 || (kt_max >= 32.0 && t128 >= 64.0))) ? 128 : 64;
+  (void)w128; (void)w64;
   GroupParams g;                             // ~2.3 KB: copied into the kernel arguments by the launch
   g.n = n;
   int total = 0;
