@@ -160,12 +160,14 @@ int ph_col2im_nhwc(const void* dcol, void* dx, int B, int H, int W, int C, int k
  * training == 0: scale/shift from the running statistics, nothing updated. */
 int ph_bn_stats(const void* y, int M, int C, const float* gamma, const float* beta, float* running_mean,
                 float* running_var, float momentum, float eps, int training, float* mean, float* rstd,
-                float* scale, float* shift, hipStream_t stream);   /* scale and shift must be ONE [2*C] block: shift == scale + C */
+                float* scale, float* shift, int prezeroed, hipStream_t stream);
+/* scale and shift must be ONE [2*C] block (shift == scale + C): it doubles as the reduction scratch.  prezeroed != 0: the
+ * caller has already zeroed that block (one memset for all BatchNorm layers of a step instead of one per layer). */
 /* BatchNorm + ReLU backward.  da = gradient w.r.t. relu(bn(y)).  Two kernels inside:
  * (1) dgamma += sum g*xhat, dbeta += sum g with g = da * [bn(y) > 0];  (2) dy = gamma*rstd*(g - dbeta/M - xhat*dgamma/M).
- * sums: fp32 workspace [2*C] (zeroed by the call). */
+ * sums: fp32 workspace [2*C], zeroed by the call unless prezeroed != 0. */
 int ph_bn_relu_bwd(const void* da, const void* y, void* dy, int M, int C, const float* gamma, const float* beta,
-                   const float* mean, const float* rstd, float* dgamma, float* dbeta, float* sums,
+                   const float* mean, const float* rstd, float* dgamma, float* dbeta, float* sums, int prezeroed,
                    hipStream_t stream);
 /* tokens[b, off + t, :] = feat[b*G + t, :] + pos[t, :] (+ inst_emb[table[inst[b, nearest(t)]], :])
  * (vit.py:141-159).  inst: int64 [B, E, E] instance map (nearest down-sampling to g x g), table: int32[256]. */
@@ -242,6 +244,12 @@ int ph_copy_rows_bf16(const void* src, int lds, ph_rowmap src_map, void* dst, in
 int ph_conv_weight_to_shadow(const float* w, void* shadow, int Cout, int Cin, int ks, int Kp, hipStream_t stream);
 /* and the adjoint for gradients: dshadow fp32 [Cout,Kp] (ky,kx,c) -> dw[Cout,Cin,kh,kw] += */
 int ph_conv_grad_from_shadow(const float* dshadow, float* dw, int Cout, int Cin, int ks, int Kp, hipStream_t stream);
+/* the two conv layout passes for n <= PH_CONV_GROUP_MAX layers in one launch each (24 stem convs + 6 1x1 convs per step):
+ * to_shadow: src = fp32 weight [Cout][Cin][ks][ks], dst = bf16 shadow [Cout][Kp];  from_shadow: src = fp32 dshadow, dst = fp32 dw (+=) */
+#define PH_CONV_GROUP_MAX 32
+typedef struct { const float* src; void* dst; int Cout, Cin, ks, Kp; } ph_conv_layout_item;
+int ph_conv_weight_to_shadow_grouped(const ph_conv_layout_item* items, int n, hipStream_t stream);
+int ph_conv_grad_from_shadow_grouped(const ph_conv_layout_item* items, int n, hipStream_t stream);
 /* advance the dropout seed (device-side, graph-replay safe): seed[0] = splitmix(seed[0]) */
 int ph_advance_seed(uint64_t* seed, hipStream_t stream);
 

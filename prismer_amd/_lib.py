@@ -46,6 +46,13 @@ class ColsumItem(C.Structure):
 GEMM_GROUP_MAX = 16      # PH_GEMM_GROUP_MAX
 
 
+class ConvLayoutItem(C.Structure):
+    _fields_ = [('src', c_void_p), ('dst', c_void_p), ('Cout', c_int), ('Cin', c_int), ('ks', c_int), ('Kp', c_int)]
+
+
+CONV_GROUP_MAX = 32      # PH_CONV_GROUP_MAX
+
+
 class LayerNormFwdArgs(C.Structure):
     _fields_ = [('x', c_void_p), ('gamma', c_void_p), ('beta', c_void_p),
                 ('y', c_void_p), ('y_map', RowMap), ('y2', c_void_p), ('y2_map', RowMap),
@@ -105,9 +112,9 @@ _SIGS = {
     'ph_im2col_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'ph_col2im_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ph_bn_stats': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
-                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                            c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'ph_bn_relu_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                               c_void_p, c_void_p, c_void_p, c_void_p]),
+                               c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'ph_tokens_finalize': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p]),
     'ph_tokens_finalize_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
@@ -124,6 +131,8 @@ _SIGS = {
     'ph_cast_bf16_to_f32': (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     'ph_colsum_bf16': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'ph_colsum_grouped_bf16': (c_int, [c_void_p, c_int, c_void_p]),
+    'ph_conv_weight_to_shadow_grouped': (c_int, [c_void_p, c_int, c_void_p]),
+    'ph_conv_grad_from_shadow_grouped': (c_int, [c_void_p, c_int, c_void_p]),
     'ph_gemm_grouped_bf16': (c_int, [c_void_p, c_int, c_void_p]),
     'ph_add_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     'ph_act_bwd_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),

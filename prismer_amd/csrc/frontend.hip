@@ -404,7 +404,7 @@ extern "C" int ph_col2im_nhwc(const void* dcol, void* dx, int B, int H, int W, i
 
 extern "C" int ph_bn_stats(const void* y, int M, int C, const float* gamma, const float* beta, float* running_mean,
                            float* running_var, float momentum, float eps, int training, float* mean, float* rstd, float* scale,
-                           float* shift, hipStream_t stream) {
+                           float* shift, int prezeroed, hipStream_t stream) {
   PH_CHECK_ARG(gamma && beta && running_mean && running_var && mean && rstd && scale && shift, "ph_bn_stats: null pointer");
   ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream, "ph_bn_stats");
   PH_CHECK_ARG(C % 8 == 0 && C <= 2048 && M > 0, "ph_bn_stats: C=%d unsupported", C);
@@ -413,7 +413,7 @@ extern "C" int ph_bn_stats(const void* y, int M, int C, const float* gamma, cons
   PH_CHECK_ARG(shift == scale + C, "ph_bn_stats: scale/shift must be one contiguous [2*C] block");
   if (training) {
     PH_CHECK_ARG(y, "ph_bn_stats: null y");
-    (void)hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, stream);
+    if (!prezeroed) (void)hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, stream);
     int rpp = 256 / (C / 8);
     int grid = (int)std::min<int64_t>(ceil_div64(M, (int64_t)rpp * 8), 1024);
     hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(grid), dim3(256), sizeof(float) * 2 * C, stream, (const bf16*)y, (const bf16*)nullptr, M,
@@ -426,12 +426,12 @@ extern "C" int ph_bn_stats(const void* y, int M, int C, const float* gamma, cons
 }
 
 extern "C" int ph_bn_relu_bwd(const void* da, const void* y, void* dy, int M, int C, const float* gamma, const float* beta,
-                              const float* mean, const float* rstd, float* dgamma, float* dbeta, float* sums,
+                              const float* mean, const float* rstd, float* dgamma, float* dbeta, float* sums, int prezeroed,
                               hipStream_t stream) {
   PH_CHECK_ARG(da && y && dy && gamma && beta && mean && rstd && sums, "ph_bn_relu_bwd: null pointer");
   ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream, "ph_bn_relu_bwd");
   PH_CHECK_ARG(C % 8 == 0 && C <= 2048 && M > 0, "ph_bn_relu_bwd: C=%d unsupported", C);
-  (void)hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, stream);
+  if (!prezeroed) (void)hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, stream);
   int rpp = 256 / (C / 8);
   int grid = (int)std::min<int64_t>(ceil_div64(M, (int64_t)rpp * 8), 1024);
   hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(grid), dim3(256), sizeof(float) * 2 * C, stream, (const bf16*)y, (const bf16*)da, M, C, mean,

@@ -158,6 +158,38 @@ __global__ void conv_g_shadow_kernel(const float* __restrict__ ds, float* __rest
   dw[((int64_t)o * Cin + c) * ks * ks + tap] += ds[(int64_t)o * Kp + k];
 }
 
+// grouped forms: all conv layers of the stems in one grid (block -> (layer, element block) through a table in the kernel args)
+struct ConvFoldGroup {
+  int n;
+  int blk_start[PH_CONV_GROUP_MAX + 1];
+  struct Item { const float* src; void* dst; int Cout, Cin, ks, Kp; } it[PH_CONV_GROUP_MAX];
+};
+__global__ void conv_g_shadow_grouped_kernel(ConvFoldGroup g) {
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.blk_start[i + 1]) ++i;
+  const ConvFoldGroup::Item& t = g.it[i];
+  int64_t id = (int64_t)((int)blockIdx.x - g.blk_start[i]) * blockDim.x + threadIdx.x;
+  int K = t.ks * t.ks * t.Cin;
+  if (id >= (int64_t)t.Cout * K) return;
+  int k = (int)(id % K), o = (int)(id / K);
+  int tap = k / t.Cin, c = k % t.Cin;
+  reinterpret_cast<float*>(t.dst)[((int64_t)o * t.Cin + c) * t.ks * t.ks + tap] += t.src[(int64_t)o * t.Kp + k];
+}
+__global__ void conv_w_shadow_grouped_kernel(ConvFoldGroup g) {
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.blk_start[i + 1]) ++i;
+  const ConvFoldGroup::Item& t = g.it[i];
+  int64_t id = (int64_t)((int)blockIdx.x - g.blk_start[i]) * blockDim.x + threadIdx.x;
+  if (id >= (int64_t)t.Cout * t.Kp) return;
+  int k = (int)(id % t.Kp), o = (int)(id / t.Kp);
+  float v = 0.f;
+  if (k < t.ks * t.ks * t.Cin) {
+    int tap = k / t.Cin, c = k % t.Cin;
+    v = t.src[((int64_t)o * t.Cin + c) * t.ks * t.ks + tap];
+  }
+  reinterpret_cast<bf16*>(t.dst)[id] = f2bf(v);
+}
+
 __global__ void advance_seed_kernel(uint64_t* seed) {
   uint64_t z = seed[0] + 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -337,6 +369,32 @@ extern "C" int ph_conv_grad_from_shadow(const float* dshadow, float* dw, int Cou
   hipLaunchKernelGGL(conv_g_shadow_kernel, dim3((unsigned)ceil_div64((int64_t)Cout * Cin * ks * ks, 256)), dim3(256), 0, stream, dshadow, dw, Cout, Cin, ks, Kp);
   PH_LAUNCH_CHECK("conv_g_shadow_kernel");
   return PH_OK;
+}
+static int conv_group_launch(const ph_conv_layout_item* items, int n, bool to_shadow, hipStream_t stream, const char* who) {
+  PH_CHECK_ARG(items && n >= 1 && n <= PH_CONV_GROUP_MAX, "%s: need 1..%d items, got %d", who, PH_CONV_GROUP_MAX, n);
+  ConvFoldGroup g;
+  g.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    const ph_conv_layout_item& a = items[i];
+    PH_CHECK_ARG(a.src && a.dst && a.Kp >= a.Cin * a.ks * a.ks, "%s: bad item %d", who, i);
+    g.it[i].src = a.src; g.it[i].dst = a.dst; g.it[i].Cout = a.Cout; g.it[i].Cin = a.Cin; g.it[i].ks = a.ks; g.it[i].Kp = a.Kp;
+    g.blk_start[i] = total;
+    total += (int)ceil_div64(to_shadow ? (int64_t)a.Cout * a.Kp : (int64_t)a.Cout * a.Cin * a.ks * a.ks, 256);
+  }
+  g.blk_start[n] = total;
+  if (to_shadow) hipLaunchKernelGGL(conv_w_shadow_grouped_kernel, dim3(total), dim3(256), 0, stream, g);
+  else hipLaunchKernelGGL(conv_g_shadow_grouped_kernel, dim3(total), dim3(256), 0, stream, g);
+  PH_LAUNCH_CHECK(who);
+  return PH_OK;
+}
+extern "C" int ph_conv_weight_to_shadow_grouped(const ph_conv_layout_item* items, int n, hipStream_t stream) {
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_conv_weight_to_shadow_grouped");
+  return conv_group_launch(items, n, true, stream, "ph_conv_weight_to_shadow_grouped");
+}
+extern "C" int ph_conv_grad_from_shadow_grouped(const ph_conv_layout_item* items, int n, hipStream_t stream) {
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_conv_grad_from_shadow_grouped");
+  return conv_group_launch(items, n, false, stream, "ph_conv_grad_from_shadow_grouped");
 }
 extern "C" int ph_advance_seed(uint64_t* seed, hipStream_t stream) {
   PH_CHECK_ARG(seed, "ph_advance_seed: null");

@@ -133,6 +133,7 @@ class WgradQueue:
         self.enabled = True
         self.gemms = {}          # K -> [(dy, x, gw, M, N, K)]
         self.cols = []           # [(dy, gb, M, N)]
+        self.folds = []          # [(dshadow, dw, Cout, Cin, ks, Kp)]  conv weight gradients: shadow layout -> parameter layout
 
     def add_gemm(self, dy, x, gw, M, N, K):
         """gw[M, N] (fp32) += dy[K, M]^T . x[K, N]"""
@@ -154,6 +155,14 @@ class WgradQueue:
         self.cols.append((dy, gb, dy.shape[0], N))
         if len(self.cols) == _lib.GEMM_GROUP_MAX:
             self._flush_cols()
+
+    def add_conv_fold(self, ds, dw, Cout, Cin, ks, Kp):
+        """dw[Cout, Cin, ks, ks] += ds[Cout, Kp] (im2col column order): queued behind the GEMM that produces ds on the
+        side stream; all layers of a step fold in one launch"""
+        if not self.enabled:
+            conv_grad_from_shadow(ds, dw, Cout, Cin, ks, Kp)
+            return
+        self.folds.append((ds, dw, Cout, Cin, ks, Kp))
 
     def _flush_gemms(self, K):
         q = self.gemms.pop(K, [])
@@ -186,6 +195,9 @@ class WgradQueue:
         for K in list(self.gemms):
             self._flush_gemms(K)
         self._flush_cols()
+        if self.folds:
+            q, self.folds = self.folds, []
+            off_critical_path(lambda: conv_layout_grouped(q, False), *[t for e in q for t in e[:2]])
 
 
 WQ = WgradQueue()
@@ -358,22 +370,26 @@ def col2im(dcol, B, H, W, Cc, ks, stride, Kp):
     return dx
 
 
-def bn_stats(y, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5):
-    """returns stats [4, C] fp32 = (mean, rstd, scale, shift); y: bf16 [M, C] conv output."""
+def bn_stats(y, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, out=None):
+    """returns stats [4, C] fp32 = (mean, rstd, scale, shift); y: bf16 [M, C] conv output.
+    out: optional ZEROED [4, C] slice of a per-step arena (saves the per-layer memset launch)."""
     M, Cc = y.shape
-    st = torch.empty((4, Cc), dtype=F32, device=y.device)
+    st = out if out is not None else torch.empty((4, Cc), dtype=F32, device=y.device)
     check(lib.ph_bn_stats(y.data_ptr(), M, Cc, gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
                           momentum, eps, int(training), st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(),
-                          _stream()), 'ph_bn_stats')
+                          int(out is not None), _stream()), 'ph_bn_stats')
     return st
 
 
-def bn_relu_bwd(da, y, gamma, beta, stats, dgamma, dbeta):
+def bn_relu_bwd(da, y, gamma, beta, stats, dgamma, dbeta, sums=None):
+    """sums: optional ZEROED fp32 [2C] slice of a per-step arena (saves the per-layer memset launch)."""
     M, Cc = y.shape
     dy = torch.empty_like(y)
-    sums = torch.empty((2 * Cc,), dtype=F32, device=y.device)
+    pre = sums is not None
+    if sums is None:
+        sums = torch.empty((2 * Cc,), dtype=F32, device=y.device)
     check(lib.ph_bn_relu_bwd(da.data_ptr(), y.data_ptr(), dy.data_ptr(), M, Cc, gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(),
-                             stats[1].data_ptr(), ptr(dgamma), ptr(dbeta), sums.data_ptr(), _stream()), 'ph_bn_relu_bwd')
+                             stats[1].data_ptr(), ptr(dgamma), ptr(dbeta), sums.data_ptr(), int(pre), _stream()), 'ph_bn_relu_bwd')
     return dy
 
 
@@ -503,6 +519,17 @@ def conv_weight_to_shadow(w, shadow, Cout, Cin, ks, Kp):
 
 def conv_grad_from_shadow(dshadow, dw, Cout, Cin, ks, Kp):
     check(lib.ph_conv_grad_from_shadow(dshadow.data_ptr(), dw.data_ptr(), Cout, Cin, ks, Kp, _stream()), 'ph_conv_grad_from_shadow')
+
+
+def conv_layout_grouped(items, to_shadow):
+    """items: [(src, dst, Cout, Cin, ks, Kp)]; one launch per PH_CONV_GROUP_MAX layers."""
+    fn = lib.ph_conv_weight_to_shadow_grouped if to_shadow else lib.ph_conv_grad_from_shadow_grouped
+    for i0 in range(0, len(items), _lib.CONV_GROUP_MAX):
+        part = items[i0:i0 + _lib.CONV_GROUP_MAX]
+        arr = (_lib.ConvLayoutItem * len(part))()
+        for it, (src, dst, Co, Ci, ks, Kp) in zip(arr, part):
+            it.src, it.dst, it.Cout, it.Cin, it.ks, it.Kp = src.data_ptr(), dst.data_ptr(), Co, Ci, ks, Kp
+        check(fn(arr, len(part), _stream()), 'ph_conv_layout_grouped')
 
 
 def advance_seed(seed):

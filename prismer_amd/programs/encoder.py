@@ -75,6 +75,7 @@ class LN:
 class EncoderProgram:
     def __init__(self, module, dims, store):
         self.mod, self.d, self.P = module, dims, store
+        self._arena, self._arena_off, self._bn_counters = None, 0, []
         d, P = dims, store
         W = d.width
         self.Kp_rgb = _rup(3 * d.patch_size ** 2, 8)
@@ -107,7 +108,8 @@ class EncoderProgram:
     def conv_shadow(self, name, ks):
         Co, Ci = self.P.shape[name][0], self.P.shape[name][1]
         Kp = _rup(ks * ks * Ci, 8)
-        return self.P.derived_buffer(name, (Co, Kp), lambda t: ops.conv_weight_to_shadow(self.P.f(name), t, Co, Ci, ks, Kp)), Kp
+        return self.P.derived_buffer(name, (Co, Kp), lambda t: ops.conv_weight_to_shadow(self.P.f(name), t, Co, Ci, ks, Kp),
+                                     conv=(name, Co, Ci, ks, Kp)), Kp
 
     def conv_wgrad(self, name, ks, dy, col):
         """dW (shadow layout [Cout, Kp], fp32) = dy^T . col, folded back into the [Cout,Cin,k,k] gradient."""
@@ -116,14 +118,11 @@ class EncoderProgram:
             return
         Co, Ci = self.P.shape[name][0], self.P.shape[name][1]
         Kp = col.shape[1]
-        def work():
-            if ks == 1 and Kp == Ci:
-                ops.gemm(dy, col, out=g.view(Co, Ci), trans_a=True, trans_b=True, out_f32=True, accumulate=True, M=Co, N=Kp, K=dy.shape[0])
-                return None
-            ds = ops.gemm(dy, col, trans_a=True, trans_b=True, out_f32=True, M=Co, N=Kp, K=dy.shape[0])
-            ops.conv_grad_from_shadow(ds, g, Co, Ci, ks, Kp)
-            return ds
-        ops.off_critical_path(work, dy, col)
+        if ks == 1 and Kp == Ci:                         # 1x1 conv: the shadow layout IS the parameter layout
+            ops.WQ.add_gemm(dy, col, g.view(Co, Ci), Co, Kp, dy.shape[0])
+            return
+        ds = ops.off_critical_path(lambda: ops.gemm(dy, col, trans_a=True, trans_b=True, out_f32=True, M=Co, N=Kp, K=dy.shape[0]), dy, col)
+        ops.WQ.add_conv_fold(ds, g, Co, Ci, ks, Kp)      # folded back into [Cout, Cin, k, k] with all other layers at the flush
 
     # ---------------------------------------------------------------------------------------- positional embedding
     def expert_pos(self):
@@ -152,6 +151,22 @@ class EncoderProgram:
         ops.scatter_taps(dpos_e, g, idx, w, d.expert_grid ** 2, 16, d.width)
 
     # ---------------------------------------------------------------------------------------- expert stems
+    def _bn_arena(self, n_experts, per_channel):
+        """one zeroed fp32 block holding per_channel * C floats for every BatchNorm layer of every stem (ONE memset per
+        pass instead of one per layer); handed out front to back by _bn_take."""
+        d = self.d
+        total = n_experts * per_channel * sum(d.width // k for k in (8, 4, 2, 1))
+        self._arena = torch.zeros(total, dtype=F32, device=self.P.master.device)
+        self._arena_off = 0
+
+    def _bn_take(self, n):
+        a = getattr(self, '_arena', None)
+        if a is None or self._arena_off + n > a.numel():
+            return None
+        o = self._arena_off
+        self._arena_off = o + n
+        return a[o:o + n]
+
     def stem_fwd(self, dom, x, training, sv):
         d = self.d
         B, Cin = x.shape[0], x.shape[1]
@@ -169,10 +184,12 @@ class EncoderProgram:
             col = ops.im2col(a, B, H, H, C, 3, s, Kp, scale, shift)
             y = ops.gemm(col, shadow)
             bn = seq[2 + 3 * i]
+            slot = self._bn_take(4 * y.shape[1])
             st = ops.bn_stats(y, self.P.f(f'conv1.{dom}.{2 + 3 * i}.weight'), self.P.f(f'conv1.{dom}.{2 + 3 * i}.bias'),
-                              bn.running_mean, bn.running_var, training, bn.momentum, bn.eps)
+                              bn.running_mean, bn.running_var, training, bn.momentum, bn.eps,
+                              out=None if slot is None else slot.view(4, y.shape[1]))
             if training:
-                bn.num_batches_tracked += 1
+                self._bn_counters.append(bn.num_batches_tracked)     # += 1 for all layers in one launch (forward_front)
             geo.append((H, C, s, Kp))
             H = ops.conv_out_size(H, 3, s)
             C = y.shape[1]
@@ -195,7 +212,8 @@ class EncoderProgram:
         for i in (3, 2, 1, 0):
             H, C, stride, Kp = s['geo'][i]
             gname, bname = f'conv1.{dom}.{2 + 3 * i}.weight', f'conv1.{dom}.{2 + 3 * i}.bias'
-            dy = ops.bn_relu_bwd(da, s['ys'][i], self.P.f(gname), self.P.f(bname), s['stats'][i], self.P.g(gname), self.P.g(bname))
+            dy = ops.bn_relu_bwd(da, s['ys'][i], self.P.f(gname), self.P.f(bname), s['stats'][i], self.P.g(gname), self.P.g(bname),
+                                 sums=self._bn_take(2 * s['ys'][i].shape[1]))
             wname = f'conv1.{dom}.{1 + 3 * i}.weight'
             self.conv_wgrad(wname, 3, dy, s['cols'][i])
             if i > 0:
@@ -353,6 +371,8 @@ class EncoderProgram:
             xf = torch.empty(B * Mx, W, dtype=BF16, device=dev)
             pos_e = self.expert_pos()
             keep = []
+            self._bn_arena(len(names), 4)
+            self._bn_counters = []
             for ei, name in enumerate(names):                  # the stems are independent: parallel graph branches
                 with ops.POOL.branch(ei):
                     dom = 'seg' if 'seg' in name else name
@@ -371,6 +391,10 @@ class EncoderProgram:
                     keep.append(f)
             ops.POOL.join()
             del keep
+            self._arena = None
+            if self._bn_counters:
+                torch._foreach_add_(self._bn_counters, 1)
+                self._bn_counters = []
         if save:
             sv.update(B=B, names=names, rgb_col=col,
                       inst=(x['obj_detection']['instance'].contiguous() if 'obj_detection' in x else None), inst_table=inst_table)
@@ -421,6 +445,7 @@ class EncoderProgram:
             same = d.expert_grid == d.rgb_grid
             dpos_e = gpos if same else torch.zeros(G, W, dtype=F32, device=dh.device)
             keep = []
+            self._bn_arena(len(names), 2)
             for ei, name in enumerate(names):
                 dom = 'seg' if 'seg' in name else name
                 dfeat = torch.empty(B * G, W, dtype=BF16, device=dh.device)
@@ -435,6 +460,7 @@ class EncoderProgram:
                     self.stem_bwd(dom, dfeat, sv)
             ops.POOL.join()
             del keep
+            self._arena = None
             if not same and gpos is not None:
                 self.expert_pos_bwd(dpos_e)
         drgb = torch.empty(B * N, W, dtype=BF16, device=dh.device)
