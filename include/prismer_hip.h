@@ -106,9 +106,16 @@ typedef struct {
   float* dgamma; float* dbeta;    /* fp32 [D], ACCUMULATED; NULL when the affine is frozen */
   int M, D;
   int x_f32;                      /* x is fp32 */
-  float* partial_ws; int64_t partial_ws_bytes;   /* optional scratch (>= 512*2*D*4 B): per-block partials + reduce instead of atomics */
+  float* partial_ws; int64_t partial_ws_bytes;   /* optional scratch (>= blocks*2*D*4 B): per-block partials + reduce instead of atomics */
+  int defer_reduce;               /* != 0 (needs partial_ws): leave the per-block partials in partial_ws and do NOT fold them into
+                                     dgamma/dbeta; the caller folds many LayerNorms at once with ph_ln_param_reduce_grouped */
 } ph_layernorm_bwd_args;
 int ph_layernorm_bwd(const ph_layernorm_bwd_args* args, hipStream_t stream);
+/* number of partial rows ph_layernorm_bwd writes for M input rows: partial_ws holds [blocks][2][D] floats */
+int ph_layernorm_bwd_blocks(int M);
+/* dgamma[c] += sum_b ws[b][0][c], dbeta[c] += sum_b ws[b][1][c] for n <= PH_GEMM_GROUP_MAX deferred LayerNorm backwards */
+typedef struct { const float* ws; int blocks, D; float* dgamma; float* dbeta; } ph_ln_reduce_item;
+int ph_ln_param_reduce_grouped(const ph_ln_reduce_item* items, int n, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused multi-head attention (flash style: online softmax, scores never materialised).

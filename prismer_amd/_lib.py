@@ -39,6 +39,10 @@ class GemmArgs(C.Structure):
                 ('residual_f32', c_int), ('workspace', c_void_p), ('workspace_bytes', c_i64)]
 
 
+class LnReduceItem(C.Structure):
+    _fields_ = [('ws', c_void_p), ('blocks', c_int), ('D', c_int), ('dgamma', c_void_p), ('dbeta', c_void_p)]
+
+
 class ColsumItem(C.Structure):
     _fields_ = [('x', c_void_p), ('out', c_void_p), ('M', c_int), ('N', c_int), ('ld', c_int)]
 
@@ -66,7 +70,7 @@ class LayerNormBwdArgs(C.Structure):
                 ('dskip', c_void_p), ('dx', c_void_p), ('dx_drop', c_void_p),
                 ('drop_p', c_float), ('drop_seed', c_void_p), ('drop_stream', c_u32),
                 ('dgamma', c_void_p), ('dbeta', c_void_p), ('M', c_int), ('D', c_int),
-                ('x_f32', c_int), ('partial_ws', c_void_p), ('partial_ws_bytes', c_i64)]
+                ('x_f32', c_int), ('partial_ws', c_void_p), ('partial_ws_bytes', c_i64), ('defer_reduce', c_int)]
 
 
 class AttnFwdArgs(C.Structure):
@@ -131,6 +135,8 @@ _SIGS = {
     'ph_cast_bf16_to_f32': (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     'ph_colsum_bf16': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'ph_colsum_grouped_bf16': (c_int, [c_void_p, c_int, c_void_p]),
+    'ph_layernorm_bwd_blocks': (c_int, [c_int]),
+    'ph_ln_param_reduce_grouped': (c_int, [c_void_p, c_int, c_void_p]),
     'ph_conv_weight_to_shadow_grouped': (c_int, [c_void_p, c_int, c_void_p]),
     'ph_conv_grad_from_shadow_grouped': (c_int, [c_void_p, c_int, c_void_p]),
     'ph_gemm_grouped_bf16': (c_int, [c_void_p, c_int, c_void_p]),

@@ -232,7 +232,49 @@ __global__ void ln_param_reduce_kernel(const float* __restrict__ ws, int nblk, i
   if (dst) atomicAdd(dst + col, s);
 }
 
+struct LnReduceGroup {
+  int n;
+  int blk_start[PH_GEMM_GROUP_MAX + 1];
+  ph_ln_reduce_item it[PH_GEMM_GROUP_MAX];
+};
+// grouped form of ln_param_reduce_kernel: block -> (LayerNorm, column block, row strip)
+__global__ void ln_param_reduce_grouped_kernel(LnReduceGroup g) {
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.blk_start[i + 1]) ++i;
+  const ph_ln_reduce_item& t = g.it[i];
+  const int lid = (int)blockIdx.x - g.blk_start[i];
+  const int ncb = (2 * t.D + 255) / 256;
+  const int strips = (g.blk_start[i + 1] - g.blk_start[i]) / ncb;
+  const int c = (lid % ncb) * 256 + threadIdx.x, strip = lid / ncb;
+  if (c >= 2 * t.D) return;
+  const int which = c / t.D, col = c % t.D;
+  float s = 0.f;
+  for (int b = strip; b < t.blocks; b += strips) s += t.ws[((size_t)b * 2 + which) * t.D + col];
+  float* dst = which ? t.dbeta : t.dgamma;
+  if (dst) atomicAdd(dst + col, s);
+}
+
 }  // namespace
+
+extern "C" int ph_layernorm_bwd_blocks(int M) { return min(ceil_div(M, 4), 768); }
+
+extern "C" int ph_ln_param_reduce_grouped(const ph_ln_reduce_item* items, int n, hipStream_t stream) {
+  PH_CHECK_ARG(items && n >= 1 && n <= PH_GEMM_GROUP_MAX, "ph_ln_param_reduce_grouped: need 1..%d items, got %d", PH_GEMM_GROUP_MAX, n);
+  ProfScope prof__(PH_FAM_LAYERNORM, 0.0, 0.0, stream);
+  LnReduceGroup g;
+  g.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    PH_CHECK_ARG(items[i].ws && items[i].blocks > 0 && items[i].D > 0, "ph_ln_param_reduce_grouped: bad item %d", i);
+    g.it[i] = items[i];
+    g.blk_start[i] = total;
+    total += ceil_div(2 * items[i].D, 256) * min(items[i].blocks, 32);
+  }
+  g.blk_start[n] = total;
+  hipLaunchKernelGGL(ln_param_reduce_grouped_kernel, dim3(total), dim3(256), 0, stream, g);
+  PH_LAUNCH_CHECK("ln_param_reduce_grouped_kernel");
+  return PH_OK;
+}
 
 extern "C" int ph_layernorm_fwd(const ph_layernorm_fwd_args* a, hipStream_t stream) {
   PH_CHECK_ARG(a && a->x && a->y && a->gamma && a->beta, "ph_layernorm_fwd: null pointer");
@@ -255,7 +297,7 @@ extern "C" int ph_layernorm_bwd(const ph_layernorm_bwd_args* a, hipStream_t stre
   ProfScope prof__(PH_FAM_LAYERNORM, 0.0, 6.0 * a->M * (double)a->D, stream);
   PH_CHECK_ARG(a->M > 0 && a->D > 0 && (a->D % 4) == 0 && a->D <= MAX_CH * 256, "ph_layernorm_bwd: D=%d unsupported", a->D);
   PH_CHECK_ARG(!a->dx_drop || !(a->drop_p > 0.f) || a->drop_seed, "ph_layernorm_bwd: dropout needs a seed");
-  int grid = min(ceil_div(a->M, 4), 768);
+  int grid = ph_layernorm_bwd_blocks(a->M);
   ph_layernorm_bwd_args b = *a;
   const bool need_params = a->dgamma || a->dbeta;
   if (!need_params || (int64_t)grid * 2 * a->D * 4 > a->partial_ws_bytes) b.partial_ws = nullptr;
@@ -271,7 +313,8 @@ extern "C" int ph_layernorm_bwd(const ph_layernorm_bwd_args* a, hipStream_t stre
   else if (nch <= 4) PH_LN_BWD(4);
   else PH_LN_BWD(8);
 #undef PH_LN_BWD
-  if (need_params && b.partial_ws)
+  PH_CHECK_ARG(!a->defer_reduce || !need_params || b.partial_ws, "ph_layernorm_bwd: defer_reduce needs a partial_ws of >= blocks*2*D floats");
+  if (need_params && b.partial_ws && !a->defer_reduce)
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(ceil_div(2 * a->D, 256), min(grid, 32)), dim3(256), 0, stream, b.partial_ws, grid, a->D, a->dgamma, a->dbeta);
   PH_LAUNCH_CHECK("ln_bwd_kernel");
   return PH_OK;

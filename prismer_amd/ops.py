@@ -134,6 +134,10 @@ class WgradQueue:
         self.gemms = {}          # K -> [(dy, x, gw, M, N, K)]
         self.cols = []           # [(dy, gb, M, N)]
         self.folds = []          # [(dshadow, dw, Cout, Cin, ks, Kp)]  conv weight gradients: shadow layout -> parameter layout
+        self.lns = []            # [(partials, blocks, D, dgamma, dbeta)]  LayerNorm gamma / beta partial sums
+        self.ln_arena = None     # fp32 scratch the deferred LayerNorm backwards write their per-block partials into
+        self.ln_off = 0
+        self.ln_stream = None
 
     def add_gemm(self, dy, x, gw, M, N, K):
         """gw[M, N] (fp32) += dy[K, M]^T . x[K, N]"""
@@ -163,6 +167,38 @@ class WgradQueue:
             conv_grad_from_shadow(ds, dw, Cout, Cin, ks, Kp)
             return
         self.folds.append((ds, dw, Cout, Cin, ks, Kp))
+
+    LN_ARENA_FLOATS = 48 << 20          # 192 MB: one pass of the decoder (~80 MB) or the encoder (~110 MB) at bs32
+
+    def ln_slot(self, blocks, D, dgamma, dbeta):
+        """partials buffer [blocks, 2, D] for one LayerNorm backward whose gamma / beta reduction is deferred; None = do not
+        defer (queue off, arena full, or a stream other than the one the pending partials were written on)"""
+        if not self.enabled:
+            return None
+        cur = torch.cuda.current_stream().cuda_stream
+        if self.lns and self.ln_stream != cur:
+            return None
+        n = blocks * 2 * D
+        if self.ln_arena is None:
+            self.ln_arena = torch.empty(self.LN_ARENA_FLOATS, dtype=F32, device=dgamma.device if dgamma is not None else dbeta.device)
+        if self.ln_off + n > self.ln_arena.numel():
+            self._flush_lns()           # same stream as the writers: the fold finishes before the arena is reused
+        if n > self.ln_arena.numel():
+            return None
+        self.ln_stream = cur
+        slot = self.ln_arena[self.ln_off:self.ln_off + n]
+        self.ln_off += n
+        self.lns.append((slot, blocks, D, dgamma, dbeta))
+        return slot
+
+    def _flush_lns(self):
+        q, self.lns, self.ln_off = self.lns, [], 0
+        for i0 in range(0, len(q), _lib.GEMM_GROUP_MAX):
+            part = q[i0:i0 + _lib.GEMM_GROUP_MAX]
+            arr = (_lib.LnReduceItem * len(part))()
+            for it, (ws, blocks, D, dg, db) in zip(arr, part):
+                it.ws, it.blocks, it.D, it.dgamma, it.dbeta = ws.data_ptr(), blocks, D, ptr(dg), ptr(db)
+            check(lib.ph_ln_param_reduce_grouped(arr, len(part), _stream()), 'ph_ln_param_reduce_grouped')
 
     def _flush_gemms(self, K):
         q = self.gemms.pop(K, [])
@@ -195,6 +231,8 @@ class WgradQueue:
         for K in list(self.gemms):
             self._flush_gemms(K)
         self._flush_cols()
+        if self.lns:
+            self._flush_lns()
         if self.folds:
             q, self.folds = self.folds, []
             off_critical_path(lambda: conv_layout_grouped(q, False), *[t for e in q for t in e[:2]])
@@ -282,8 +320,14 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, *, dy_map=IDENT, dy2=None, dy2_map=I
         dx_drop = None
         a.dx_drop, a.drop_p, a.drop_seed, a.drop_stream = None, 0.0, None, 0
     a.dgamma, a.dbeta, a.M, a.D = ptr(dgamma), ptr(dbeta), M, D
-    ws = _workspace(x.device)
-    a.partial_ws, a.partial_ws_bytes = ws.data_ptr(), WS_BYTES
+    slot = None
+    if dgamma is not None or dbeta is not None:
+        slot = WQ.ln_slot(lib.ph_layernorm_bwd_blocks(M), D, dgamma, dbeta)     # gamma / beta reduction deferred and grouped
+    if slot is not None:
+        a.partial_ws, a.partial_ws_bytes, a.defer_reduce = slot.data_ptr(), slot.numel() * 4, 1
+    else:
+        ws = _workspace(x.device)
+        a.partial_ws, a.partial_ws_bytes, a.defer_reduce = ws.data_ptr(), WS_BYTES, 0
     check(lib.ph_layernorm_bwd(C.byref(a), _stream()), 'ph_layernorm_bwd')
     return dx, (dx_drop if dx_drop is not None else dx)
 

@@ -200,7 +200,17 @@ def test_layernorm(ops, M, D):
     dx, _ = ops.layernorm_bwd(dy, x, mean, rstd, g, dskip=dsk, dgamma=dg, dbeta=db)
     ref.backward(dy.float())
     assert rel_fro(dx, xf.grad + dsk.float()) < 6e-3
+    assert ops.WQ.lns, 'the gamma / beta reduction should have been deferred'
+    ops.join_side()                                       # folds the deferred per-block partials (one grouped launch)
     assert rel_fro(dg, gf.grad) < 1e-4 and rel_fro(db, bf.grad) < 1e-4
+    # immediate (non-deferred) path: in-kernel reduction
+    ops.WQ.enabled = False
+    try:
+        dg2 = torch.zeros(D, device='cuda'); db2 = torch.zeros(D, device='cuda')
+        ops.layernorm_bwd(dy, x, mean, rstd, g, dskip=dsk, dgamma=dg2, dbeta=db2)
+        assert rel_fro(dg2, gf.grad) < 1e-4 and rel_fro(db2, bf.grad) < 1e-4
+    finally:
+        ops.WQ.enabled = True
 
 
 def test_layernorm_rowmap_and_dropout(ops):
