@@ -299,7 +299,9 @@ __global__ __launch_bounds__(256) void tokens_kernel(const bf16* __restrict__ fe
   }
 }
 
-// one thread per (t, 4 channels): loops over the batch -> deterministic dpos; dinst_emb via atomics.
+// one thread per (t, 4 channels) and batch slice (blockIdx.y): the slice is walked 8 images at a time with all 8 loads
+// issued before the first store (a load -> store loop over the batch is a 2-3 us latency chain per image: 95 us per call);
+// dpos / dinst_emb via fp32 atomics (gridDim.y partial sums per position).
 __global__ __launch_bounds__(256) void tokens_bwd_kernel(const bf16* __restrict__ dtok, bf16* __restrict__ dfeat, float* __restrict__ dpos,
                                                          int B, int G, int D, int tpb, int off, const int64_t* __restrict__ inst,
                                                          int E, int g, const int32_t* __restrict__ table, float* __restrict__ dinst) {
@@ -308,19 +310,32 @@ __global__ __launch_bounds__(256) void tokens_bwd_kernel(const bf16* __restrict_
   int id = blockIdx.x * 256 + threadIdx.x;
   if (id >= total) return;
   int c = (id % cpr) * 4, t = id / cpr;
+  const int per = (B + gridDim.y - 1) / gridDim.y;
+  const int b_lo = blockIdx.y * per, b_hi = min(B, b_lo + per);
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8                      // 8 independent 8-B loads in flight per thread (the batch loop is a latency chain otherwise)
-  for (int b = 0; b < B; ++b) {
-    bf16x4 d = *reinterpret_cast<const bf16x4*>(dtok + ((int64_t)b * tpb + off + t) * D + c);
-    if (dfeat) *reinterpret_cast<bf16x4*>(dfeat + ((int64_t)b * G + t) * D + c) = d;
+  int src_y = 0, src_x = 0;
+  if (inst && dinst) { src_y = nearest_src(t / g, E, g); src_x = nearest_src(t % g, E, g); }
+  for (int b0 = b_lo; b0 < b_hi; b0 += 8) {
+    bf16x4 d[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] += bf2f(d[e]);
-    if (inst && dinst) {
-      int ty = t / g, tx = t % g;
-      int64_t lab = inst[((int64_t)b * E + nearest_src(ty, E, g)) * E + nearest_src(tx, E, g)];
-      int row = table[(int)(lab & 255)];
+    for (int j = 0; j < 8; ++j) {
+      int b = min(b0 + j, b_hi - 1);
+      d[j] = *reinterpret_cast<const bf16x4*>(dtok + ((int64_t)b * tpb + off + t) * D + c);
+    }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(dinst + (int64_t)row * D + c + e, bf2f(d[e]));
+    for (int j = 0; j < 8; ++j) {
+      int b = b0 + j;
+      if (b < b_hi) {
+        if (dfeat) *reinterpret_cast<bf16x4*>(dfeat + ((int64_t)b * G + t) * D + c) = d[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += bf2f(d[j][e]);
+        if (inst && dinst) {
+          int64_t lab = inst[((int64_t)b * E + src_y) * E + src_x];
+          int row = table[(int)(lab & 255)];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) atomicAdd(dinst + (int64_t)row * D + c + e, bf2f(d[j][e]));
+        }
+      }
     }
   }
   if (dpos) {
@@ -459,7 +474,7 @@ extern "C" int ph_tokens_finalize_bwd(const void* dtokens, void* dfeat, float* d
                                       hipStream_t stream) {
   PH_CHECK_ARG(dtokens && D % 4 == 0 && (!inst || g * g == G), "ph_tokens_finalize_bwd: bad args");
   ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream, "ph_tokens_finalize_bwd");
-  hipLaunchKernelGGL(tokens_bwd_kernel, dim3(ceil_div(G * (D / 4), 256)), dim3(256), 0, stream, (const bf16*)dtokens, (bf16*)dfeat, dpos, B, G,
+  hipLaunchKernelGGL(tokens_bwd_kernel, dim3(ceil_div(G * (D / 4), 256), B >= 16 ? 4 : 1), dim3(256), 0, stream, (const bf16*)dtokens, (bf16*)dfeat, dpos, B, G,
                      D, tok_per_batch, tok_off, inst, E, g, table, dinst_emb);
   PH_LAUNCH_CHECK("tokens_bwd_kernel");
   return PH_OK;

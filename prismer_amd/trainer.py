@@ -237,11 +237,13 @@ class Trainer:
         torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
         g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1, pool=pool):
+        # thread_local: RCCL's watchdog thread polls events while we capture (world > 1); only this thread's calls are policed
+        mode = dict(capture_error_mode='thread_local')
+        with torch.cuda.graph(g1, pool=pool, **mode):
             self._seg_forward_dec_backward(s)
-        with torch.cuda.graph(g2, pool=pool):
+        with torch.cuda.graph(g2, pool=pool, **mode):
             self._seg_enc_backward()
-        with torch.cuda.graph(g3, pool=pool):
+        with torch.cuda.graph(g3, pool=pool, **mode):
             self._seg_optimizer()
         self.graphs = (g1, g2, g3)
 

@@ -380,8 +380,9 @@ def test_batchnorm(ops, M, C):
     assert rel_fro(ev[2], g * (rv + 1e-5).rsqrt()) < 1e-5
 
 
-def test_tokens_finalize(ops):
-    B, g_, D, E = 2, 4, 256, 64
+@pytest.mark.parametrize('B', [2, 19])          # 19: batch slices (gridDim.y = 4) with a ragged last slice
+def test_tokens_finalize(ops, B):
+    g_, D, E = 4, 256, 64
     G = g_ * g_
     feat = rnd(B * G, D, seed=60)
     pos = rnd(G, D, dtype=torch.float32, seed=61)
