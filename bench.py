@@ -88,6 +88,7 @@ def build_trainer(batch, use_graph, rank, T=30, workload='base_caption'):
                  side_stream=os.environ.get('PRISMER_SIDE_STREAM', '1') != '0')
     from prismer_amd import ops as _ops
     _ops.WQ.enabled = os.environ.get('PRISMER_WGRAD_QUEUE', '1') != '0'      # A/B switch: grouped deferred wgrads
+    _ops.WQ.eager_flush = os.environ.get('PRISMER_WGRAD_EAGER_FLUSH', '0') != '0'
     x, ids, mask, labels = make_inputs(dims, batch, T, 1234 + rank, torch.device('cuda'))
     weights = None
     if workload == 'large_vqa':

@@ -131,6 +131,10 @@ class WgradQueue:
 
     def __init__(self):
         self.enabled = True
+        # False: nothing is launched before flush() -- the grouped launches are big (hundreds of 16 us tiles); issued while the
+        # decoder's chain of small dependent kernels is running they take every CU slot and each chain kernel then waits for
+        # slots to drain.  True: launch as soon as 16 problems of one reduction length are queued.
+        self.eager_flush = False
         self.gemms = {}          # K -> [(dy, x, gw, M, N, K)]
         self.cols = []           # [(dy, gb, M, N)]
         self.folds = []          # [(dshadow, dw, Cout, Cin, ks, Kp)]  conv weight gradients: shadow layout -> parameter layout
@@ -144,12 +148,9 @@ class WgradQueue:
         if not self.enabled:
             gemm(dy, x, out=gw, trans_a=True, trans_b=True, out_f32=True, accumulate=True, M=M, N=N, K=K)
             return
-        q = self.gemms.setdefault(K, [])
-        if any(e[2].data_ptr() == gw.data_ptr() for e in q):      # two read-modify-writes of one output never share a launch
-            self._flush_gemms(K)
-            q = self.gemms.setdefault(K, [])
+        q = self.gemms.setdefault(K, [])                           # (two writers of one output never share a launch: _flush_gemms)
         q.append((dy, x, gw, M, N, K))
-        if len(q) == _lib.GEMM_GROUP_MAX:
+        if self.eager_flush and len(q) == _lib.GEMM_GROUP_MAX:
             self._flush_gemms(K)
 
     def add_colsum(self, dy, gb, N):
@@ -157,7 +158,7 @@ class WgradQueue:
             colsum(dy, gb, N=N)
             return
         self.cols.append((dy, gb, dy.shape[0], N))
-        if len(self.cols) == _lib.GEMM_GROUP_MAX:
+        if self.eager_flush and len(self.cols) == _lib.GEMM_GROUP_MAX:
             self._flush_cols()
 
     def add_conv_fold(self, ds, dw, Cout, Cin, ks, Kp):
@@ -201,31 +202,38 @@ class WgradQueue:
             check(lib.ph_ln_param_reduce_grouped(arr, len(part), _stream()), 'ph_ln_param_reduce_grouped')
 
     def _flush_gemms(self, K):
-        q = self.gemms.pop(K, [])
-        if not q:
+        allq = self.gemms.pop(K, [])
+        if not allq:
             return
 
         def work():
-            arr = (_lib.GemmArgs * len(q))()
-            for g, (dy, x, gw, M, N, Kk) in zip(arr, q):
-                g.A, g.B, g.C = dy.data_ptr(), x.data_ptr(), gw.data_ptr()
-                g.M, g.N, g.K = M, N, Kk
-                g.lda, g.ldb, g.ldc = dy.stride(0), x.stride(0), gw.stride(0)
-                g.trans_a, g.trans_b, g.out_f32, g.accumulate, g.alpha = 1, 1, 1, 1, 1.0
-            check(lib.ph_gemm_grouped_bf16(arr, len(q), _stream()), 'ph_gemm_grouped_bf16')
-        off_critical_path(work, *[t for e in q for t in e[:3]])
+            i0 = 0
+            while i0 < len(allq):                    # <= 16 problems per launch, no output twice in one launch
+                q, seen = [], set()
+                while i0 < len(allq) and len(q) < _lib.GEMM_GROUP_MAX and allq[i0][2].data_ptr() not in seen:
+                    seen.add(allq[i0][2].data_ptr()); q.append(allq[i0]); i0 += 1
+                arr = (_lib.GemmArgs * len(q))()
+                for g, (dy, x, gw, M, N, Kk) in zip(arr, q):
+                    g.A, g.B, g.C = dy.data_ptr(), x.data_ptr(), gw.data_ptr()
+                    g.M, g.N, g.K = M, N, Kk
+                    g.lda, g.ldb, g.ldc = dy.stride(0), x.stride(0), gw.stride(0)
+                    g.trans_a, g.trans_b, g.out_f32, g.accumulate, g.alpha = 1, 1, 1, 1, 1.0
+                check(lib.ph_gemm_grouped_bf16(arr, len(q), _stream()), 'ph_gemm_grouped_bf16')
+        off_critical_path(work, *[t for e in allq for t in e[:3]])
 
     def _flush_cols(self):
-        q, self.cols = self.cols, []
-        if not q:
+        allq, self.cols = self.cols, []
+        if not allq:
             return
 
         def work():
-            arr = (_lib.ColsumItem * len(q))()
-            for it, (dy, gb, M, N) in zip(arr, q):
-                it.x, it.out, it.M, it.N, it.ld = dy.data_ptr(), gb.data_ptr(), M, N, dy.stride(0)
-            check(lib.ph_colsum_grouped_bf16(arr, len(q), _stream()), 'ph_colsum_grouped_bf16')
-        off_critical_path(work, *[t for e in q for t in e[:2]])
+            for i0 in range(0, len(allq), _lib.GEMM_GROUP_MAX):
+                q = allq[i0:i0 + _lib.GEMM_GROUP_MAX]
+                arr = (_lib.ColsumItem * len(q))()
+                for it, (dy, gb, M, N) in zip(arr, q):
+                    it.x, it.out, it.M, it.N, it.ld = dy.data_ptr(), gb.data_ptr(), M, N, dy.stride(0)
+                check(lib.ph_colsum_grouped_bf16(arr, len(q), _stream()), 'ph_colsum_grouped_bf16')
+        off_critical_path(work, *[t for e in allq for t in e[:2]])
 
     def flush(self):
         for K in list(self.gemms):

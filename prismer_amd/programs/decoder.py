@@ -10,6 +10,8 @@ LayerNorm kernel; the post-LN residual stream (LayerNorm outputs and the pre-nor
 copies the GEMMs read -- what autocast does on the reference (its fp32 LayerNorm returns fp32 to an fp32 residual); logits live in a [B*T, Vpad] bf16 buffer (Vpad = vocab rounded up to 64) and the backward
 overwrites it with dlogits.
 """
+import os
+
 import torch
 
 from .. import ops
@@ -45,6 +47,21 @@ class DecoderProgram:
                         out=Linear(P, p + '1.output.dense.weight', p + '1.output.dense.bias'), ln=LN(P, p + '1.output.LayerNorm', eps)),
                 ad=dict(down=Linear(P, p + '2.adaptor.down_proj.weight', p + '2.adaptor.down_proj.bias'),
                         up=Linear(P, p + '2.adaptor.up_proj.weight', p + '2.adaptor.up_proj.bias'), ln=LN(P, p + '2.adaptor_ln', 1e-5))))
+        # all cross-attention K/V projections read the same encoder output: when the store placed them back-to-back
+        # (store._reorder_qkv) they are ONE linear of 2*H*layers output features -- forward, dgrad and wgrad
+        self.kv_all = None
+        if self.layers:
+            L = len(self.layers)
+            k0 = 'roberta.encoder.layer.0.1.self.key.'
+            o = P.offset
+            ok = all(o[f'roberta.encoder.layer.{l}.1.self.key.weight'] - o[k0 + 'weight'] == 2 * l * H * Hv and
+                     o[f'roberta.encoder.layer.{l}.1.self.value.weight'] - o[k0 + 'weight'] == (2 * l + 1) * H * Hv and
+                     o[f'roberta.encoder.layer.{l}.1.self.key.bias'] - o[k0 + 'bias'] == 2 * l * H and
+                     o[f'roberta.encoder.layer.{l}.1.self.value.bias'] - o[k0 + 'bias'] == (2 * l + 1) * H for l in range(L))
+            same = len({P.is_trainable(f'roberta.encoder.layer.{l}.1.self.{w}.{t}') for l in range(L) for w in ('key', 'value')
+                        for t in ('weight', 'bias')}) == 1
+            if ok and same and os.environ.get('PRISMER_MERGED_KV', '1') != '0':      # (env: A/B switch)
+                self.kv_all = Linear(P, k0 + 'weight', k0 + 'bias', rows=2 * H * L, cols=Hv)
         p = 'roberta.encoder.output_layer.'
         self.final = dict(idx=d.num_hidden_layers, sa=self_attn(p + 'attention.'), mlp=mlp(p))
         self.head_dense = Linear(P, 'lm_head.dense.weight', 'lm_head.dense.bias')
@@ -109,8 +126,8 @@ class DecoderProgram:
         if kv is None:
             kv = blk['kv'].fwd(enc)
         elif kv_ready is not None:
-            torch.cuda.current_stream().wait_event(kv_ready)       # K/V projection of this layer ran on the branch stream
-        ks = (S * 2 * H, 2 * H)
+            torch.cuda.current_stream().wait_event(kv_ready)       # the K/V projections ran on the branch stream
+        ks = (S * kv.stride(0), kv.stride(0))                      # kv may be a column slice of the all-layers buffer
         dr_a = self.drop(li * 16 + 3, d.attention_probs_dropout_prob, seed)
         o, lse = ops.attention_fwd(q, kv[:, :H], kv[:, H:], B, nh, T, S, dh, q_strides=(T * H, H), k_strides=ks, v_strides=ks, drop=dr_a)
         dr_h = self.drop(li * 16 + 4, d.hidden_dropout_prob, seed)
@@ -120,7 +137,9 @@ class DecoderProgram:
             sv.append(dict(h=h, q=q, kv=kv, o=o, lse=lse, s=s, m=m, r=r, dr_a=dr_a, dr_h=dr_h))
         return y, yf
 
-    def cross_attn_bwd(self, blk, s, dy, enc, denc, B, T, S):
+    def cross_attn_bwd(self, blk, s, dy, enc, denc, B, T, S, dkv=None):
+        """dkv: this layer's column slice of the all-layers dK/dV buffer (merged projection: its dgrad / wgrad run once,
+        after the last layer); None: per-layer K/V linear, d(enc) accumulated into the fp32 buffer `denc`."""
         d = self.d
         H, nh = d.hidden_size, d.num_attention_heads
         dh = H // nh
@@ -128,16 +147,20 @@ class DecoderProgram:
         do = blk['out'].dgrad(dsd)
         blk['out'].wgrad(dsd, s['o'])
         dq = torch.empty_like(s['q'])
-        dkv = torch.empty_like(s['kv'])
-        ks = (S * 2 * H, 2 * H)
-        ops.attention_bwd(do, s['q'], s['kv'][:, :H], s['kv'][:, H:], s['o'], s['lse'], B, nh, T, S, dh, q_strides=(T * H, H), k_strides=ks,
-                          v_strides=ks, dq=dq, dk=dkv[:, :H], dv=dkv[:, H:], dq_strides=(T * H, H), dk_strides=ks, dv_strides=ks,
+        merged = dkv is not None
+        if not merged:
+            dkv = torch.empty(s['kv'].shape, dtype=BF16, device=dy.device)
+        kv = s['kv']
+        ks, dks = (S * kv.stride(0), kv.stride(0)), (S * dkv.stride(0), dkv.stride(0))
+        ops.attention_bwd(do, s['q'], kv[:, :H], kv[:, H:], s['o'], s['lse'], B, nh, T, S, dh, q_strides=(T * H, H), k_strides=ks,
+                          v_strides=ks, dq=dq, dk=dkv[:, :H], dv=dkv[:, H:], dq_strides=(T * H, H), dk_strides=dks, dv_strides=dks,
                           drop=s['dr_a'])
         blk['q'].wgrad(dq, s['h'])
-        blk['kv'].wgrad(dkv, enc)
-        # d(enc) is only needed after the last layer: its 12 accumulating GEMMs leave the critical path (fp32 accumulate,
-        # serialised on the side stream)
-        ops.off_critical_path(lambda: blk['kv'].dgrad(dkv, out=denc, out_f32=True, accumulate=True), dkv)
+        if not merged:
+            blk['kv'].wgrad(dkv, enc)
+            # d(enc) is only needed after the last layer: its accumulating GEMMs leave the critical path (fp32 accumulate,
+            # serialised on the side stream)
+            ops.off_critical_path(lambda: blk['kv'].dgrad(dkv, out=denc, out_f32=True, accumulate=True), dkv)
         return blk['q'].dgrad(dq, residual=ds)
 
     def adaptor_fwd(self, blk, h, hf, sv):
@@ -196,7 +219,21 @@ class DecoderProgram:
         # the K/V projections of all cross-attention layers depend on `enc` only: issue them up front on a branch stream
         # (12 x [B*S, 2H] GEMMs that overlap the latency-bound decoder chain); each layer waits on its own event.
         kvs, kv_evs = [None] * len(self.layers), [None] * len(self.layers)
-        if self.kv_prefetch and isinstance(ops.POOL, ops.BranchPool):
+        branch = self.kv_prefetch and isinstance(ops.POOL, ops.BranchPool)
+        if self.kv_all is not None:                      # ONE [B*S, 2H*layers] GEMM; every layer reads its column slice
+            def all_kv():
+                return self.kv_all.fwd(enc2)
+            if branch:
+                with ops.POOL.branch(0):
+                    kva = all_kv()
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream())
+                ops.POOL.used.clear()                    # joined through the event the first cross-attention waits on
+                kv_evs[0] = ev
+            else:
+                kva = all_kv()
+            kvs = [kva[:, 2 * H * i:2 * H * (i + 1)] for i in range(len(self.layers))]
+        elif branch:
             with ops.POOL.branch(0):
                 for i, L in enumerate(self.layers):
                     kvs[i] = L['ca']['kv'].fwd(enc2)
@@ -250,14 +287,20 @@ class DecoderProgram:
         self.head_dense.wgrad(dt0pre, sv['hL'])
         dh = self.head_dense.dgrad(dt0pre)
         blocks = list(sv['blocks'])
-        denc = torch.zeros(B * S, d.vision_hidden_size, dtype=F32, device=dh.device)
+        H = d.hidden_size
+        nl = len(self.layers)
+        merged = self.kv_all is not None and nl > 0
+        denc = None if merged else torch.zeros(B * S, d.vision_hidden_size, dtype=F32, device=dh.device)
+        dkv_all = torch.empty(B * S, 2 * H * nl, dtype=BF16, device=dh.device) if merged else None
         F_ = self.final
         dh = self.mlp_bwd(F_['mlp'], blocks.pop(), dh)
         dh = self.self_attn_bwd(F_['sa'], blocks.pop(), dh, B, T, sv['key_mask'])
-        for L in reversed(self.layers):
+        for li in range(nl - 1, -1, -1):
+            L = self.layers[li]
             dh = self.mlp_bwd(L['mlp'], blocks.pop(), dh)
             dh = self.adaptor_bwd(L['ad'], blocks.pop(), dh)
-            dh = self.cross_attn_bwd(L['ca'], blocks.pop(), dh, sv['enc'], denc, B, T, S)
+            dh = self.cross_attn_bwd(L['ca'], blocks.pop(), dh, sv['enc'], denc, B, T, S,
+                                     dkv=dkv_all[:, 2 * H * li:2 * H * (li + 1)] if merged else None)
             dh = self.self_attn_bwd(L['sa'], blocks.pop(), dh, B, T, sv['key_mask'])
         # The tied word-embedding gradient has two writers, the LM-head wgrad GEMM (read-modify-write tiles) and these
         # scatter-adds: both live on the side stream, whose order serialises them (also across micro-batches).
@@ -270,5 +313,9 @@ class DecoderProgram:
         # caller's ops.join_side() -- this program never makes its own stream wait for the side stream (under stream capture
         # a forked stream that re-joins work it forked itself crashes this ROCm's capture_end; only the origin may join).
         denc_b = torch.empty(B * S, d.vision_hidden_size, dtype=BF16, device=dh.device)
-        ops.off_critical_path(lambda: ops.cast_to_bf16(denc, out=denc_b), denc, denc_b)
+        if merged:               # d(enc) = dKV_all . W_all (K = 2H*layers: fp32 accumulation inside ONE GEMM), dW_all = dKV_all^T enc
+            self.kv_all.wgrad(dkv_all, sv['enc'])
+            ops.off_critical_path(lambda: self.kv_all.dgrad(dkv_all, out=denc_b), dkv_all, denc_b)
+        else:
+            ops.off_critical_path(lambda: ops.cast_to_bf16(denc, out=denc_b), denc, denc_b)
         return denc_b.view(B, S, d.vision_hidden_size)

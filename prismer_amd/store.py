@@ -22,17 +22,38 @@ from . import ops
 ALIGN = 64   # elements: keeps every view 128-B (bf16) / 256-B (fp32) aligned
 
 
+_CROSS_KEY = re.compile(r'(.*\.layer)\.(\d+)\.1\.self\.key\.weight$')
+
+
 def _reorder_qkv(names):
-    """[..self.query.weight, ..self.query.bias, ..self.key.weight, ..] -> weights (q,k,v) then biases (q,k,v)."""
+    """[..self.query.weight, ..self.query.bias, ..self.key.weight, ..] -> weights (q,k,v) then biases (q,k,v).
+    Cross-attention K/V projections (encoder.layer.{l}.1.self.{key,value}) of ALL layers are additionally placed
+    back-to-back -- [k0,v0,k1,v1,...] weights, then the same for biases: they all project the same encoder output, so
+    the decoder program runs them (and their dgrad / wgrad) as ONE GEMM of N = 2*H*layers (roberta.py:88-92 x 12)."""
     out, used = [], set()
+    cross = [m for m in (_CROSS_KEY.match(n) for n in names) if m]
+    if cross:
+        pre = cross[0].group(1)
+        layers = sorted(int(m.group(2)) for m in cross)
+        grp = [f'{pre}.{l}.1.self.{w}.{s}' for s in ('weight', 'bias') for l in layers for w in ('key', 'value')]
+        if all(g in names for g in grp):
+            cross_grp, cross_at = grp, f'{pre}.{layers[0]}.1.self.key.weight'
+            used.update(grp)
+        else:
+            cross_grp, cross_at = None, None
+    else:
+        cross_grp, cross_at = None, None
     for n in names:
+        if n == cross_at:
+            out += cross_grp
+            continue
         if n in used:
             continue
         m = re.match(r'(.*\.self)\.query\.weight$', n)
         if m:
             p = m.group(1)
             grp = [f'{p}.{w}.{s}' for s in ('weight', 'bias') for w in ('query', 'key', 'value')]
-            if all(g in names for g in grp):
+            if all(g in names and g not in used for g in grp):
                 out += grp
                 used.update(grp)
                 continue
