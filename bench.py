@@ -226,9 +226,11 @@ def main():
         'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
         'data': 'synthetic',
-        'config': {'workload': 'Prismer-BASE caption fine-tune step (fwd+bwd+allreduce+AdamW), 224^2, 6 experts + Resampler, T=30, '
-                               'freeze_vision, dropout 0.1, train-mode BatchNorm',
-                   'model': 'prismer_base' if args.workload == 'base_caption' else 'prismer_large (VQA, 480^2, T=40)', 'global_batch': world * args.batch, 'seq_len': dims.seq_len, 'text_len': 30,
+        'config': {'workload': ('Prismer-BASE caption fine-tune step (fwd+bwd+allreduce+AdamW), 224^2, 6 experts + Resampler, T=30, '
+                                'freeze_vision, dropout 0.1, train-mode BatchNorm') if args.workload == 'base_caption' else
+                               ('Prismer-LARGE VQAv2 fine-tune step (fwd+bwd+allreduce+AdamW), 480^2, 6 experts + Resampler, T=35+5, '
+                                'freeze_vision, weighted loss, dropout 0.1, train-mode BatchNorm'),
+                   'model': 'prismer_base' if args.workload == 'base_caption' else 'prismer_large (VQA, 480^2, T=40)', 'global_batch': world * args.batch, 'seq_len': dims.seq_len, 'text_len': 30 if args.workload == 'base_caption' else 40,
                    'parallelism': f'dp{world}', 'trainable_params': n_train, 'hip_graph': not args.no_graph,
                    'final_loss': round(final_loss, 4)},
         'step_tflops': round(value / world * gf_img / 1e3, 2),
