@@ -322,16 +322,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int block_i
 
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int wm = wave >> 1, wn = wave & 1;
-#ifdef PH_GEMM_STAGGER   // experiment: put the two co-resident blocks of a CU in anti-phase (one computes while the other stores)
-  if (nt > 2 * 512 && block_id < 512 && nsplits == 1) {
-    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_ID.WAVE_ID
-    if (slot & 1) {
-      const long long t0 = __builtin_readcyclecounter();
-      const long long wait = (long long)(kt_end - kt_begin) * PH_GEMM_STAGGER;      // shader clocks per k-tile
-      while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-    }
-  }
-#endif
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -360,28 +350,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int block_i
   auto compute = [&](int buf) {
     const char* la = smem + buf * STAGE;
     const char* lb = la + A_BYTES;
-#ifdef PH_GEMM_FRAG_PIPE   // experiment: fragments of step kk+1 are requested before the MFMAs of step kk
-    bf16x8 fx[2][TM], fw[2][TN];
-    auto frags = [&](int kk, bf16x8 (&ox)[TM], bf16x8 (&ow)[TN]) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        ox[i] = TA ? frag_ks<BM>(la, wm * WM + i * 32, kk, lane) : frag_kc(la, wm * WM + i * 32, kk, lane);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        ow[j] = TB ? frag_ks<BN>(lb, wn * WN + j * 32, kk, lane) : frag_kc(lb, wn * WN + j * 32, kk, lane);
-    };
-    frags(0, fx[0], fw[0]);
-    static_for(std::make_integer_sequence<int, BK / 16>{}, [&](auto idx) {
-      constexpr int kk = decltype(idx)::value;
-      if constexpr (kk + 1 < BK / 16) frags(kk + 1, fx[(kk + 1) & 1], fw[(kk + 1) & 1]);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[kk & 1][j], fx[kk & 1][i], acc[i][j], 0, 0, 0);
-    });
-    return;
-#endif
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
       bf16x8 fx[TM], fw[TN];
@@ -738,6 +706,11 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
         if (cost < best) { best = cost; BM = bm; splits = sp; }
       }
     }
+  }
+  {
+    static int force = -1;           // PH_GEMM_FORCE_TILE=64|128: tile-shape experiments (tools/ab_probe.py)
+    if (force < 0) { const char* e = getenv("PH_GEMM_FORCE_TILE"); force = e ? atoi(e) : 0; }
+    if (force == 64 || (force == 128 && a->M > 64 && a->N > 64)) { BM = force; if (a->split_k <= 0) splits = 1; }
   }
   if (splits > kt) splits = kt;
   p.tiles_m = ceil_div(a->M, BM); p.tiles_n = ceil_div(a->N, BM);
