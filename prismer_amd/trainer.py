@@ -9,9 +9,11 @@ with a hand-scheduled step that never enters autograd:
             overlapping the whole encoder backward)
     -> encoder program bwd -> (all-reduce of the encoder gradients) -> fused AdamW over the two flat buffers.
 
-The three compute segments are captured once into hipGraphs (torch.cuda.CUDAGraph) and replayed, so the ~2000 kernel
-launches of a step cost three graph launches on the host; the collectives stay outside the graphs (eager RCCL calls
-ordered by stream events), which keeps the multi-GPU path identical to the single-GPU one plus two all_reduce calls.
+The compute segments are captured once into hipGraphs (torch.cuda.CUDAGraph) and replayed, so the ~1100 kernel launches of
+a step cost a handful of graph launches on the host; the collectives stay outside the graphs (eager RCCL calls ordered by
+stream events), which keeps the multi-GPU path identical to the single-GPU one plus three all_reduce sweeps.  With more
+than one rank the encoder backward is cut after the trunk (Trainer._schedule): the trunk's gradients are exchanged while the
+stems' backward runs, only the stems' own gradients wait on the critical path.
 Data parallel semantics = DDP's: every rank holds all parameters, gradients are summed over ranks and divided by
 world size (folded into the AdamW kernel as grad_scale), BatchNorm uses per-rank batch statistics (no SyncBN in the
 reference).  DDP's per-step buffer broadcast from rank 0 is replaced by rank-local BN running statistics
@@ -96,16 +98,16 @@ class Trainer:
             for b in mod.buffers():
                 torch.distributed.broadcast(b, 0, group=self.pg)
 
-    def _allreduce_async(self, flat, n):
-        """bucketed SUM all-reduce of flat[:n] on the communication stream, after everything queued so far on the
-        compute stream (the gradients are complete by then)."""
-        if self.world == 1:
+    def _allreduce_async(self, flat, n, start=0):
+        """bucketed SUM all-reduce of flat[start:n] on the communication stream, after everything queued so far on the
+        compute stream (those gradients are complete by then)."""
+        if self.world == 1 or n <= start:
             return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self.comm_stream.wait_event(ev)
         with torch.cuda.stream(self.comm_stream):
-            bucketed_all_reduce(flat, n, self.bucket_elems, self.pg)
+            bucketed_all_reduce(flat[start:n], n - start, self.bucket_elems, self.pg)
 
     def _wait_comm(self):
         if self.world > 1:
@@ -147,26 +149,70 @@ class Trainer:
         ops.join_side()
         self.loss_buf = torch.stack(losses).sum() / B
 
-    def _seg_enc_backward(self):
+    def _seg_enc_trunk_backward(self):
         ep = self.enc_prog
         d = ep.d
         S, Mx = d.seq_len, d.num_expert_tokens
         parts = [(sv['B']) for sv in self.sv_t]
         B = sum(parts)
         dev = self.denc[0].device
-        dh = torch.empty(B * S, d.width, dtype=BF16, device=dev)
-        dxf = torch.empty(B * Mx, d.width, dtype=BF16, device=dev) if self.sv_t[0]['has_x'] else None
+        self.dh = torch.empty(B * S, d.width, dtype=BF16, device=dev)
+        self.dxf = torch.empty(B * Mx, d.width, dtype=BF16, device=dev) if self.sv_t[0]['has_x'] else None
         b0 = 0
         for mi, Bh in enumerate(parts):
             b1 = b0 + Bh
             with (ops.MICRO.branch(mi) if len(parts) > 1 else contextlib.nullcontext()):
-                ep.backward_trunk(self.sv_t[mi], self.denc[mi], dh[b0 * S:b1 * S], None if dxf is None else dxf[b0 * Mx:b1 * Mx])
+                ep.backward_trunk(self.sv_t[mi], self.denc[mi], self.dh[b0 * S:b1 * S],
+                                  None if self.dxf is None else self.dxf[b0 * Mx:b1 * Mx])
             b0 = b1
         if len(parts) > 1:
             ops.MICRO.join()
-        ep.backward_front(self.sv_f, dh, dxf)
+        self.sv_t = self.denc = None
+
+    def _seg_enc_front_backward(self):
+        self.enc_prog.backward_front(self.sv_f, self.dh, self.dxf)
         ops.join_side()
-        self.sv_t = self.sv_f = self.denc = None
+        self.sv_f = self.dh = self.dxf = None
+
+    def _seg_enc_backward(self):
+        self._seg_enc_trunk_backward()
+        self._seg_enc_front_backward()
+
+    def _seg_enc_trunk_backward_joined(self):
+        self._seg_enc_trunk_backward()
+        ops.join_side()                                        # trunk gradients complete: their all-reduce may start
+
+    def _schedule(self):
+        """[(compute segment, collective issued right after it)].  One rank: forward + decoder backward | encoder backward |
+        AdamW.  Data parallel: the encoder backward is cut after the trunk, so that the all-reduce of the trunk's gradients
+        (adaptors, resampler: the tail of the encoder's flat buffer) overlaps the stems' backward and only the stems' own
+        gradients (the head of the buffer) are exchanged on the critical path."""
+        enc, dec = self.stores
+        if self.world == 1:
+            return [(lambda: self._seg_forward_dec_backward(self.static), None), (self._seg_enc_backward, None),
+                    (self._seg_optimizer, None)]
+        cut = self._trunk_grad_start()
+        return [(lambda: self._seg_forward_dec_backward(self.static), lambda: self._allreduce_async(dec.grad, dec.n_train)),
+                (self._seg_enc_trunk_backward_joined, lambda: self._allreduce_async(enc.grad, enc.n_train, cut)),
+                (self._seg_enc_front_backward, lambda: (self._allreduce_async(enc.grad, cut), self._wait_comm())),
+                (self._seg_optimizer, None)]
+
+    def _trunk_grad_start(self):
+        """offset in the encoder's flat gradient buffer where the parameters whose gradients are complete after the trunk
+        backward begin (transformer.* adaptors, resampler.*, ln_pre / ln_post); everything before it (positional / instance
+        embeddings, conv1.* stems) is written by the front backward."""
+        st = self.stores[0]
+        front = ('positional_embedding', 'instance_embedding', 'conv1.')
+        cut, seen_trunk = st.n_train, False
+        for n in st.names:
+            if not st.is_trainable(n):
+                continue
+            is_front = n.startswith(front)
+            if not is_front and not seen_trunk:
+                cut, seen_trunk = st.offset[n], True
+            elif is_front and seen_trunk:
+                return 0                                       # interleaved layout: no overlap, exchange everything at the end
+        return cut
 
     def _seg_optimizer(self):
         for st, m, v in zip(self.stores, self.m, self.v):
@@ -227,25 +273,22 @@ class Trainer:
         with torch.cuda.stream(side):                           # warm-up outside capture (allocations, lazily built shadows)
             for _ in range(2):
                 self._host_prologue()
-                self._seg_forward_dec_backward(s)
-                self._allreduce_async(self.stores[1].grad, self.stores[1].n_train)
-                self._seg_enc_backward()
-                self._allreduce_async(self.stores[0].grad, self.stores[0].n_train)
-                self._wait_comm()
-                self._seg_optimizer()
+                for seg, coll in self._schedule():
+                    seg()
+                    if coll is not None:
+                        coll()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
-        g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # thread_local: RCCL's watchdog thread polls events while we capture (world > 1); only this thread's calls are policed
         mode = dict(capture_error_mode='thread_local')
-        with torch.cuda.graph(g1, pool=pool, **mode):
-            self._seg_forward_dec_backward(s)
-        with torch.cuda.graph(g2, pool=pool, **mode):
-            self._seg_enc_backward()
-        with torch.cuda.graph(g3, pool=pool, **mode):
-            self._seg_optimizer()
-        self.graphs = (g1, g2, g3)
+        graphs = []
+        for seg, coll in self._schedule():
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, **mode):
+                seg()
+            graphs.append((g, coll))
+        self.graphs = graphs
 
     def step(self):
         """one optimisation step on the bound batch; returns the (device) scalar loss tensor without synchronising."""
@@ -261,20 +304,15 @@ class Trainer:
                 ops.join_side()
         self._host_prologue()
         if self.use_graph:
-            g1, g2, g3 = self.graphs
-            g1.replay()
-            self._allreduce_async(self.stores[1].grad, self.stores[1].n_train)
-            g2.replay()
-            self._allreduce_async(self.stores[0].grad, self.stores[0].n_train)
-            self._wait_comm()
-            g3.replay()
+            for g, coll in self.graphs:
+                g.replay()
+                if coll is not None:
+                    coll()
         else:
-            self._seg_forward_dec_backward(self.static)
-            self._allreduce_async(self.stores[1].grad, self.stores[1].n_train)
-            self._seg_enc_backward()
-            self._allreduce_async(self.stores[0].grad, self.stores[0].n_train)
-            self._wait_comm()
-            self._seg_optimizer()
+            for seg, coll in self._schedule():
+                seg()
+                if coll is not None:
+                    coll()
         return self.loss_buf
 
     def state_dict(self):
