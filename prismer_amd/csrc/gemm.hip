@@ -686,7 +686,7 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
   // pick (tile, split) by a small cost model calibrated on the MI355X microbenchmarks (profiles/r1_*): a k-tile
   // iteration costs ~1.5 us for co-resident 128x128 blocks (2 per CU) and ~0.5 us for 64x64 blocks (4 per CU);
   // a split adds the reduce launch (~4 us) plus splits*M*N*4 bytes of partial traffic.
-  int BM = 128, splits = 1;
+  int BM = 128, BN = 0, splits = 1;      // BN = 0: square tile
   if (a->split_k > 0) {
     splits = a->split_k;
     if (a->M <= 64 || a->N <= 64 || t128 * splits < 128) BM = 64;
@@ -711,9 +711,14 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
     static int force = -1;           // PH_GEMM_FORCE_TILE=64|128: tile-shape experiments (tools/ab_probe.py)
     if (force < 0) { const char* e = getenv("PH_GEMM_FORCE_TILE"); force = e ? atoi(e) : 0; }
     if (force == 64 || (force == 128 && a->M > 64 && a->N > 64)) { BM = force; if (a->split_k <= 0) splits = 1; }
+    if (force == 12864 && a->M > 64) { BM = 128; BN = 64; if (a->split_k <= 0) splits = 1; }
   }
   if (splits > kt) splits = kt;
-  p.tiles_m = ceil_div(a->M, BM); p.tiles_n = ceil_div(a->N, BM);
+  // N = 64 mod 128 and narrow (the stems' N = 192 convs): 128x64 tiles cover N exactly instead of wasting half a column tile
+  // (100352x192x864: 71 -> 66 us); on every other shape the narrower wave tile (one B fragment per two MFMAs) loses
+  if (BN == 0 && BM == 128 && splits == 1 && a->N % 128 == 64 && a->N <= 192) BN = 64;
+  if (BN == 0) BN = BM;
+  p.tiles_m = ceil_div(a->M, BM); p.tiles_n = ceil_div(a->N, BN);
   p.k_tiles_per_split = ceil_div(kt, splits);
   splits = ceil_div(kt, p.k_tiles_per_split);
   p.ws = nullptr; p.ldws = ldws;
@@ -721,9 +726,9 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
     if (ws_fits(splits)) p.ws = (float*)a->workspace;
     else PH_CHECK_ARG(plain_acc, "ph_gemm_bf16: split_k > 1 without workspace needs out_f32 + accumulate and no fused epilogue");
   }
-  const bool small = BM == 64;
-  int rc = small ? dispatch_layout<64, 64>(p, a->trans_a, a->trans_b, splits, stream)
-                 : dispatch_layout<128, 128>(p, a->trans_a, a->trans_b, splits, stream);
+  int rc = BM == 64 ? dispatch_layout<64, 64>(p, a->trans_a, a->trans_b, splits, stream)
+           : BN == 64 ? dispatch_layout<128, 64>(p, a->trans_a, a->trans_b, splits, stream)
+                      : dispatch_layout<128, 128>(p, a->trans_a, a->trans_b, splits, stream);
   if (rc != PH_OK || !p.ws) return rc;
   int grid = (int)min((int64_t)2048, ceil_div64((int64_t)a->M * ((a->N + 3) / 4), 256));
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, p, splits);
