@@ -230,8 +230,10 @@ int ph_ce_bwd(void* logits, int ld, const int64_t* labels, int B, int T, int V, 
 /* torch.optim.AdamW step (train_caption.py:111-112,133) over a flat fp32 range; also refreshes the bf16 shadow.
  * lr and step are read from device memory (hipGraph replays see new values): hyper[0] = lr, hyper[1] = bias
  * correction1 = 1-b1^t, hyper[2] = bias correction2 = 1-b2^t. grad_scale multiplies g first (1/world). */
-int ph_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const float* hyper, float beta1,
-             float beta2, float eps, float weight_decay, float grad_scale, hipStream_t stream);
+int ph_adamw(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, const float* hyper, float beta1,
+             float beta2, float eps, float weight_decay, float grad_scale, int zero_grad, hipStream_t stream);
+/* zero_grad != 0: g is overwritten with zeros after it has been read (the next step's optimizer.zero_grad(), without a
+ * separate pass over the 1 GB gradient buffers) */
 int ph_cast_f32_to_bf16(const float* x, void* y, int64_t n, hipStream_t stream);
 int ph_cast_bf16_to_f32(const void* x, float* y, int64_t n, hipStream_t stream);
 /* out[n] += sum_m x[m,n]  (bias gradients) */

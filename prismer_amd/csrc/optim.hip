@@ -8,14 +8,14 @@ namespace {
 // torch.optim.AdamW:  p *= 1 - lr*wd ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
 //                     p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 // HBM-bound: 16 B read + 14 B written per parameter.
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16* __restrict__ pb, int64_t n, const float* __restrict__ hyper,
-                                                    float b1, float b2, float eps, float wd, float gscale) {
+                                                    float b1, float b2, float eps, float wd, float gscale, int zero_g) {
   const float lr = hyper[0], bc1 = hyper[1], bc2 = hyper[2];
   const float step = lr / bc1, rbc2 = rsqrtf(bc2), decay = 1.f - lr * wd;
   int64_t n4 = n >> 2;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    f32x4 tp = reinterpret_cast<f32x4*>(p)[i], tg = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 tp = reinterpret_cast<f32x4*>(p)[i], tg = reinterpret_cast<f32x4*>(g)[i];
     f32x4 tm = reinterpret_cast<f32x4*>(m)[i], tv = reinterpret_cast<f32x4*>(v)[i];
     bf16x4 ob;
 #pragma unroll
@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     reinterpret_cast<f32x4*>(m)[i] = tm;
     reinterpret_cast<f32x4*>(v)[i] = tv;
     if (pb) reinterpret_cast<bf16x4*>(pb)[i] = ob;
+    if (zero_g) reinterpret_cast<f32x4*>(g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};      // optimizer.zero_grad() of the NEXT step
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     int64_t i = (n4 << 2) + threadIdx.x;
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     pp -= step * mm / (sqrtf(vv) * rbc2 + eps);
     p[i] = pp; m[i] = mm; v[i] = vv;
     if (pb) pb[i] = f2bf(pp);
+    if (zero_g) g[i] = 0.f;
   }
 }
 
@@ -236,13 +238,13 @@ inline int grid_for(int64_t work_items) { return (int)std::min<int64_t>(ceil_div
 
 }  // namespace
 
-extern "C" int ph_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const float* hyper, float beta1,
-                        float beta2, float eps, float weight_decay, float grad_scale, hipStream_t stream) {
+extern "C" int ph_adamw(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, const float* hyper, float beta1,
+                        float beta2, float eps, float weight_decay, float grad_scale, int zero_grad, hipStream_t stream) {
   PH_CHECK_ARG(p && g && m && v && hyper && n > 0, "ph_adamw: bad args");
   ProfScope prof__(PH_FAM_OPTIM, 0.0, 30.0 * (double)n, stream);
   PH_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && (((uintptr_t)p_bf16) & 7) == 0, "ph_adamw: misaligned");
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, stream, p, g, m, v, (bf16*)p_bf16, n, hyper, beta1, beta2, eps,
-                     weight_decay, grad_scale);
+                     weight_decay, grad_scale, zero_grad);
   PH_LAUNCH_CHECK("adamw_kernel");
   return PH_OK;
 }

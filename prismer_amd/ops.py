@@ -520,9 +520,9 @@ def ce_bwd(logits, labels, B, T, V, eps, row_lse, dloss):
 
 # ---------------------------------------------------------------------------------------------- utilities
 
-def adamw(p, g, m, v, p_bf16, n, hyper, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.05, grad_scale=1.0):
+def adamw(p, g, m, v, p_bf16, n, hyper, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.05, grad_scale=1.0, zero_grad=False):
     check(lib.ph_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), ptr(p_bf16), n, hyper.data_ptr(), beta1, beta2, eps,
-                       weight_decay, grad_scale, _stream()), 'ph_adamw')
+                       weight_decay, grad_scale, int(zero_grad), _stream()), 'ph_adamw')
 
 
 def cast_to_bf16(x, out=None):

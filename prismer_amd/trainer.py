@@ -39,7 +39,7 @@ def cosine_lr(it, total, init_lr, min_lr):
 
 class Trainer:
     def __init__(self, model, lr=5e-5, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8, min_lr=0.0, total_steps=1000,
-                 task='caption', use_graph=True, process_group=None, bucket_mb=64, side_stream=True, micro_batches=1):
+                 task='caption', use_graph=True, process_group=None, bucket_mb=64, side_stream=True, micro_batches=1, keep_grads=False):
         self.model = model
         self.enc, self.dec = model.expert_encoder, model.text_decoder
         self.init_lr, self.min_lr, self.total_steps = lr, min_lr, total_steps
@@ -85,6 +85,8 @@ class Trainer:
             ops.POOL = ops.BranchPool(dev, 3)
             ops.MICRO = ops.BranchPool(dev, self.micro) if self.micro > 1 else ops._NoPool()
         self.loss = None
+        self._grads_clean = False
+        self.keep_grads = keep_grads           # True: gradients stay readable after step() (tests); False: AdamW zeroes them
         if self.world > 1:
             self.broadcast_parameters()
 
@@ -120,8 +122,12 @@ class Trainer:
         return [(cuts[i], cuts[i + 1]) for i in range(n)]
 
     def _seg_forward_dec_backward(self, s):
-        for st in self.stores:
-            st.grad.zero_()                                    # optimizer.zero_grad()
+        # optimizer.zero_grad(): the fused AdamW of the previous step already left the gradient buffers zeroed (they are
+        # allocated zeroed); only a step that did not end in _seg_optimizer (first step after an exception) needs the fill
+        if not self._grads_clean:
+            for st in self.stores:
+                st.grad.zero_()
+        self._grads_clean = False
         ep, dp = self.enc_prog, self.dec_prog
         d = ep.d
         S, Mx = d.seq_len, d.num_expert_tokens
@@ -217,9 +223,10 @@ class Trainer:
     def _seg_optimizer(self):
         for st, m, v in zip(self.stores, self.m, self.v):
             ops.adamw(st.master, st.grad, m, v, st.shadow, st.n_train, self.hyper, self.betas[0], self.betas[1], self.eps, self.wd,
-                      1.0 / self.world)
+                      1.0 / self.world, zero_grad=not self.keep_grads)
             st.refresh_derived()
         ops.advance_seed(self.seed)
+        self._grads_clean = not self.keep_grads
 
     def _host_prologue(self):
         """per-step host work: LR schedule (cosine per ITERATION, train_caption.py:127), Adam bias corrections and the

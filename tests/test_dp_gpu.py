@@ -44,7 +44,7 @@ def _worker(rank, world, port, use_graph, out):
         pass
     m = Holder(); m.expert_encoder, m.text_decoder = enc, dec
     tab = case.instance_table(x)
-    tr = Trainer(m, lr=1e-3, total_steps=10, use_graph=use_graph)
+    tr = Trainer(m, lr=1e-3, total_steps=10, use_graph=use_graph, keep_grads=True)
     assert tr.world == world
     tr.set_batch(T.to_dev(x), ids, mask, labels)
     orig = tr._host_prologue

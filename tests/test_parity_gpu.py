@@ -176,7 +176,7 @@ def test_trainer_step_matches_oracle_adamw():
     results = []
     for use_graph in (False, True):
         m, esd, dsd = make()
-        tr = Trainer(m, lr=1e-3, total_steps=10, use_graph=use_graph)
+        tr = Trainer(m, lr=1e-3, total_steps=10, use_graph=use_graph, keep_grads=True)
         tr.set_batch(to_dev(x), ids, mask, labels)
         random.seed(0)
         m.expert_encoder.instance_table = None
@@ -260,7 +260,7 @@ def test_trainer_micro_batch_branches_match_whole_batch():
         enc, dec, _, _ = build(case, p_drop=0.0)
         set_freeze(enc, dec)
         m = Holder(); m.expert_encoder, m.text_decoder = enc, dec
-        tr = Trainer(m, lr=0.0, weight_decay=0.0, total_steps=10, use_graph=use_graph, micro_batches=micro)
+        tr = Trainer(m, lr=0.0, weight_decay=0.0, total_steps=10, use_graph=use_graph, micro_batches=micro, keep_grads=True)
         tr.set_batch(to_dev(x4), ids4, mask4, labels4)
         assert len(tr._slices(4)) == micro
         m.expert_encoder.instance_table = None
