@@ -23,6 +23,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(ph_layernorm_fwd_args a) {
   const float* xf = reinterpret_cast<const float*>(a.x) + (size_t)row * a.D;
   float v[NCH][4];
   float s = 0.f;
+  f32x4 gam[NCH], bet[NCH];            // requested with the row: their latency hides behind the two reductions
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    int c = min(lane + 64 * i, nch - 1);
+    gam[i] = *reinterpret_cast<const f32x4*>(a.gamma + c * 4);
+    bet[i] = *reinterpret_cast<const f32x4*>(a.beta + c * 4);
+  }
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     int c = lane + 64 * i;
@@ -59,8 +66,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(ph_layernorm_fwd_args a) {
   for (int i = 0; i < NCH; ++i) {
     int c = lane + 64 * i;
     if (c < nch) {
-      f32x4 g = *reinterpret_cast<const f32x4*>(a.gamma + c * 4);
-      f32x4 b = *reinterpret_cast<const f32x4*>(a.beta + c * 4);
+      const f32x4 g = gam[i], b = bet[i];
       bf16x4 o;
       f32x4 of;
 #pragma unroll
