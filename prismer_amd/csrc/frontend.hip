@@ -78,6 +78,13 @@ __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ x
 }
 
 // ------------------------------------------------------------------------------------------------ im2col
+// id -> (id / d, id % d): 64-bit integer division costs ~100 instructions per element on the GPU; every index space of this
+// model fits 32 bits, so the (uniform) fast path divides unsigned 32-bit numbers
+__device__ __forceinline__ void divmod(int64_t id, int d, bool fits32, int64_t& q, int& r) {
+  if (fits32) { unsigned u = (unsigned)id, ud = (unsigned)d; q = u / ud; r = (int)(u % ud); }
+  else { q = id / d; r = (int)(id % d); }
+}
+
 // col[m][(ky*ks+kx)*C + c] = act(x[b][oy*s - pad + ky][ox*s - pad + kx][c]), zero outside / beyond K.
 // act = BN(scale, shift) + ReLU when bn_scale != NULL (the conv of vit.py:92-103 consumes relu(bn(prev))).
 template <bool VEC>
@@ -89,10 +96,14 @@ __global__ __launch_bounds__(256) void im2col_kernel(const bf16* __restrict__ x,
   if (VEC) {   // C % 8 == 0: one thread per 16-B chunk
     const int cpr = Kp / 8;
     int64_t total = (int64_t)B * Ho * Wo * cpr;
+    const bool f32 = total < (1ll << 31);
     for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
-      int ch = (int)(id % cpr);
-      int64_t m = id / cpr;
-      int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho), b = (int)(m / ((int64_t)Wo * Ho));
+      int ch, ox, oy;
+      int64_t m, t, bb;
+      divmod(id, cpr, f32, m, ch);
+      divmod(m, Wo, f32, t, ox);
+      divmod(t, Ho, f32, bb, oy);
+      const int b = (int)bb;
       int k = ch * 8;
       u32x4 v = {0u, 0u, 0u, 0u};
       if (k < K) {
@@ -136,10 +147,15 @@ __global__ __launch_bounds__(256) void col2im_kernel(const bf16* __restrict__ dc
   const int pad = ks / 2;
   const int cpr = C / 8;
   int64_t total = (int64_t)B * H * W * cpr;
+  const bool f32 = total < (1ll << 31);
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
-    int c = (int)(id % cpr) * 8;
-    int64_t pix = id / cpr;
-    int ix = (int)(pix % W), iy = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+    int c, ix, iy;
+    int64_t pix, t, bb;
+    divmod(id, cpr, f32, pix, c);
+    c *= 8;
+    divmod(pix, W, f32, t, ix);
+    divmod(t, H, f32, bb, iy);
+    const int b = (int)bb;
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
@@ -244,9 +260,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restric
   const int cpr = C / 8;
   int64_t total = M * cpr;
   float invM = 1.f / (float)M;
+  const bool f32 = total < (1ll << 31);
   for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
-    int c = (int)(id % cpr) * 8;
-    int64_t r = id / cpr;
+    int c;
+    int64_t r;
+    divmod(id, cpr, f32, r, c);
+    c *= 8;
     bf16x8 t = *reinterpret_cast<const bf16x8*>(y + r * C + c);
     bf16x8 d = *reinterpret_cast<const bf16x8*>(da + r * C + c);
     bf16x8 o;

@@ -167,6 +167,33 @@ def ln_suite():
         ab(f'ln bwd M={M} D={D} f32={int(f32)} +dskip', lambda: ops.layernorm_bwd(dy, xx, mean, rstd, g, dskip=dsk, dgamma=dg, dbeta=db, dx=dx))
 
 
+def front_suite():
+    """stem byte movers at the dense experts' layer-2 / layer-3 geometry (bs32)."""
+    dev = 'cuda'
+    import ctypes as Ct
+    from prismer_amd._lib import check
+    for (B, H, Cc, s_) in ((32, 112, 96, 2), (32, 56, 192, 2), (32, 28, 384, 2)):
+        Kp = 9 * Cc
+        x = torch.randn(B * H * H, Cc, device=dev).to(BF)
+        sc, sh = torch.rand(Cc, device=dev) + 0.5, torch.randn(Cc, device=dev) * 0.1
+        Ho = (H + 2 - 3) // s_ + 1
+        col = torch.empty(B * Ho * Ho, Kp, dtype=BF, device=dev)
+        dx = torch.empty(B * H * H, Cc, dtype=BF, device=dev)
+        ab(f'im2col {H}x{H}x{Cc} s{s_}', lambda: check(ops.lib.ph_im2col_nhwc(x.data_ptr(), col.data_ptr(), B, H, H, Cc, 3, s_, Kp, sc.data_ptr(),
+                                                                         sh.data_ptr(), ops._stream()), 'im2col'))
+        ab(f'col2im {H}x{H}x{Cc} s{s_}', lambda: check(ops.lib.ph_col2im_nhwc(col.data_ptr(), dx.data_ptr(), B, H, H, Cc, 3, s_, Kp, ops._stream()),
+                                                      'col2im'))
+        M = B * Ho * Ho
+        C2 = 2 * Cc
+        y = torch.randn(M, C2, device=dev).to(BF); da = torch.randn(M, C2, device=dev).to(BF)
+        g, b_ = torch.rand(C2, device=dev) + 0.5, torch.randn(C2, device=dev) * 0.1
+        rm, rv = torch.zeros(C2, device=dev), torch.ones(C2, device=dev)
+        st = ops.bn_stats(y, g, b_, rm, rv, True)
+        dg, db = torch.zeros(C2, device=dev), torch.zeros(C2, device=dev)
+        ab(f'bn_stats M={M} C={C2}', lambda: ops.bn_stats(y, g, b_, rm, rv, True))
+        ab(f'bn_relu_bwd M={M} C={C2}', lambda: ops.bn_relu_bwd(da, y, g, b_, st, dg, db))
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['gemm', 'attn', 'ln']
     print('libs:', [n for n, _ in LIBS])
@@ -178,3 +205,5 @@ if __name__ == '__main__':
         gemm_suite()
     if 'epi' in which:
         epi_suite()
+    if 'front' in which:
+        front_suite()
