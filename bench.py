@@ -190,10 +190,18 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback path exists)')
+    # PRISMER_DIST_BACKEND=gloo + PRISMER_ONE_DEVICE=1: dry run of the multi-rank path on a single GPU (RCCL refuses two ranks
+    # per device); the real launch uses the defaults: one GPU per rank, backend nccl (= RCCL)
+    backend = os.environ.get('PRISMER_DIST_BACKEND', 'nccl')
+    if os.environ.get('PRISMER_ONE_DEVICE', '0') != '0':
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            torch.distributed.init_process_group(backend)
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     tr, dims, n_train = build_trainer(args.batch, not args.no_graph, rank, workload=args.workload)
