@@ -87,3 +87,32 @@ def test_no_eager_fallback_on_cpu():
         dec(torch.zeros(1, 4, dtype=torch.long), encoder_hidden_states=torch.zeros(1, 16, 256))
     with pytest.raises(RuntimeError):
         enc.ln_pre(torch.zeros(2, 256))
+
+
+def test_store_layout_packs_qkv_and_all_cross_kv():
+    """ParamStore ordering (pure host logic): self-attention q/k/v of a layer adjacent (weights, then biases); the
+    cross-attention K/V projections of ALL layers adjacent ([k0,v0,k1,v1,...] weights, then biases) -- the decoder program
+    runs them as one linear (roberta.py:88-92 x num_hidden_layers)."""
+    from prismer_amd.store import _reorder_qkv
+    names = ['roberta.embeddings.word_embeddings.weight']
+    L = 3
+    for l in range(L):
+        p = f'roberta.encoder.layer.{l}.'
+        for a in ('0.attention.self.', '1.self.'):
+            for w in ('query', 'key', 'value'):
+                for t in ('weight', 'bias'):
+                    names.append(p + a + w + '.' + t)
+        names += [p + '0.attention.output.dense.weight', p + '2.adaptor.down_proj.weight']
+    order = _reorder_qkv(list(names))
+    assert sorted(order) == sorted(names) and len(set(order)) == len(names)          # a permutation
+    pos = {n: i for i, n in enumerate(order)}
+    for l in range(L):                                                               # packed self-attention q|k|v
+        sa = f'roberta.encoder.layer.{l}.0.attention.self.'
+        i0 = pos[sa + 'query.weight']
+        assert [order[i0 + j] for j in range(6)] == [sa + w + '.' + t for t in ('weight', 'bias') for w in ('query', 'key', 'value')]
+    k0 = pos['roberta.encoder.layer.0.1.self.key.weight']                            # all cross K/V back to back
+    want = [f'roberta.encoder.layer.{l}.1.self.{w}.{t}' for t in ('weight', 'bias') for l in range(L) for w in ('key', 'value')]
+    assert order[k0:k0 + len(want)] == want
+    # incomplete cross set (a layer without value.bias): falls back to leaving those names in place
+    broken = [n for n in names if n != 'roberta.encoder.layer.1.1.self.value.bias']
+    assert sorted(_reorder_qkv(list(broken))) == sorted(broken)
