@@ -194,6 +194,19 @@ def front_suite():
         ab(f'bn_relu_bwd M={M} C={C2}', lambda: ops.bn_relu_bwd(da, y, g, b_, st, dg, db))
 
 
+def tokens_suite():
+    dev = 'cuda'
+    B, G, D, tpb, off = 32, 196, 768, 1176, 392
+    dtok = torch.randn(B * tpb, D, device=dev).to(BF)
+    dfeat = torch.empty(B * G, D, dtype=BF, device=dev)
+    dpos = torch.zeros(G, D, device=dev)
+    ab('tokens_bwd 32x196x768 (no instance)', lambda: ops.tokens_finalize_bwd(dtok, dfeat, dpos, B, G, D, tpb, off))
+    inst = torch.randint(0, 12, (B, 1, 224, 224), device=dev)
+    table = torch.randint(0, 128, (256,), dtype=torch.int32, device=dev)
+    demb = torch.zeros(128, D, device=dev)
+    ab('tokens_bwd 32x196x768 (instance)', lambda: ops.tokens_finalize_bwd(dtok, dfeat, dpos, B, G, D, tpb, off, inst, 224, 14, table, demb))
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['gemm', 'attn', 'ln']
     print('libs:', [n for n, _ in LIBS])
@@ -207,3 +220,5 @@ if __name__ == '__main__':
         epi_suite()
     if 'front' in which:
         front_suite()
+    if 'tokens' in which:
+        tokens_suite()
