@@ -38,7 +38,8 @@ def make_inputs(dims, batch, T, seed, device):
     g = torch.Generator(device=device).manual_seed(seed)
     R, E = dims.image_resolution, dims.expert_resolution
     x = {'rgb': torch.randn(batch, 3, R, R, generator=g, device=device)}
-    names = ['depth', 'normal', 'seg_coco', 'edge', 'obj_detection', 'ocr_detection']
+    names = [n for n in ['depth', 'normal', 'seg_coco', 'edge', 'obj_detection', 'ocr_detection'] if n in dims.experts or
+             (n == 'seg_coco' and 'seg' in dims.experts)]
 
     def label_map():
         lab = torch.full((batch, E, E), 255, dtype=torch.int64, device=device)
@@ -68,7 +69,7 @@ def make_inputs(dims, batch, T, seed, device):
     return x, ids, mask, labels
 
 
-def build_trainer(batch, use_graph, rank, T=30, workload='base_caption'):
+def build_trainer(batch, use_graph, rank, T=30, workload='base_caption', freeze='freeze_vision'):
     from prismer_amd import config as pcfg
     from prismer_amd.model.prismer_caption import PrismerCaption
     from prismer_amd.model.prismer_vqa import PrismerVQA
@@ -79,9 +80,13 @@ def build_trainer(batch, use_graph, rank, T=30, workload='base_caption'):
         cfg = {'experts': pcfg.CAPTION_EXPERTS, 'image_resolution': 480, 'prismer_model': 'prismer_large', 'freeze': 'freeze_vision'}
         model = PrismerVQA(cfg).cuda()
         T = 40
+    elif workload == 'z_base_caption':                     # BASELINE config 2: PrismerZ-BASE (rgb only, no resampler)
+        dims = pcfg.prismerz_base()
+        cfg = {'experts': 'none', 'image_resolution': 224, 'prismer_model': 'prismer_base', 'freeze': freeze}
+        model = PrismerCaption(cfg).cuda()
     else:
         dims = pcfg.prismer_base()
-        cfg = {'experts': pcfg.CAPTION_EXPERTS, 'image_resolution': 224, 'prismer_model': 'prismer_base', 'freeze': 'freeze_vision'}
+        cfg = {'experts': pcfg.CAPTION_EXPERTS, 'image_resolution': 224, 'prismer_model': 'prismer_base', 'freeze': freeze}
         model = PrismerCaption(cfg).cuda()
     tr = Trainer(model, lr=5e-5, weight_decay=0.05, total_steps=10000, task='caption', use_graph=use_graph,
                  micro_batches=int(os.environ.get('PRISMER_MICRO_BATCHES', '1')),
@@ -178,7 +183,9 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=32)
-    ap.add_argument('--workload', default='base_caption', choices=['base_caption', 'large_vqa'],
+    ap.add_argument('--freeze', default='freeze_vision', choices=['freeze_vision', 'none'],
+                    help='freeze_vision = the shipped fine-tune setting (headline); none = all parameters trainable (secondary)')
+    ap.add_argument('--workload', default='base_caption', choices=['base_caption', 'large_vqa', 'z_base_caption'],
                     help='base_caption = the headline metric (BASELINE config 3/4); large_vqa = config 5 (secondary; use --batch 16)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -204,8 +211,11 @@ def main():
             torch.distributed.init_process_group(backend)
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
-    tr, dims, n_train = build_trainer(args.batch, not args.no_graph, rank, workload=args.workload)
-    gf_img = TRAIN_GF_PER_IMG if args.workload == 'base_caption' else 2987.8
+    tr, dims, n_train = build_trainer(args.batch, not args.no_graph, rank, workload=args.workload, freeze=args.freeze)
+    # algorithmic train GFLOP per image (SURVEY 8d / BASELINE.md section 2): (freeze_vision, none)
+    gf_img = {'base_caption': (TRAIN_GF_PER_IMG, 307.26), 'z_base_caption': (134.30, 167.59), 'large_vqa': (2987.8, 3724.7)}[args.workload][
+        0 if args.freeze == 'freeze_vision' else 1]
+    headline = args.workload == 'base_caption' and args.freeze == 'freeze_vision'
 
     def barrier():
         if world > 1:
@@ -229,22 +239,25 @@ def main():
     final_loss = float(loss.item())
 
     out = {
-        'metric': 'images/sec Prismer-BASE caption train, 224^2 + 6 experts, bs32/GPU' if args.workload == 'base_caption' else
-                  'images/sec Prismer-LARGE VQAv2 fine-tune, 480^2 + 6 experts, bs16/GPU',
+        'metric': {'base_caption': 'images/sec Prismer-BASE caption train, 224^2 + 6 experts, bs32/GPU',
+                   'z_base_caption': 'images/sec PrismerZ-BASE caption train, 224^2, rgb only, bs32/GPU',
+                   'large_vqa': 'images/sec Prismer-LARGE VQAv2 fine-tune, 480^2 + 6 experts, bs16/GPU'}[args.workload] +
+                  ('' if args.freeze == 'freeze_vision' else ' (freeze: none)'),
         'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
         'data': 'synthetic',
         'config': {'workload': ('Prismer-BASE caption fine-tune step (fwd+bwd+allreduce+AdamW), 224^2, 6 experts + Resampler, T=30, '
-                                'freeze_vision, dropout 0.1, train-mode BatchNorm') if args.workload == 'base_caption' else
+                                'freeze_vision, dropout 0.1, train-mode BatchNorm') if headline else
+                               f'{args.workload} fine-tune step (fwd+bwd+allreduce+AdamW), freeze={args.freeze}, dropout 0.1' if args.workload != 'large_vqa' else
                                ('Prismer-LARGE VQAv2 fine-tune step (fwd+bwd+allreduce+AdamW), 480^2, 6 experts + Resampler, T=35+5, '
                                 'freeze_vision, weighted loss, dropout 0.1, train-mode BatchNorm'),
-                   'model': 'prismer_base' if args.workload == 'base_caption' else 'prismer_large (VQA, 480^2, T=40)', 'global_batch': world * args.batch, 'seq_len': dims.seq_len, 'text_len': 30 if args.workload == 'base_caption' else 40,
+                   'model': {'base_caption': 'prismer_base', 'z_base_caption': 'prismerz_base', 'large_vqa': 'prismer_large (VQA, 480^2, T=40)'}[args.workload], 'global_batch': world * args.batch, 'seq_len': dims.seq_len, 'text_len': 30 if args.workload == 'base_caption' else 40,
                    'parallelism': f'dp{world}', 'trainable_params': n_train, 'hip_graph': not args.no_graph,
                    'final_loss': round(final_loss, 4)},
         'step_tflops': round(value / world * gf_img / 1e3, 2),
         'step_mfma_frac': round(value / world * gf_img / 1e3 / PEAK_TFLOPS, 4),
     }
-    if rank == 0 and world == 1 and args.workload != 'base_caption':
+    if rank == 0 and world == 1 and not headline:
         args.no_cpu_baseline = True                        # the CPU leg is defined on the headline workload only
     if rank == 0 and world == 1:
         if not args.no_roofline:
