@@ -94,6 +94,7 @@ def build_trainer(batch, use_graph, rank, T=30, workload='base_caption', freeze=
     from prismer_amd import ops as _ops
     _ops.WQ.enabled = os.environ.get('PRISMER_WGRAD_QUEUE', '1') != '0'      # A/B switch: grouped deferred wgrads
     _ops.WQ.eager_flush = os.environ.get('PRISMER_WGRAD_EAGER_FLUSH', '0') != '0'
+    _ops.WQ.bg_blocks = int(os.environ.get('PRISMER_WGRAD_BG_BLOCKS', '0'))       # with eager flush: capped background launches
     x, ids, mask, labels = make_inputs(dims, batch, T, 1234 + rank, torch.device('cuda'))
     weights = None
     if workload == 'large_vqa':
@@ -192,6 +193,20 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, rendezvous on
+        # 127.0.0.1) through torch.distributed.run and hand its exit code back; never degrade to a 1-rank run.
+        import socket
+        import subprocess
+        one_dev = os.environ.get('PRISMER_ONE_DEVICE', '0') != '0'
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_dev < args.gpus and not one_dev:
+            raise SystemExit(f'bench.py: --gpus {args.gpus} requested but {n_dev} GPU(s) visible; refusing to run fewer ranks')
+        sock = socket.socket(); sock.bind(('127.0.0.1', 0)); port = sock.getsockname()[1]; sock.close()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -209,7 +224,14 @@ def main():
             torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
         else:
             torch.distributed.init_process_group(backend)
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)')
+    ranks_seen = 1
+    if world > 1:                                          # proof that the collective transport spans all ranks
+        t = torch.ones(1, device='cuda')
+        torch.distributed.all_reduce(t)
+        ranks_seen = int(t.item())
+        assert ranks_seen == world, (ranks_seen, world)
 
     tr, dims, n_train = build_trainer(args.batch, not args.no_graph, rank, workload=args.workload, freeze=args.freeze)
     # algorithmic train GFLOP per image (SURVEY 8d / BASELINE.md section 2): (freeze_vision, none)
@@ -237,6 +259,8 @@ def main():
     ms = dt / args.steps * 1e3
     value = world * args.batch * args.steps / dt
     final_loss = float(loss.item())
+    if not args.no_graph and not (tr.use_graph and tr.graphs is not None):
+        raise SystemExit('bench.py: hipGraph replay was requested but the Trainer is running eager launches')
 
     out = {
         'metric': {'base_caption': 'images/sec Prismer-BASE caption train, 224^2 + 6 experts, bs32/GPU',
@@ -252,7 +276,9 @@ def main():
                                ('Prismer-LARGE VQAv2 fine-tune step (fwd+bwd+allreduce+AdamW), 480^2, 6 experts + Resampler, T=35+5, '
                                 'freeze_vision, weighted loss, dropout 0.1, train-mode BatchNorm'),
                    'model': {'base_caption': 'prismer_base', 'z_base_caption': 'prismerz_base', 'large_vqa': 'prismer_large (VQA, 480^2, T=40)'}[args.workload], 'global_batch': world * args.batch, 'seq_len': dims.seq_len, 'text_len': 30 if args.workload == 'base_caption' else 40,
-                   'parallelism': f'dp{world}', 'trainable_params': n_train, 'hip_graph': not args.no_graph,
+                   'parallelism': f'dp{world}', 'ranks_in_collective': ranks_seen, 'collective_backend': ('rccl' if backend == 'nccl' else backend) if world > 1 else None,
+                   'grad_exchange': tr.exchange_desc() if world > 1 else None,
+                   'trainable_params': n_train, 'hip_graph': bool(tr.use_graph and tr.graphs is not None),
                    'final_loss': round(final_loss, 4)},
         'step_tflops': round(value / world * gf_img / 1e3, 2),
         'step_mfma_frac': round(value / world * gf_img / 1e3 / PEAK_TFLOPS, 4),

@@ -33,7 +33,8 @@ typedef struct ihipStream_t* hipStream_t;
 #define PH_VERSION 100
 
 enum { PH_OK = 0, PH_ERR_BAD_ARG = -1, PH_ERR_UNSUPPORTED = -2, PH_ERR_LAUNCH = -3 };
-enum { PH_ACT_NONE = 0, PH_ACT_QUICKGELU = 1, PH_ACT_RELU2 = 2, PH_ACT_GELU = 3, PH_ACT_RELU = 4 };
+enum { PH_ACT_NONE = 0, PH_ACT_QUICKGELU = 1, PH_ACT_RELU2 = 2, PH_ACT_GELU = 3, PH_ACT_RELU = 4,
+       PH_ACT_SAVED_GRAD = 5 /* backward only: act_in already holds act'(x) (see pre_grad) */ };
 
 int ph_version(void);
 const char* ph_last_error(void);
@@ -64,6 +65,9 @@ typedef struct {
   int residual_f32;
   void* workspace; int64_t workspace_bytes;   /* optional fp32 scratch for split-K partials (deterministic reduce + full
                                      epilogue); without it only plain fp32-accumulate GEMMs are split (atomics) */
+  int pre_grad;                   /* pre_out receives act'(x) instead of x: the backward GEMM (act = PH_ACT_SAVED_GRAD) then
+                                     multiplies by the saved derivative -- no transcendental in its epilogue, and the
+                                     derivative is taken from the fp32 pre-activation instead of its bf16 rounding */
 } ph_gemm_args;
 int ph_gemm_bf16(const ph_gemm_args* args, hipStream_t stream);
 
@@ -73,6 +77,10 @@ int ph_gemm_bf16(const ph_gemm_args* args, hipStream_t stream);
  * cover 18..144 tiles each, far fewer than the chip holds, so the host side defers them and issues each layer's set at once. */
 #define PH_GEMM_GROUP_MAX 16
 int ph_gemm_grouped_bf16(const ph_gemm_args* args, int n, hipStream_t stream);
+/* same, as a BACKGROUND launch: at most `max_blocks` blocks (0 = one per tile), each walking several tiles.  Deferred weight
+ * gradients issued beside the latency-bound backward chain of the decoder (roberta.py:212-231 in reverse) then fill the
+ * idle CUs without taking every block slot from the chain's small kernels. */
+int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int max_blocks, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm (fp32 math, eps inside the sqrt).  Replaces model/modules/utils.py:14-19 (F.layer_norm in

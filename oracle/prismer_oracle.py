@@ -234,8 +234,10 @@ def text_decoder(sd, input_ids, attention_mask, enc, heads, labels=None, pad=1, 
         attention_mask = torch.ones_like(input_ids)
     am = extended_attention_mask(attention_mask, dtype)
     pos_ids = position_ids_from_input_ids(input_ids, pad)
-    h = sd[e + 'word_embeddings.weight'][input_ids] + sd[e + 'token_type_embeddings.weight'][0] \
-        + sd[e + 'position_embeddings.weight'][pos_ids]                          # roberta.py:66-73
+    # nn.Embedding(padding_idx=pad) (roberta.py:52,62): the pad row takes part in the forward but receives NO gradient from the
+    # lookup (it matters when a pad sits inside a row, e.g. between question and answer: prismer_vqa.py:22-30)
+    h = F.embedding(input_ids, sd[e + 'word_embeddings.weight'], padding_idx=pad) + sd[e + 'token_type_embeddings.weight'][0] \
+        + F.embedding(pos_ids, sd[e + 'position_embeddings.weight'], padding_idx=pad)      # roberta.py:66-73
     h = layer_norm(h, sd[e + 'LayerNorm.weight'], sd[e + 'LayerNorm.bias'])
     l = 0
     while f'roberta.encoder.layer.{l}.0.attention.self.query.weight' in sd:      # roberta.py:223-227

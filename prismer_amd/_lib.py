@@ -15,7 +15,7 @@ from . import build as _build
 c_void_p, c_int, c_float, c_i64, c_u32, c_u64 = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_uint32, C.c_uint64
 
 PH_OK = 0
-ACT_NONE, ACT_QUICKGELU, ACT_RELU2, ACT_GELU, ACT_RELU = 0, 1, 2, 3, 4
+ACT_NONE, ACT_QUICKGELU, ACT_RELU2, ACT_GELU, ACT_RELU, ACT_SAVED_GRAD = 0, 1, 2, 3, 4, 5
 
 
 class RowMap(C.Structure):
@@ -36,7 +36,7 @@ class GemmArgs(C.Structure):
                 ('residual', c_void_p), ('ldr', c_int),
                 ('drop_p', c_float), ('drop_seed', c_void_p), ('drop_stream', c_u32),
                 ('out_f32', c_int), ('accumulate', c_int), ('alpha', c_float), ('split_k', c_int),
-                ('residual_f32', c_int), ('workspace', c_void_p), ('workspace_bytes', c_i64)]
+                ('residual_f32', c_int), ('workspace', c_void_p), ('workspace_bytes', c_i64), ('pre_grad', c_int)]
 
 
 class LnReduceItem(C.Structure):
@@ -140,6 +140,7 @@ _SIGS = {
     'ph_conv_weight_to_shadow_grouped': (c_int, [c_void_p, c_int, c_void_p]),
     'ph_conv_grad_from_shadow_grouped': (c_int, [c_void_p, c_int, c_void_p]),
     'ph_gemm_grouped_bf16': (c_int, [c_void_p, c_int, c_void_p]),
+    'ph_gemm_grouped_capped_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p]),
     'ph_add_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     'ph_act_bwd_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     'ph_copy_rows_bf16': (c_int, [c_void_p, c_int, RowMap, c_void_p, c_int, RowMap, c_int, c_int, c_int, c_void_p]),

@@ -13,13 +13,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libprismer_hip.so')
+COMM_LIB = os.path.join(LIBDIR, 'libprismer_comm.so')     # RCCL gradient-exchange transport (include/prismer_comm.h), host code only
 SOURCES = ['core.hip', 'gemm.hip', 'norm.hip', 'attention.hip', 'frontend.hip', 'embed_loss.hip', 'optim.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-pass-failed']
 
 
 def _digest():
     h = hashlib.sha256()
-    for f in sorted(os.listdir(CSRC)) + ['../../include/prismer_hip.h']:
+    for f in sorted(os.listdir(CSRC)) + ['../../include/prismer_hip.h', '../../include/prismer_comm.h']:
         p = os.path.join(CSRC, f)
         if os.path.isfile(p):
             h.update(f.encode()); h.update(open(p, 'rb').read())
@@ -31,7 +32,7 @@ def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     stamp = os.path.join(LIBDIR, 'build.stamp')
     dig = _digest()
-    if not force and os.path.isfile(LIB) and os.path.isfile(stamp) and open(stamp).read() == dig:
+    if not force and os.path.isfile(LIB) and os.path.isfile(COMM_LIB) and os.path.isfile(stamp) and open(stamp).read() == dig:
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = []
@@ -49,6 +50,10 @@ def build(force=False, verbose=True):
     r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n' + r.stderr[-4000:])
+    r = subprocess.run([hipcc, '-O2', '-std=c++17', '-fPIC', '-shared', '-I/opt/rocm/include', os.path.join(CSRC, 'comm.cpp'), '-o', COMM_LIB,
+                        '-ldl'], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('hipcc failed on comm.cpp:\n' + r.stderr[-4000:])
     open(stamp, 'w').write(dig)
     if verbose:
         print(f'built {LIB} ({os.path.getsize(LIB) / 1e6:.1f} MB)')

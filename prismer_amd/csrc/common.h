@@ -101,6 +101,7 @@ __device__ __forceinline__ float act_grad(int act, float x) {
       return c + x * 0.3989422804014327f * e;
     }
     case PH_ACT_RELU: return x > 0.0f ? 1.0f : 0.0f;
+    case PH_ACT_SAVED_GRAD: return x;                               // the forward stored act'(x) itself (ph_gemm_args.pre_grad)
     default: return 1.0f;
   }
 }

@@ -55,7 +55,7 @@ struct GemmParams {
   const bf16* act_in; int ld_act;
   const bf16* residual; int ldr; int res_f32;
   float drop_p; const uint64_t* drop_seed; uint32_t drop_stream;
-  int act, out_f32, accumulate;
+  int act, out_f32, accumulate, pre_grad;
   float alpha;
   int k_tiles_per_split;   // in units of BK
   int tiles_m, tiles_n;
@@ -175,10 +175,13 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
   }
   if (p.pre_out) {
     bf16* q = p.pre_out + (size_t)m * p.ldc + n;
-    if (full) { bf16x4 t = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *reinterpret_cast<bf16x4*>(q) = t; }
+    float w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = p.pre_grad ? act_grad(p.act, v[e]) : v[e];
+    if (full) { bf16x4 t = {f2bf(w[0]), f2bf(w[1]), f2bf(w[2]), f2bf(w[3])}; *reinterpret_cast<bf16x4*>(q) = t; }
     else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) if (n + e < p.N) q[e] = f2bf(v[e]);
+      for (int e = 0; e < 4; ++e) if (n + e < p.N) q[e] = f2bf(w[e]);
     }
   }
   if (p.act_in) {       // backward through an activation: multiply by act'(saved pre-activation)
@@ -238,7 +241,7 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int m, int 
   if (p.pre_out) {
     bf16x8 t;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) t[e] = f2bf(v[e]);
+    for (int e = 0; e < 8; ++e) t[e] = f2bf(p.pre_grad ? act_grad(p.act, v[e]) : v[e]);
     *reinterpret_cast<bf16x8*>(p.pre_out + (size_t)m * p.ldc + n) = t;
   }
   if (p.act_in) {
@@ -480,16 +483,16 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int block_i
         if (n + 4 < p.N) epilogue_store(p, m, n + 4, v1, false, drop, dc);
       }
     }
-    return;
-  }
+  } else {
 #pragma unroll 4
-  for (int it = 0; it < BM * CH / 256; ++it) {
-    const int id = it * 256 + threadIdx.x;
-    const int ml = id / CH, c = id % CH;
-    const int m = m0 + ml, n = n0 + c * 4;
-    f32x4 t = *reinterpret_cast<const f32x4*>(cl + ml * BN + ((c ^ (ml & (CH - 1))) << 2));
-    float v[4] = {t[0], t[1], t[2], t[3]};
-    if (m < p.M && n < p.N) epilogue_store(p, m, n, v, splitk, drop, dc);
+    for (int it = 0; it < BM * CH / 256; ++it) {
+      const int id = it * 256 + threadIdx.x;
+      const int ml = id / CH, c = id % CH;
+      const int m = m0 + ml, n = n0 + c * 4;
+      f32x4 t = *reinterpret_cast<const f32x4*>(cl + ml * BN + ((c ^ (ml & (CH - 1))) << 2));
+      float v[4] = {t[0], t[1], t[2], t[3]};
+      if (m < p.M && n < p.N) epilogue_store(p, m, n, v, splitk, drop, dc);
+    }
   }
 }
 
@@ -506,11 +509,18 @@ struct GroupParams {
   int tile_start[PH_GEMM_GROUP_MAX + 1];
   GemmParams p[PH_GEMM_GROUP_MAX];
 };
+// The grid may be SMALLER than the number of tiles (ph_gemm_grouped_bf16's max_blocks): each block then walks tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ... -- a background launch that occupies at most max_blocks block slots and leaves the rest
+// of the chip to the latency-bound chain on the main stream (deferred weight gradients beside the decoder's backward).
 template <int BM, int BN, bool TA, bool TB, int PF>
 __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupParams g) {
+  const int total = g.tile_start[g.n];
   int i = 0;
-  while (i + 1 < g.n && (int)blockIdx.x >= g.tile_start[i + 1]) ++i;
-  gemm_body<BM, BN, TA, TB, PF>(g.p[i], (int)blockIdx.x - g.tile_start[i], 0, 1);
+  for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    while (i + 1 < g.n && t >= g.tile_start[i + 1]) ++i;
+    gemm_body<BM, BN, TA, TB, PF>(g.p[i], t - g.tile_start[i], 0, 1);
+    __syncthreads();                     // the epilogue's LDS staging area is the next tile's stage buffer
+  }
 }
 
 // folds the split-K partials and applies the fused epilogue (bias / activation / dropout / residual / accumulate / dtype)
@@ -592,32 +602,37 @@ static int fill_params(const ph_gemm_args* a, GemmParams& p) {
   p.bias = a->bias; p.pre_out = (bf16*)a->pre_out; p.act_in = (const bf16*)a->act_in; p.ld_act = a->ld_act;
   p.residual = (const bf16*)a->residual; p.ldr = a->ldr; p.res_f32 = a->residual_f32;
   p.drop_p = a->drop_p; p.drop_seed = a->drop_seed; p.drop_stream = a->drop_stream;
-  p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.alpha = a->alpha;
+  p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.alpha = a->alpha; p.pre_grad = a->pre_grad;
   p.ws = nullptr; p.ldws = (a->N + 3) / 4 * 4;
   return PH_OK;
 }
 
 template <int BM, bool TA, bool TB, int PF>
-static int launch_grouped(const GroupParams& g, int total, hipStream_t s) {
+static int launch_grouped(const GroupParams& g, int total, int max_blocks, hipStream_t s) {
   constexpr int smem = 2 * ((TA ? TileBytes<BM>::ks : TileBytes<BM>::kc) + (TB ? TileBytes<BM>::ks : TileBytes<BM>::kc));
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<BM, BM, TA, TB, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_grouped_kernel<BM, BM, TA, TB, PF>), dim3(total), dim3(256), smem, s, g);
+  const int grid = (max_blocks > 0 && max_blocks < total) ? max_blocks : total;
+  hipLaunchKernelGGL((gemm_grouped_kernel<BM, BM, TA, TB, PF>), dim3(grid), dim3(256), smem, s, g);
   PH_LAUNCH_CHECK("gemm_grouped_kernel");
   return PH_OK;
 }
 template <int BM, int PF>
-static int launch_grouped_layout(const GroupParams& g, int total, int ta, int tb, hipStream_t s) {
-  if (!ta && !tb) return launch_grouped<BM, false, false, PF>(g, total, s);
-  if (!ta && tb) return launch_grouped<BM, false, true, PF>(g, total, s);
-  if (ta && tb) return launch_grouped<BM, true, true, PF>(g, total, s);
-  return launch_grouped<BM, true, false, PF>(g, total, s);
+static int launch_grouped_layout(const GroupParams& g, int total, int max_blocks, int ta, int tb, hipStream_t s) {
+  if (!ta && !tb) return launch_grouped<BM, false, false, PF>(g, total, max_blocks, s);
+  if (!ta && tb) return launch_grouped<BM, false, true, PF>(g, total, max_blocks, s);
+  if (ta && tb) return launch_grouped<BM, true, true, PF>(g, total, max_blocks, s);
+  return launch_grouped<BM, true, false, PF>(g, total, max_blocks, s);
 }
 
 extern "C" int ph_gemm_grouped_bf16(const ph_gemm_args* args, int n, hipStream_t stream) {
+  return ph_gemm_grouped_capped_bf16(args, n, 0, stream);
+}
+
+extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int max_blocks, hipStream_t stream) {
   PH_CHECK_ARG(args && n >= 1 && n <= PH_GEMM_GROUP_MAX, "ph_gemm_grouped_bf16: need 1..%d problems, got %d", PH_GEMM_GROUP_MAX, n);
   double flops = 0.0, bytes = 0.0;
   double w128 = 0.0, w64 = 0.0, kt_max = 0.0;      // tile-iterations of work per tile shape
@@ -656,11 +671,11 @@ extern "C" int ph_gemm_grouped_bf16(const ph_gemm_args* args, int n, hipStream_t
   g.tile_start[n] = total;
   const int ta = args[0].trans_a, tb = args[0].trans_b;
   if (BMsel == 128) {
-    if (kfull && PH_RING128 > 1 && !ta) return launch_grouped_layout<128, PH_RING128>(g, total, ta, tb, stream);
-    return launch_grouped_layout<128, 1>(g, total, ta, tb, stream);
+    if (kfull && PH_RING128 > 1 && !ta) return launch_grouped_layout<128, PH_RING128>(g, total, max_blocks, ta, tb, stream);
+    return launch_grouped_layout<128, 1>(g, total, max_blocks, ta, tb, stream);
   }
-  if (kfull && PH_RING64 > 1) return launch_grouped_layout<64, PH_RING64>(g, total, ta, tb, stream);
-  return launch_grouped_layout<64, 1>(g, total, ta, tb, stream);
+  if (kfull && PH_RING64 > 1) return launch_grouped_layout<64, PH_RING64>(g, total, max_blocks, ta, tb, stream);
+  return launch_grouped_layout<64, 1>(g, total, max_blocks, ta, tb, stream);
 }
 
 extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {

@@ -209,7 +209,10 @@ class RobertaForCausalLMModified(nn.Module):
         seed = self.dropout_seed() if self.training else None
         if torch.is_grad_enabled() and labels is not None and (self._train_names or enc.requires_grad):
             params = [self._store.params[n] for n in self._train_names]
-            loss, logits = _DecoderFn.apply(self, input_ids, attention_mask, enc, labels, seed, *params)
+            # the backward regenerates the dropout masks from *seed when ITS kernels run, i.e. after the advance below:
+            # this forward/backward pair gets its own snapshot of the seed (the persistent one moves on for the next forward)
+            seed_fb = None if seed is None else seed.clone()
+            loss, logits = _DecoderFn.apply(self, input_ids, attention_mask, enc, labels, seed_fb, *params)
         else:
             logits, loss, _ = prog.forward(input_ids, attention_mask, enc, labels, seed, save=False)
         if seed is not None:

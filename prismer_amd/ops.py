@@ -6,7 +6,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_RELU2, IDENT, RowMap, check, lib, ptr)
+from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, ACT_RELU2, ACT_SAVED_GRAD, IDENT, RowMap, check, lib, ptr)
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -135,6 +135,9 @@ class WgradQueue:
         # decoder's chain of small dependent kernels is running they take every CU slot and each chain kernel then waits for
         # slots to drain.  True: launch as soon as 16 problems of one reduction length are queued.
         self.eager_flush = False
+        # > 0 (with eager_flush): mid-segment launches are BACKGROUND launches of at most this many blocks (each walks several
+        # tiles), so the weight gradients trickle through the CUs the chain leaves idle; the flush at the segment end is uncapped
+        self.bg_blocks = 0
         self.gemms = {}          # K -> [(dy, x, gw, M, N, K)]
         self.cols = []           # [(dy, gb, M, N)]
         self.folds = []          # [(dshadow, dw, Cout, Cin, ks, Kp)]  conv weight gradients: shadow layout -> parameter layout
@@ -151,7 +154,7 @@ class WgradQueue:
         q = self.gemms.setdefault(K, [])                           # (two writers of one output never share a launch: _flush_gemms)
         q.append((dy, x, gw, M, N, K))
         if self.eager_flush and len(q) == _lib.GEMM_GROUP_MAX:
-            self._flush_gemms(K)
+            self._flush_gemms(K, self.bg_blocks)
 
     def add_colsum(self, dy, gb, N):
         if not self.enabled:
@@ -201,7 +204,7 @@ class WgradQueue:
                 it.ws, it.blocks, it.D, it.dgamma, it.dbeta = ws.data_ptr(), blocks, D, ptr(dg), ptr(db)
             check(lib.ph_ln_param_reduce_grouped(arr, len(part), _stream()), 'ph_ln_param_reduce_grouped')
 
-    def _flush_gemms(self, K):
+    def _flush_gemms(self, K, max_blocks=0):
         allq = self.gemms.pop(K, [])
         if not allq:
             return
@@ -218,7 +221,7 @@ class WgradQueue:
                     g.M, g.N, g.K = M, N, Kk
                     g.lda, g.ldb, g.ldc = dy.stride(0), x.stride(0), gw.stride(0)
                     g.trans_a, g.trans_b, g.out_f32, g.accumulate, g.alpha = 1, 1, 1, 1, 1.0
-                check(lib.ph_gemm_grouped_bf16(arr, len(q), _stream()), 'ph_gemm_grouped_bf16')
+                check(lib.ph_gemm_grouped_capped_bf16(arr, len(q), max_blocks, _stream()), 'ph_gemm_grouped_capped_bf16')
         off_critical_path(work, *[t for e in allq for t in e[:3]])
 
     def _flush_cols(self):
@@ -261,7 +264,7 @@ def wait_side():
 
 
 def gemm(a, b, out=None, *, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, pre_out=None, act_in=None,
-         residual=None, drop=None, out_f32=False, accumulate=False, alpha=1.0, split_k=0, M=None, N=None, K=None):
+         residual=None, drop=None, out_f32=False, accumulate=False, alpha=1.0, split_k=0, M=None, N=None, K=None, pre_grad=False):
     """out[M,N] = epi(alpha * opA . opB^T).  a: [M,K] (or [K,M] if trans_a), b: [N,K] (or [K,N] if trans_b)."""
     if M is None:
         M = a.shape[1] if trans_a else a.shape[0]
@@ -279,6 +282,7 @@ def gemm(a, b, out=None, *, trans_a=False, trans_b=False, bias=None, act=ACT_NON
     g.bias = ptr(bias)
     g.act = act
     g.pre_out = ptr(pre_out)
+    g.pre_grad = int(pre_grad)
     g.act_in = ptr(act_in)
     g.ld_act = act_in.stride(0) if act_in is not None else 0
     g.residual = ptr(residual)

@@ -16,7 +16,7 @@ import torch
 
 from .. import ops
 from .._lib import ACT_GELU, ACT_RELU2
-from .encoder import LN, Linear
+from .encoder import LN, SAVE_ACT_GRAD, Linear, _bwd_act
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -165,7 +165,7 @@ class DecoderProgram:
 
     def adaptor_fwd(self, blk, h, hf, sv):
         dpre = torch.empty_like(h)
-        dact = blk['down'].fwd(h, act=ACT_RELU2, pre_out=dpre)
+        dact = blk['down'].fwd(h, act=ACT_RELU2, pre_out=dpre, pre_grad=SAVE_ACT_GRAD)
         s = blk['up'].fwd(dact, residual=hf, out_f32=True)
         y, yf, m, r = self.post_ln(blk['ln'], s)                          # norm_late (utils.py:61-62)
         if sv is not None:
@@ -174,7 +174,7 @@ class DecoderProgram:
 
     def adaptor_bwd(self, blk, s, dy):
         ds, _ = blk['ln'].bwd(dy, s['s'], s['m'], s['r'])
-        ddpre = blk['up'].dgrad(ds, act=ACT_RELU2, act_in=s['dpre'])
+        ddpre = blk['up'].dgrad(ds, act=_bwd_act(ACT_RELU2), act_in=s['dpre'])
         blk['up'].wgrad(ds, s['dact'])
         blk['down'].wgrad(ddpre, s['h'])
         return blk['down'].dgrad(ddpre, residual=ds)
@@ -182,7 +182,7 @@ class DecoderProgram:
     def mlp_fwd(self, blk, li, h, hf, seed, sv):
         d = self.d
         ipre = torch.empty(h.shape[0], d.intermediate_size, dtype=BF16, device=h.device)
-        iact = blk['inter'].fwd(h, act=ACT_GELU, pre_out=ipre)
+        iact = blk['inter'].fwd(h, act=ACT_GELU, pre_out=ipre, pre_grad=SAVE_ACT_GRAD)
         dr_h = self.drop(li * 16 + 5, d.hidden_dropout_prob, seed)
         s = blk['out'].fwd(iact, drop=dr_h, residual=hf, out_f32=True)
         y, yf, m, r = self.post_ln(blk['ln'], s)
@@ -192,7 +192,7 @@ class DecoderProgram:
 
     def mlp_bwd(self, blk, s, dy):
         ds, dsd = blk['ln'].bwd(dy, s['s'], s['m'], s['r'], drop=s['dr_h'])
-        dipre = blk['out'].dgrad(dsd, act=ACT_GELU, act_in=s['ipre'])
+        dipre = blk['out'].dgrad(dsd, act=_bwd_act(ACT_GELU), act_in=s['ipre'])
         blk['out'].wgrad(dsd, s['iact'])
         blk['inter'].wgrad(dipre, s['h'])
         return blk['inter'].dgrad(dipre, residual=ds)
@@ -266,6 +266,15 @@ class DecoderProgram:
 
     def backward(self, sv, dloss):
         """dloss: fp32 [B] gradient of the per-sample losses. Returns d(enc) as bf16 [B, S, Hv]."""
+        st = self.backward_start(sv, dloss)
+        self.backward_layers(st, len(self.layers), 0)
+        return self.backward_finish(st)
+
+    # The backward is resumable so that the Trainer can cut it into hipGraph segments in reverse layer order: after each
+    # segment the gradients of the layers it covered are complete (their flat-buffer range can go to the all-reduce while the
+    # next segment runs).  backward_start: CE, LM head, output_layer; backward_layers(hi, lo): layers hi-1 .. lo;
+    # backward_finish: embeddings + the merged cross-attention K/V projection (whose weights sit in layer 0's range).
+    def backward_start(self, sv, dloss):
         d, P = self.d, self.P
         B, T, S = sv['B'], sv['T'], sv['S']
         V = d.vocab_size
@@ -295,13 +304,27 @@ class DecoderProgram:
         F_ = self.final
         dh = self.mlp_bwd(F_['mlp'], blocks.pop(), dh)
         dh = self.self_attn_bwd(F_['sa'], blocks.pop(), dh, B, T, sv['key_mask'])
-        for li in range(nl - 1, -1, -1):
+        return dict(sv=sv, dh=dh, blocks=blocks, merged=merged, denc=denc, dkv_all=dkv_all)
+
+    def backward_layers(self, st, hi, lo):
+        sv, d = st['sv'], self.d
+        B, T, S, H = sv['B'], sv['T'], sv['S'], d.hidden_size
+        dh, blocks, merged = st['dh'], st['blocks'], st['merged']
+        for li in range(hi - 1, lo - 1, -1):
             L = self.layers[li]
             dh = self.mlp_bwd(L['mlp'], blocks.pop(), dh)
             dh = self.adaptor_bwd(L['ad'], blocks.pop(), dh)
-            dh = self.cross_attn_bwd(L['ca'], blocks.pop(), dh, sv['enc'], denc, B, T, S,
-                                     dkv=dkv_all[:, 2 * H * li:2 * H * (li + 1)] if merged else None)
+            dh = self.cross_attn_bwd(L['ca'], blocks.pop(), dh, sv['enc'], st['denc'], B, T, S,
+                                     dkv=st['dkv_all'][:, 2 * H * li:2 * H * (li + 1)] if merged else None)
             dh = self.self_attn_bwd(L['sa'], blocks.pop(), dh, B, T, sv['key_mask'])
+        st['dh'] = dh
+
+    def backward_finish(self, st):
+        d, P = self.d, self.P
+        sv, dh, merged, denc, dkv_all = st['sv'], st['dh'], st['merged'], st['denc'], st['dkv_all']
+        B, S = sv['B'], sv['S']
+        e = 'roberta.embeddings.'
+        wname = e + 'word_embeddings.weight'
         # The tied word-embedding gradient has two writers, the LM-head wgrad GEMM (read-modify-write tiles) and these
         # scatter-adds: both live on the side stream, whose order serialises them (also across micro-batches).
         ops.off_critical_path(lambda: ops.embed_bwd(

@@ -13,11 +13,23 @@ permuted view of the final buffer.
 import torch
 import torch.nn.functional as F
 
+import os
+
 from .. import ops
-from .._lib import ACT_QUICKGELU, ACT_RELU2, IDENT, RowMap
+from .._lib import ACT_QUICKGELU, ACT_RELU2, ACT_SAVED_GRAD, IDENT, RowMap
 from ..config import LABEL_DOMAINS
 
 BF16, F32 = torch.bfloat16, torch.float32
+
+
+# Activations inside a Linear: the forward epilogue stores act'(x) (bf16, taken from the fp32 accumulator) instead of x, and the
+# backward GEMM multiplies by it -- nothing in the backward needs x itself, and its epilogue loses two transcendentals per
+# element (QuickGELU' / erf-GELU').  PRISMER_SAVE_ACT_GRAD=0: store x and recompute act' (round-1 behaviour, A/B switch).
+SAVE_ACT_GRAD = os.environ.get('PRISMER_SAVE_ACT_GRAD', '1') != '0'
+
+
+def _bwd_act(act):
+    return ACT_SAVED_GRAD if SAVE_ACT_GRAD else act
 
 
 def _rup(x, m):
@@ -244,7 +256,7 @@ class EncoderProgram:
             lat1 = blk['out'].fwd(o, residual=lat)
             f, m3, r3 = blk['ln_ff'].fwd(lat1)
             hpre = torch.empty(B * L, 4 * W, dtype=BF16, device=xf.device)
-            hact = blk['fc'].fwd(f, act=ACT_RELU2, pre_out=hpre)
+            hact = blk['fc'].fwd(f, act=ACT_RELU2, pre_out=hpre, pre_grad=SAVE_ACT_GRAD)
             lat2 = blk['proj'].fwd(hact, residual=lat1)
             layers.append(dict(lat=lat, kvin=kvin, qin=qin, m1=m1, r1=r1, m2=m2, r2=r2, q=q, kv=kv, o=o, lse=lse, lat1=lat1, f=f,
                                m3=m3, r3=r3, hpre=hpre, hact=hact))
@@ -263,7 +275,7 @@ class EncoderProgram:
         xf = sv['xf']
         dxf = None
         for blk, s in zip(reversed(self.rblocks), reversed(sv['resampler'])):
-            dhpre = blk['proj'].dgrad(dlat, act=ACT_RELU2, act_in=s['hpre'])
+            dhpre = blk['proj'].dgrad(dlat, act=_bwd_act(ACT_RELU2), act_in=s['hpre'])
             blk['proj'].wgrad(dlat, s['hact'])
             blk['fc'].wgrad(dhpre, s['f'])
             df = blk['fc'].dgrad(dhpre)
@@ -308,11 +320,11 @@ class EncoderProgram:
         x1 = blk['out'].fwd(o, residual=x)
         b_, m2, r2 = blk['aln'].fwd(x1)                                   # Adaptor, pre-norm (utils.py:63-64)
         dpre = torch.empty_like(b_)
-        dact = blk['down'].fwd(b_, act=ACT_RELU2, pre_out=dpre)
+        dact = blk['down'].fwd(b_, act=ACT_RELU2, pre_out=dpre, pre_grad=SAVE_ACT_GRAD)
         x2 = blk['up'].fwd(dact, residual=x1)
         c, m3, r3 = blk['ln_2'].fwd(x2)
         fpre = torch.empty(x.shape[0], 4 * W, dtype=BF16, device=x.device)
-        fact = blk['fc'].fwd(c, act=ACT_QUICKGELU, pre_out=fpre)
+        fact = blk['fc'].fwd(c, act=ACT_QUICKGELU, pre_out=fpre, pre_grad=SAVE_ACT_GRAD)
         x3 = blk['proj'].fwd(fact, residual=x2)
         if sv_list is not None:
             sv_list.append(dict(x=x, a=a, m1=m1, r1=r1, qkv=qkv, o=o, lse=lse, x1=x1, b=b_, m2=m2, r2=r2, dpre=dpre, dact=dact, x2=x2,
@@ -323,12 +335,12 @@ class EncoderProgram:
         d = self.d
         W, H = d.width, d.vit_heads
         dh = W // H
-        dfpre = blk['proj'].dgrad(dx3, act=ACT_QUICKGELU, act_in=s['fpre'])
+        dfpre = blk['proj'].dgrad(dx3, act=_bwd_act(ACT_QUICKGELU), act_in=s['fpre'])
         blk['proj'].wgrad(dx3, s['fact'])
         blk['fc'].wgrad(dfpre, s['c'])
         dc = blk['fc'].dgrad(dfpre)
         dx2, _ = blk['ln_2'].bwd(dc, s['x2'], s['m3'], s['r3'], dskip=dx3)
-        ddpre = blk['up'].dgrad(dx2, act=ACT_RELU2, act_in=s['dpre'])
+        ddpre = blk['up'].dgrad(dx2, act=_bwd_act(ACT_RELU2), act_in=s['dpre'])
         blk['up'].wgrad(dx2, s['dact'])
         blk['down'].wgrad(ddpre, s['b'])
         db = blk['down'].dgrad(ddpre)

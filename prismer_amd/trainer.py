@@ -27,7 +27,8 @@ import random
 import torch
 
 from . import ops
-from .dist import bucketed_all_reduce
+from .dist import GradExchange, contiguous_stages
+from .store import ALIGN
 
 F32, BF16 = torch.float32, torch.bfloat16
 
@@ -39,18 +40,19 @@ def cosine_lr(it, total, init_lr, min_lr):
 
 class Trainer:
     def __init__(self, model, lr=5e-5, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8, min_lr=0.0, total_steps=1000,
-                 task='caption', use_graph=True, process_group=None, bucket_mb=64, side_stream=True, micro_batches=1, keep_grads=False):
+                 task='caption', use_graph=True, process_group=None, bucket_mb=64, side_stream=True, micro_batches=1, keep_grads=False,
+                 max_text_len=None, grad_payload='bf16', transport='torch.distributed', dec_backward_stages=3):
         self.model = model
         self.enc, self.dec = model.expert_encoder, model.text_decoder
         self.init_lr, self.min_lr, self.total_steps = lr, min_lr, total_steps
         self.wd, self.betas, self.eps = weight_decay, betas, eps
         self.task = task
+        self.max_text_len = max_text_len
         self.use_graph = use_graph
         self.pg = process_group
         self.world = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(process_group)
-        self.bucket_elems = bucket_mb * 1024 * 1024 // 4
         self.it = 0
         self.graphs = None
         self.static = None
@@ -66,11 +68,23 @@ class Trainer:
         self.m = [torch.zeros(st.n_train, dtype=F32, device=dev) for st in self.stores]
         self.v = [torch.zeros(st.n_train, dtype=F32, device=dev) for st in self.stores]
         self.hyper = torch.zeros(3, dtype=F32, device=dev)
-        self.hyper_host = torch.zeros(3, dtype=F32).pin_memory()
-        self.table_host = torch.zeros(256, dtype=torch.int32).pin_memory()
+        # per-step host values travel through a ring of pinned slots: a slot is rewritten only after the async copy that read
+        # it last has executed (event per slot), so a host that runs ahead of the device (no loss.item() in the loop) can
+        # neither tear the instance table nor hand a step a later step's learning rate
+        self._slots = [dict(hyper=torch.zeros(3, dtype=F32).pin_memory(), table=torch.zeros(256, dtype=torch.int32).pin_memory(),
+                            ev=None) for _ in range(4)]
         self.table = torch.zeros(256, dtype=torch.int32, device=dev)
         self.seed = self.dec.dropout_seed()
         self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
+        # optimizer stream: the decoder's AdamW runs beside the encoder backward (PRISMER_ADAMW_OVERLAP=0: after it)
+        self.opt_stream = torch.cuda.Stream(device=dev) if (self.world > 1 or os.environ.get('PRISMER_ADAMW_OVERLAP', '1') != '0') else None
+        self.micro = micro_batches if (side_stream and micro_batches > 1) else 1
+        nl = len(self.dec_prog.layers)
+        k = max(1, min(dec_backward_stages, nl)) if (self.world > 1 and self.micro == 1) else 1
+        self.dec_cuts = [nl - (nl * i) // k for i in range(k + 1)]      # e.g. 12 layers, 3 stages: [12, 8, 4, 0]
+        self.bucket_elems = bucket_mb * 1024 * 1024 // (2 if grad_payload == 'bf16' else 4)
+        self.exchange = self._make_exchange(grad_payload, transport)
+        self.stage_ranges = self._stage_ranges()
         # Micro-batches (optional, default off): the stems see the whole batch (train-mode BatchNorm statistics), everything
         # after them is sample-independent, so the batch can be cut into `micro_batches` contiguous slices that run as
         # parallel branches (one stream each).  Motivation: at bs32 the phase times shrink only ~0.7x when the batch is
@@ -79,12 +93,12 @@ class Trainer:
         # eager launches with 2 slices: 38.5 ms, host-bound) -- so the default stays 1.  Weight-gradient accumulation is
         # race-free either way because every read-modify-write of the gradient buffer lives on the single side stream, and
         # forked streams never re-join work they forked themselves (capture_end crashes on such diamonds here).
-        self.micro = micro_batches if (side_stream and micro_batches > 1) else 1
         if side_stream:
             ops.SIDE = ops.SideStream(dev)
             ops.POOL = ops.BranchPool(dev, 3)
             ops.MICRO = ops.BranchPool(dev, self.micro) if self.micro > 1 else ops._NoPool()
         self.loss = None
+        self.trace = []
         self._grads_clean = False
         self.keep_grads = keep_grads           # True: gradients stay readable after step() (tests); False: AdamW zeroes them
         if self.world > 1:
@@ -100,16 +114,64 @@ class Trainer:
             for b in mod.buffers():
                 torch.distributed.broadcast(b, 0, group=self.pg)
 
-    def _allreduce_async(self, flat, n, start=0):
-        """bucketed SUM all-reduce of flat[start:n] on the communication stream, after everything queued so far on the
-        compute stream (those gradients are complete by then)."""
-        if self.world == 1 or n <= start:
+    def _make_exchange(self, payload, transport):
+        if self.world == 1:
+            return None
+        if transport == 'native':                              # the library's own RCCL communicator (include/prismer_comm.h)
+            from . import comm
+            self._native_comm = comm.NativeComm.from_process_group(self.pg, self.device)
+            reduce_fn = self._native_comm.all_reduce_
+        else:
+            def reduce_fn(t):
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        return GradExchange(self.world, reduce_fn, pack=lambda src, dst: ops.cast_to_bf16(src, out=dst),
+                            unpack=lambda src, dst: ops.cast_to_f32(src, out=dst), payload=payload, chunk_elems=self.bucket_elems,
+                            comm_stream=self.comm_stream, transport='rccl via ' + ('prismer_comm (native)' if transport == 'native' else 'torch.distributed'))
+
+    def exchange_desc(self):
+        return None if self.exchange is None else self.exchange.describe()
+
+    def _stage_ranges(self):
+        """{stage: [(store index, lo, hi)]}: the ranges of the flat gradient buffers whose gradients are COMPLETE once backward
+        stage `stage` has run, in buffer order.  Decoder stages follow the reverse layer order of its backward -- 'dec0' = LM
+        head, output_layer and the last layers ... 'dec{k-1}' = the first layers, the embeddings (tied LM-head weight: written
+        at both ends of the backward) and the merged cross-attention K/V projection (one wgrad after the last layer);
+        'trunk' = ViT adaptors, resampler, ln_pre / ln_post; 'front' = expert stems, positional / instance embeddings."""
+        enc, dec = self.stores
+        cuts = self.dec_cuts
+        merged_kv = self.dec_prog.kv_all is not None
+        last = f'dec{len(cuts) - 2}'
+
+        def dec_stage(n):
+            if n.startswith('lm_head.') or n.startswith('roberta.encoder.output_layer.'):
+                return 'dec0'
+            if n.startswith('roberta.encoder.layer.'):
+                l = int(n.split('.')[3])
+                if merged_kv and ('.1.self.key.' in n or '.1.self.value.' in n):
+                    return last
+                for k in range(len(cuts) - 1):
+                    if cuts[k + 1] <= l < cuts[k]:
+                        return f'dec{k}'
+            return last                                            # embeddings
+
+        def enc_stage(n):
+            return 'front' if n.startswith(('positional_embedding', 'instance_embedding', 'conv1.')) else 'trunk'
+        out = {}
+        for si, (st, fn) in enumerate(((enc, enc_stage), (dec, dec_stage))):
+            tr = [n for n in st.names if st.is_trainable(n)]
+            for stage, lo, hi in contiguous_stages(tr, st.offset, st.numel, fn, ALIGN):
+                out.setdefault(stage, []).append((si, lo, min(hi, st.n_train)))
+        return out
+
+    def _issue(self, stage):
+        """hand the finished ranges of `stage` to the gradient exchange (communication stream, behind an event recorded now)"""
+        if self.exchange is None:
             return
+        self.trace.append(('issue', stage))
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
-        self.comm_stream.wait_event(ev)
-        with torch.cuda.stream(self.comm_stream):
-            bucketed_all_reduce(flat[start:n], n - start, self.bucket_elems, self.pg)
+        for si, lo, hi in self.stage_ranges.get(stage, ()):
+            self.exchange.issue(self.stores[si].grad, lo, hi, tag=f'{stage}:{si}', after=ev)
 
     def _wait_comm(self):
         if self.world > 1:
@@ -121,9 +183,10 @@ class Trainer:
         cuts = [B * i // n for i in range(n + 1)]
         return [(cuts[i], cuts[i + 1]) for i in range(n)]
 
-    def _seg_forward_dec_backward(self, s):
+    def _seg_forward(self, s, dec_hi_lo):
+        """forward of everything + the first stage of the decoder backward (CE, LM head, output_layer, layers hi-1 .. lo)"""
         # optimizer.zero_grad(): the fused AdamW of the previous step already left the gradient buffers zeroed (they are
-        # allocated zeroed); only a step that did not end in _seg_optimizer (first step after an exception) needs the fill
+        # allocated zeroed); only a step that did not end in the optimizer segments (first step after an exception) needs the fill
         if not self._grads_clean:
             for st in self.stores:
                 st.grad.zero_()
@@ -134,7 +197,7 @@ class Trainer:
         h, xf, self.sv_f = ep.forward_front(s['experts'], self.table, True, True)
         B = s['input_ids'].shape[0]
         parts = self._slices(B)
-        self.sv_t, self.denc, losses = [None] * len(parts), [None] * len(parts), [None] * len(parts)
+        self.sv_t, self.denc, self.dec_state, losses = [None] * len(parts), [None] * len(parts), [None] * len(parts), [None] * len(parts)
         dp.kv_prefetch = len(parts) == 1
         for mi, (b0, b1) in enumerate(parts):
             with (ops.MICRO.branch(mi) if len(parts) > 1 else contextlib.nullcontext()):
@@ -147,13 +210,28 @@ class Trainer:
                     dloss, losses[mi] = w / B, (loss * w).sum()
                 else:                                          # caption: loss.mean()          (prismer_caption.py:33)
                     dloss, losses[mi] = torch.full((Bh,), 1.0 / B, dtype=F32, device=loss.device), loss.sum()
-                self.denc[mi] = dp.backward(sv_d, dloss)       # (valid after the join_side below)
-                del sv_d
+                st = dp.backward_start(sv_d, dloss)
+                dp.backward_layers(st, *dec_hi_lo)
+                if dec_hi_lo[1] == 0:
+                    self.denc[mi] = dp.backward_finish(st)     # (valid after the join_side below)
+                else:
+                    self.dec_state[mi] = st
+                del sv_d, st
         dp.site_base = 0
         if len(parts) > 1:
             ops.MICRO.join()
         ops.join_side()
         self.loss_buf = torch.stack(losses).sum() / B
+
+    def _seg_dec_backward(self, hi, lo):
+        """decoder layers hi-1 .. lo of the backward (+ embeddings / merged K/V when lo == 0); single-slice schedules only"""
+        dp = self.dec_prog
+        st = self.dec_state[0]
+        dp.backward_layers(st, hi, lo)
+        if lo == 0:
+            self.denc[0] = dp.backward_finish(st)
+            self.dec_state = None
+        ops.join_side()
 
     def _seg_enc_trunk_backward(self):
         ep = self.enc_prog
@@ -180,67 +258,90 @@ class Trainer:
         ops.join_side()
         self.sv_f = self.dh = self.dxf = None
 
-    def _seg_enc_backward(self):
+    def _adamw(self, i):
+        st = self.stores[i]
+        ops.adamw(st.master, st.grad, self.m[i], self.v[i], st.shadow, st.n_train, self.hyper, self.betas[0], self.betas[1], self.eps,
+                  self.wd, 1.0 / self.world, zero_grad=not self.keep_grads)
+        st.refresh_derived()
+
+    def _seg_enc_backward_with_dec_adamw(self):
+        """one rank: the decoder's gradients are final when the encoder backward starts, and nothing in the encoder backward
+        reads a decoder weight -- its fused AdamW (HBM-bound: 5.1 GB of state for Prismer-BASE) runs as a parallel branch
+        beside the MFMA-bound encoder backward instead of after it."""
+        main = torch.cuda.current_stream()
+        if self.opt_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self.opt_stream.wait_event(ev)
+            with torch.cuda.stream(self.opt_stream):
+                self._adamw(1)
         self._seg_enc_trunk_backward()
         self._seg_enc_front_backward()
+        if self.opt_stream is not None:
+            main.wait_stream(self.opt_stream)
+        else:
+            self._adamw(1)
 
     def _seg_enc_trunk_backward_joined(self):
         self._seg_enc_trunk_backward()
         ops.join_side()                                        # trunk gradients complete: their all-reduce may start
 
-    def _schedule(self):
-        """[(compute segment, collective issued right after it)].  One rank: forward + decoder backward | encoder backward |
-        AdamW.  Data parallel: the encoder backward is cut after the trunk, so that the all-reduce of the trunk's gradients
-        (adaptors, resampler: the tail of the encoder's flat buffer) overlaps the stems' backward and only the stems' own
-        gradients (the head of the buffer) are exchanged on the critical path."""
-        enc, dec = self.stores
-        if self.world == 1:
-            return [(lambda: self._seg_forward_dec_backward(self.static), None), (self._seg_enc_backward, None),
-                    (self._seg_optimizer, None)]
-        cut = self._trunk_grad_start()
-        return [(lambda: self._seg_forward_dec_backward(self.static), lambda: self._allreduce_async(dec.grad, dec.n_train)),
-                (self._seg_enc_trunk_backward_joined, lambda: self._allreduce_async(enc.grad, enc.n_train, cut)),
-                (self._seg_enc_front_backward, lambda: (self._allreduce_async(enc.grad, cut), self._wait_comm())),
-                (self._seg_optimizer, None)]
-
-    def _trunk_grad_start(self):
-        """offset in the encoder's flat gradient buffer where the parameters whose gradients are complete after the trunk
-        backward begin (transformer.* adaptors, resampler.*, ln_pre / ln_post); everything before it (positional / instance
-        embeddings, conv1.* stems) is written by the front backward."""
-        st = self.stores[0]
-        front = ('positional_embedding', 'instance_embedding', 'conv1.')
-        cut, seen_trunk = st.n_train, False
-        for n in st.names:
-            if not st.is_trainable(n):
-                continue
-            is_front = n.startswith(front)
-            if not is_front and not seen_trunk:
-                cut, seen_trunk = st.offset[n], True
-            elif is_front and seen_trunk:
-                return 0                                       # interleaved layout: no overlap, exchange everything at the end
-        return cut
-
-    def _seg_optimizer(self):
-        for st, m, v in zip(self.stores, self.m, self.v):
-            ops.adamw(st.master, st.grad, m, v, st.shadow, st.n_train, self.hyper, self.betas[0], self.betas[1], self.eps, self.wd,
-                      1.0 / self.world, zero_grad=not self.keep_grads)
-            st.refresh_derived()
+    def _seg_optimizer_tail(self):
+        """encoder AdamW (the decoder's already ran beside the encoder backward), dropout seed advance"""
+        self._adamw(0)
         ops.advance_seed(self.seed)
         self._grads_clean = not self.keep_grads
+
+    def _dec_adamw_after_comm(self):
+        """N ranks: the decoder's AdamW starts on the optimizer stream as soon as its last bucket has been reduced and runs
+        beside the encoder backward (an eager launch between graph replays, ordered by stream events like the collectives)"""
+        self.opt_stream.wait_stream(self.comm_stream)
+        with torch.cuda.stream(self.opt_stream):
+            self._adamw(1)
+
+    def _seg_optimizer_tail_dp(self):
+        torch.cuda.current_stream().wait_stream(self.opt_stream)
+        self._seg_optimizer_tail()
+
+    def _schedule(self):
+        """[(compute segment, host action right after it)].
+        One rank: forward + decoder backward | encoder backward (+ decoder AdamW as a parallel branch) | encoder AdamW.
+        Data parallel: the backward is cut in reverse layer order -- decoder in `len(dec_cuts) - 1` stages, encoder trunk,
+        encoder front; after every segment the finished ranges go to the bf16 all-reduce on the communication stream, so only
+        the last one (the stems' 25 M parameters) is exchanged on the critical path; the decoder's AdamW runs on the
+        optimizer stream as soon as its buckets are reduced."""
+        s = self.static
+        if self.world == 1:
+            nl = len(self.dec_prog.layers)
+            return [(lambda: self._seg_forward(self.static, (nl, 0)), None), (self._seg_enc_backward_with_dec_adamw, None),
+                    (self._seg_optimizer_tail, None)]
+        cuts = self.dec_cuts
+        nst = len(cuts) - 1
+        sched = [(lambda: self._seg_forward(self.static, (cuts[0], cuts[1])), lambda: self._issue('dec0'))]
+        for k in range(1, nst):
+            sched.append(((lambda k=k: self._seg_dec_backward(cuts[k], cuts[k + 1])), (lambda k=k: self._issue(f'dec{k}'))))
+        seg, host = sched[-1]
+        sched[-1] = (seg, lambda host=host: (host(), self._dec_adamw_after_comm()))
+        sched += [(self._seg_enc_trunk_backward_joined, lambda: self._issue('trunk')),
+                  (self._seg_enc_front_backward, lambda: (self._issue('front'), self._wait_comm())),
+                  (self._seg_optimizer_tail_dp, None)]
+        return sched
 
     def _host_prologue(self):
         """per-step host work: LR schedule (cosine per ITERATION, train_caption.py:127), Adam bias corrections and the
         instance-embedding draw table (vit.py:145-147: Python `random`), shipped with two async pinned copies."""
         self.it += 1
+        slot = self._slots[self.it % len(self._slots)]
+        if slot['ev'] is not None:
+            slot['ev'].synchronize()
         lr = cosine_lr(self.it - 1, self.total_steps, self.init_lr, self.min_lr)
-        self.hyper_host[0] = lr
-        self.hyper_host[1] = 1.0 - self.betas[0] ** self.it
-        self.hyper_host[2] = 1.0 - self.betas[1] ** self.it
-        self.hyper.copy_(self.hyper_host, non_blocking=True)
+        slot['hyper'].copy_(torch.tensor([lr, 1.0 - self.betas[0] ** self.it, 1.0 - self.betas[1] ** self.it], dtype=F32))
+        self.hyper.copy_(slot['hyper'], non_blocking=True)
         if 'obj_detection' in self.enc.experts:
-            for i in range(256):
-                self.table_host[i] = random.randint(0, 127)
-            self.table.copy_(self.table_host, non_blocking=True)
+            slot['table'].copy_(torch.tensor([random.randint(0, 127) for _ in range(256)], dtype=torch.int32))
+            self.table.copy_(slot['table'], non_blocking=True)
+        slot['ev'] = torch.cuda.Event()
+        slot['ev'].record(torch.cuda.current_stream())
 
     # ------------------------------------------------------------------------------------------ public API
     def set_batch(self, experts, input_ids, attention_mask, labels, weights=None):
@@ -253,28 +354,80 @@ class Trainer:
                     self.enc.expert_resolution, self.enc._prog = er, None
                     self.enc_prog = self.enc._program()
                 break
+        # The step is a fixed-shape program (hipGraph replay over static buffers).  The reference tokenises with
+        # padding='longest' (prismer_caption.py:20, prismer_vqa.py:25-30), so T varies per batch: text is padded here to the
+        # static length with <pad> / mask 0 / label -100 -- masked keys and ignored labels, i.e. the same loss.  The batch
+        # size is fixed like the reference's training loader (dataset/__init__.py:42 drop_last=True).
+        pad = self.dec.config.pad_token_id
         if self.static is None:
+            T = max(self.max_text_len or 0, input_ids.shape[1])
+            B = input_ids.shape[0]
+
             def clone(t):
                 return {k: clone(v) for k, v in t.items()} if isinstance(t, dict) else t.to(self.device).contiguous().clone()
-            self.static = dict(experts=clone(experts), input_ids=input_ids.to(self.device).contiguous().clone(),
-                               attention_mask=attention_mask.to(self.device).contiguous().clone(),
-                               labels=labels.to(self.device).contiguous().clone(),
-                               weights=None if weights is None else weights.to(self.device).contiguous().clone())
-            return
+            self.static = dict(experts=clone(experts),
+                               input_ids=torch.full((B, T), pad, dtype=input_ids.dtype, device=self.device),
+                               attention_mask=torch.zeros((B, T), dtype=attention_mask.dtype, device=self.device),
+                               labels=torch.full((B, T), -100, dtype=labels.dtype, device=self.device),
+                               weights=None if weights is None else torch.zeros(B, dtype=F32, device=self.device))
 
-        def copy(dst, src):
+        def copy(dst, src, what):
             if isinstance(dst, dict):
+                if not isinstance(src, dict) or set(src) != set(dst):
+                    raise ValueError(f'set_batch: {what} keys changed: {sorted(src) if isinstance(src, dict) else type(src)} vs {sorted(dst)}')
                 for k in dst:
-                    copy(dst[k], src[k])
-            else:
-                dst.copy_(src, non_blocking=True)
+                    copy(dst[k], src[k], f'{what}[{k!r}]')
+                return
+            if tuple(src.shape) != tuple(dst.shape):
+                raise ValueError(f'set_batch: {what} has shape {tuple(src.shape)}, the bound program expects {tuple(dst.shape)} '
+                                 '(fixed batch size / expert resolution; use drop_last=True like the reference loader)')
+            dst.copy_(src, non_blocking=True)
+
+        def copy_text(dst, src, fill, what):
+            B, T = dst.shape
+            if src.shape[0] != B or src.shape[1] > T:
+                raise ValueError(f'set_batch: {what} has shape {tuple(src.shape)}, the bound program holds [{B}, <= {T}] '
+                                 '(pass max_text_len= to the Trainer for longer captions)')
+            if src.shape[1] < T:
+                dst.fill_(fill)
+            dst[:, :src.shape[1]].copy_(src, non_blocking=True)
         s = self.static
-        copy(s['experts'], experts); copy(s['input_ids'], input_ids); copy(s['attention_mask'], attention_mask); copy(s['labels'], labels)
+        copy(s['experts'], experts, 'experts')
+        copy_text(s['input_ids'], input_ids, pad, 'input_ids'); copy_text(s['attention_mask'], attention_mask, 0, 'attention_mask')
+        copy_text(s['labels'], labels, -100, 'labels')
+        if (weights is None) != (s['weights'] is None):
+            raise ValueError('set_batch: per-sample loss weights must be given for every batch or for none (the loss form is part '
+                             'of the captured program)')
         if weights is not None:
-            copy(s['weights'], weights)
+            copy(s['weights'], weights.to(F32), 'weights')
+
+    def _snapshot(self):
+        """everything a training step mutates: masters (+ bf16 shadows and derived conv shadows follow from them), Adam moments,
+        BatchNorm running statistics / counters, the dropout seed, the iteration counter and Python's RNG (instance draws)"""
+        return dict(master=[st.master.clone() for st in self.stores], m=[t.clone() for t in self.m], v=[t.clone() for t in self.v],
+                    bufs=[b.clone() for mod in (self.enc, self.dec) for b in mod.buffers()], seed=self.seed.clone(), it=self.it,
+                    rng=random.getstate(), grads=[st.grad.clone() for st in self.stores], clean=self._grads_clean)
+
+    def _restore(self, snap):
+        for st, t in zip(self.stores, snap['master']):
+            st.master.copy_(t)
+            st.refresh()
+        for dst, src in zip(self.m + self.v, snap['m'] + snap['v']):
+            dst.copy_(src)
+        for b, t in zip([b for mod in (self.enc, self.dec) for b in mod.buffers()], snap['bufs']):
+            b.copy_(t)
+        for st, t in zip(self.stores, snap['grads']):
+            st.grad.copy_(t)
+        self.seed.copy_(snap['seed'])
+        self.it, self._grads_clean = snap['it'], snap['clean']
+        random.setstate(snap['rng'])
 
     def _capture(self):
-        s = self.static
+        """hipGraph capture of the compute segments.  The warm-up passes that precede it (allocator pools, lazily built
+        shadows, RCCL channel set-up) run REAL steps, so the training state is snapshotted before and restored after them:
+        the first replayed step is then update-for-update the first eager step (one AdamW update per batch like the
+        reference loop, train_caption.py:126-135)."""
+        snap = self._snapshot()
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                           # warm-up outside capture (allocations, lazily built shadows)
@@ -285,6 +438,8 @@ class Trainer:
                     if coll is not None:
                         coll()
         torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._restore(snap)
         torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
         # thread_local: RCCL's watchdog thread polls events while we capture (world > 1); only this thread's calls are policed
@@ -303,20 +458,30 @@ class Trainer:
         if self.use_graph and self.graphs is None:
             try:
                 self._capture()
-            except Exception as e:                      # capture is an optimisation: fall back to eager launches of the same kernels
+            except Exception as e:
+                # no silent fall-back: a benchmark line must not claim graphs that did not run.  PRISMER_ALLOW_EAGER_FALLBACK=1
+                # continues with eager launches of the same kernels and flips use_graph (callers report tr.use_graph).
+                if os.environ.get('PRISMER_ALLOW_EAGER_FALLBACK', '0') == '0':
+                    raise RuntimeError(f'hipGraph capture of the training step failed ({type(e).__name__}: {e}); pass use_graph=False '
+                                       'or set PRISMER_ALLOW_EAGER_FALLBACK=1') from e
                 import sys
                 print(f'[prismer_amd] hipGraph capture failed ({type(e).__name__}: {e}); continuing with eager launches', file=sys.stderr)
                 torch.cuda.synchronize()
                 self.graphs, self.use_graph = None, False
                 ops.join_side()
         self._host_prologue()
+        if self.exchange is not None:
+            self.exchange.begin_step()
+        self.trace = []                                         # host enqueue order of compute segments and bucket hand-offs
         if self.use_graph:
-            for g, coll in self.graphs:
+            for i, (g, coll) in enumerate(self.graphs):
+                self.trace.append(('seg', i))
                 g.replay()
                 if coll is not None:
                     coll()
         else:
-            for seg, coll in self._schedule():
+            for i, (seg, coll) in enumerate(self._schedule()):
+                self.trace.append(('seg', i))
                 seg()
                 if coll is not None:
                     coll()

@@ -12,14 +12,18 @@ INSTANCE_SEED = 7     # random.seed before every encoder call: vit.py:145-147 dr
 
 
 def _dims(name):
-    if name in ('tiny_caption', 'tiny_vqa'):
+    if name in ('tiny_caption', 'tiny_vqa', 'tiny_vqa_head'):
         return config.prismer_tiny()
     if name == 'tiny_bicubic':            # rgb grid 6x6 vs expert grid 4x4 -> bicubic pos-embed path (utils.py:34-44)
         return config.prismer_tiny(image_resolution=96, expert_resolution=64)
     if name == 'tiny_z':                  # PrismerZ: rgb only, no resampler (vit.py:125,128)
         return config.prismer_tiny(experts=[])
-    if name == 'base_caption':
+    if name in ('base_caption', 'base_b8'):
         return config.prismer_base()
+    if name == 'zbase_b4':                # BASELINE config 2 geometry: PrismerZ-BASE, full depth
+        return config.prismerz_base()
+    if name == 'large_vqa_b1':            # BASELINE config 5 geometry: Prismer-LARGE VQA, 480^2, full depth (24 + 24 layers)
+        return config.prismer_large()
     raise KeyError(name)
 
 
@@ -30,9 +34,19 @@ CASES = OrderedDict([
     ('tiny_bicubic', (2, 10, False)),
     ('tiny_z', (2, 12, True)),
     ('base_caption', (1, 30, False)),
+    # round 2: the sizes bench.py runs (full depth, batch > 1); train-mode + gradients are what the Trainer tests compare
+    ('base_b8', (8, 30, True)),
+    ('zbase_b4', (4, 30, True)),
+    ('large_vqa_b1', (1, 40, False)),
+    # question ‖ answer exactly as PrismerVQA.forward concatenates them (prismer_vqa.py:22-33): each part padded to ITS longest,
+    # so pads sit in the middle of a row
+    ('tiny_vqa_head', (3, 9 + 5, True)),
 ])
 
-LOGIT_STRIDE = {'base_caption': 97}       # store every 97th vocab column for the big case
+LOGIT_STRIDE = {'base_caption': 97, 'base_b8': 97, 'zbase_b4': 97, 'large_vqa_b1': 97}    # every 97th vocab column for the big cases
+ENC_STRIDE = {'base_b8': 16, 'zbase_b4': 8, 'large_vqa_b1': 16}                             # every n-th feature of the encoder output
+VQA_CASES = ('tiny_vqa', 'large_vqa_b1')
+VQA_HEAD_TQ, VQA_HEAD_TA = 9, 5
 
 
 class Case:
@@ -49,9 +63,15 @@ class Case:
         d = self.dims
         x = synth.synth_experts(d, self.batch, seed=1234)
         prompt = 4
-        if self.name == 'tiny_vqa':       # prismer_vqa.py:32-33: everything but the answer span is -100
-            ids, mask, labels = synth.synth_text(d, self.batch, self.T, seed=1234, ragged=True, prompt_length=1)
-            ans = 4
+        if self.name == 'tiny_vqa_head':
+            q_ids, q_att, a_ids, a_att, weights = self.vqa_parts()
+            ids, mask = torch.cat([q_ids, a_ids], 1), torch.cat([q_att, a_att], 1)
+            labels = ids.masked_fill(ids == d.pad_token_id, -100)
+            labels[:, :-a_ids.shape[1]] = -100
+            return x, ids, mask, labels, weights
+        if self.name in VQA_CASES:        # prismer_vqa.py:32-33: everything but the answer span is -100
+            ids, mask, labels = synth.synth_text(d, self.batch, self.T, seed=1234, ragged=self.ragged, prompt_length=1)
+            ans = 4 if self.name == 'tiny_vqa' else 5
             for b in range(self.batch):
                 L = int(mask[b].sum())
                 labels[b, :max(0, L - ans)] = -100
@@ -59,6 +79,23 @@ class Case:
             return x, ids, mask, labels, weights
         ids, mask, labels = synth.synth_text(d, self.batch, self.T, seed=1234, ragged=self.ragged, prompt_length=prompt)
         return x, ids, mask, labels, None
+
+    def vqa_parts(self):
+        """what the tokenizer calls of prismer_vqa.py:22-30 return: '<s>Question' ids (no </s>, ragged, padded to longest) and
+        ' Answer</s>' ids (ragged, padded to longest), with their attention masks, plus the per-sample loss weights"""
+        d = self.dims
+        Tq, Ta = VQA_HEAD_TQ, VQA_HEAD_TA
+        q = synth.randint('in.vqa_q', (self.batch, Tq), 3, d.vocab_size, 1234)
+        a = synth.randint('in.vqa_a', (self.batch, Ta), 3, d.vocab_size, 1234)
+        q[:, 0] = d.bos_token_id
+        qa, aa = torch.ones_like(q), torch.ones_like(a)
+        for b in range(self.batch):
+            lq, la = Tq - (2 * b) % (Tq - 2), Ta - b % (Ta - 1)
+            q[b, lq:] = d.pad_token_id; qa[b, lq:] = 0
+            a[b, la - 1] = d.eos_token_id
+            a[b, la:] = d.pad_token_id; aa[b, la:] = 0
+        weights = 0.6 + 0.4 * synth.uniform_pm1('in.vqa_w', (self.batch,), 1234)
+        return q, qa, a, aa, weights
 
     def instance_table(self, x):
         """The table the reference's per-label random.randint draws produce after random.seed(INSTANCE_SEED)."""

@@ -45,7 +45,8 @@ def run_case(name):
     with torch.no_grad():
         e, o = fwd()
     stride = C.LOGIT_STRIDE.get(name, 1)
-    out['enc_eval'] = e.numpy()
+    es = C.ENC_STRIDE.get(name, 1)
+    out['enc_eval'] = e[..., ::es].numpy()
     out['logits_eval'] = o.logits[..., ::stride].numpy()
     out['loss_eval'] = o.loss.numpy()
 
@@ -54,7 +55,7 @@ def run_case(name):
     e, o = fwd()
     total = (o.loss if weights is None else weights * o.loss).mean()
     total.backward()
-    out['enc_train'] = e.detach().numpy()
+    out['enc_train'] = e.detach()[..., ::es].numpy()
     out['loss_train'] = o.loss.detach().numpy()
     out['total_train'] = total.detach().numpy()
     for k, v in enc.state_dict().items():

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from prismer_amd.dist import bucket_ranges, bucketed_all_reduce
+from prismer_amd.dist import GradExchange, bucket_ranges, bucketed_all_reduce, contiguous_stages
 
 
 def _free_port():
@@ -49,3 +49,52 @@ def test_bucket_ranges_cover_exactly():
     r = bucket_ranges(1000, 300)
     assert r == [(0, 300), (300, 600), (600, 900), (900, 1000)]
     assert bucket_ranges(5, 16) == [(0, 5)]
+
+
+def _worker_bf16(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    g = torch.randn(5000) * torch.logspace(-4, 0, 5000)           # gradients spanning four decades
+    flat32, flat16 = g.clone(), g.clone()
+    ex32 = GradExchange(world, lambda t: dist.all_reduce(t), payload='fp32', chunk_elems=1024)
+    ex16 = GradExchange(world, lambda t: dist.all_reduce(t), pack=lambda s, d: d.copy_(s), unpack=lambda s, d: d.copy_(s),
+                        payload='bf16', chunk_elems=1024)
+    for ex, flat in ((ex32, flat32), (ex16, flat16)):
+        ex.begin_step()
+        # stages arrive in REVERSE buffer order, like the backward: tail first, head last; a stage may own several ranges
+        ex.issue(flat, 3000, 5000, 'late')
+        ex.issue(flat, 1000, 3000, 'mid')
+        ex.issue(flat, 0, 1000, 'early')
+    out[rank] = (flat32, flat16, list(ex16.log), ex16.bytes_per_step, ex32.bytes_per_step)
+    dist.destroy_process_group()
+
+
+def test_bf16_bucket_exchange_matches_fp32_within_1e2():
+    """bf16 payload (pack -> all-reduce -> unpack per chunk, issued per finished backward stage) vs the fp32 exchange."""
+    world = 2
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_worker_bf16, args=(world, _free_port(), out), nprocs=world, join=True)
+    f32, f16, log, b16, b32 = out[0]
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])       # every rank ends with the same sums
+    rel = ((f16 - f32).norm() / f32.norm()).item()
+    assert rel < 1e-2, rel
+    mag = torch.zeros(5000)
+    for r in range(world):
+        torch.manual_seed(100 + r)
+        mag += (torch.randn(5000) * torch.logspace(-4, 0, 5000)).abs()
+    assert ((f16 - f32).abs() <= 2.0 ** -7 * mag + 1e-9).all()                             # element-wise: bf16 rounding of each operand + of the sum
+    assert [e[0] for e in log] == ['late', 'mid', 'early'] and [e[3] for e in log] == [2, 2, 1]
+    assert b16 * 2 == b32 == 4 * 5000
+
+
+def test_contiguous_stages_cover_the_buffer_in_order():
+    names = ['emb', 'l0.a', 'l0.kv', 'l1.a', 'l2.a', 'head']
+    numel = {'emb': 100, 'l0.a': 64, 'l0.kv': 300, 'l1.a': 64, 'l2.a': 70, 'head': 10}
+    offset, o = {}, 0
+    for n in names:
+        offset[n] = o; o += (numel[n] + 63) // 64 * 64
+    stage = {'emb': 'last', 'l0.a': 'last', 'l0.kv': 'last', 'l1.a': 'mid', 'l2.a': 'first', 'head': 'first'}
+    runs = contiguous_stages(names, offset, numel, stage.get, 64)
+    assert runs == [('last', 0, 128 + 64 + 320), ('mid', 512, 576), ('first', 576, 576 + 128 + 64)]
+    assert runs[0][1] == 0 and all(a[2] == b[1] for a, b in zip(runs, runs[1:]))

@@ -17,7 +17,7 @@ def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, use_graph, out):
+def _worker(rank, world, port, use_graph, out, payload='bf16'):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
@@ -44,8 +44,8 @@ def _worker(rank, world, port, use_graph, out):
         pass
     m = Holder(); m.expert_encoder, m.text_decoder = enc, dec
     tab = case.instance_table(x)
-    tr = Trainer(m, lr=1e-3, total_steps=10, use_graph=use_graph, keep_grads=True)
-    assert tr.world == world
+    tr = Trainer(m, lr=1e-3, total_steps=10, use_graph=use_graph, keep_grads=True, grad_payload=payload, dec_backward_stages=2)
+    assert tr.world == world and tr.dec_cuts == [2, 1, 0]
     tr.set_batch(T.to_dev(x), ids, mask, labels)
     orig = tr._host_prologue
 
@@ -57,7 +57,9 @@ def _worker(rank, world, port, use_graph, out):
         loss = tr.step()
     torch.cuda.synchronize()
     out[rank] = dict(loss=float(loss), grads=[st.grad[:st.n_train].float().cpu() for st in tr.stores],
-                     params=[st.master[:st.n_train].float().cpu() for st in tr.stores])
+                     params=[st.master[:st.n_train].float().cpu() for st in tr.stores], trace=list(tr.trace),
+                     log=list(tr.exchange.log), desc=tr.exchange.describe() if tr.exchange.log_last else None,
+                     n_train=[st.n_train for st in tr.stores])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -74,3 +76,26 @@ def test_two_ranks_one_gpu(use_graph):
     for pa, pb in zip(a['params'], b['params']):    # same start (broadcast) + same update => identical parameters
         assert torch.equal(pa, pb)
     assert a['loss'] != b['loss']                   # the ranks really saw different batches
+    # overlap structure: every stage's ranges are handed to the communication stream right after ITS segment, i.e. all but the
+    # last one (the stems) are in flight before the last backward segment is even launched; together they tile both buffers
+    tr = a['trace']
+    assert tr == [('seg', 0), ('issue', 'dec0'), ('seg', 1), ('issue', 'dec1'), ('seg', 2), ('issue', 'trunk'), ('seg', 3),
+                  ('issue', 'front'), ('seg', 4)], tr
+    cover = {0: 0, 1: 0}
+    for tag, lo, hi, n in a['log']:
+        assert n >= 1 and hi > lo
+        cover[int(tag.split(':')[1])] += hi - lo
+    assert [cover[0], cover[1]] == a['n_train'], (cover, a['n_train'])
+    assert a['desc'] is None or a['desc']['payload'] == 'bf16'
+
+
+def test_two_ranks_bf16_payload_close_to_fp32():
+    """same two-rank step with the fp32 payload (DDP's): the bf16 buckets change the summed gradients by < 1e-2"""
+    world = 2
+    res = {}
+    for payload in ('fp32', 'bf16'):
+        mgr = mp.Manager(); out = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), False, out, payload), nprocs=world, join=True)
+        res[payload] = out[0]
+    for g32, g16 in zip(res['fp32']['grads'], res['bf16']['grads']):
+        assert ((g16 - g32).norm() / g32.norm()).item() < 1e-2

@@ -109,6 +109,51 @@ def test_gemm_epilogue(ops, act):
     assert rel_fro(got, ref) < 6e-3
 
 
+@pytest.mark.parametrize('act', [1, 2, 3])
+def test_gemm_saved_activation_gradient(ops, act):
+    """pre_grad: the forward epilogue stores act'(x) (from the fp32 accumulator) instead of x; the backward GEMM with
+    PH_ACT_SAVED_GRAD multiplies by it.  Together = the autograd gradient through Linear -> act."""
+    from prismer_amd._lib import ACT_SAVED_GRAD
+    M, N, K = 333, 520, 256
+    a, b = rnd(M, K, scale=0.5, seed=3), rnd(N, K, scale=0.3, seed=4)
+    bias = rnd(N, dtype=torch.float32, seed=5)
+    g = torch.empty(M, N, dtype=BF, device='cuda')
+    out = ops.gemm(a, b, bias=bias, act=act, pre_out=g, pre_grad=True)
+    fn = {1: lambda t: t * torch.sigmoid(1.702 * t), 2: lambda t: torch.relu(t) ** 2, 3: lambda t: F.gelu(t)}[act]
+    z = (a.float() @ b.float().t() + bias).requires_grad_(True)
+    y = fn(z)
+    y.backward(torch.ones_like(y))
+    assert rel_fro(out, y) < 6e-3
+    assert rel_fro(g, z.grad) < 6e-3
+    dy = rnd(M, 64, scale=0.5, seed=7)
+    w2 = rnd(64, N, scale=0.3, seed=8)           # dY[M,64] . W[64,N] -> [M,N], times the saved derivative
+    got = ops.gemm(dy, w2, trans_b=True, act=ACT_SAVED_GRAD, act_in=g)
+    assert rel_fro(got, (dy.float() @ w2.float()) * g.float()) < 6e-3
+
+
+def test_gemm_grouped_capped_background_launch(ops):
+    """ph_gemm_grouped_capped_bf16: a grid smaller than the tile count (blocks walk several tiles) gives the same result"""
+    import ctypes as C
+    from prismer_amd import _lib
+    shapes = [(768, 768, 960), (2304, 768, 960), (100, 200, 960)]
+    ops_, refs = [], []
+    for i, (M, N, K) in enumerate(shapes):
+        dy, x = rnd(K, M, scale=0.3, seed=20 + i), rnd(K, N, scale=0.3, seed=40 + i)
+        ops_.append((dy, x, torch.zeros(M, N, device='cuda')))
+        refs.append(dy.float().t() @ x.float())
+    for cap in (0, 7, 40, 100000):
+        arr = (_lib.GemmArgs * len(shapes))()
+        for g, (dy, x, gw) in zip(arr, ops_):
+            gw.zero_()
+            g.A, g.B, g.C = dy.data_ptr(), x.data_ptr(), gw.data_ptr()
+            g.M, g.N, g.K = gw.shape[0], gw.shape[1], dy.shape[0]
+            g.lda, g.ldb, g.ldc = dy.stride(0), x.stride(0), gw.stride(0)
+            g.trans_a, g.trans_b, g.out_f32, g.accumulate, g.alpha = 1, 1, 1, 1, 1.0
+        _lib.check(_lib.lib.ph_gemm_grouped_capped_bf16(arr, len(shapes), cap, torch.cuda.current_stream().cuda_stream), 'capped')
+        for (dy, x, gw), ref in zip(ops_, refs):
+            assert rel_fro(gw, ref) < 3e-4, cap
+
+
 def test_gemm_f32_accumulate_splitk(ops):
     M, N, K = 768, 768, 4160           # wgrad shape: dW[N_out, K_in] = dY^T X, reduction over 4160 rows
     dy, x = rnd(K, M, scale=0.3, seed=10), rnd(K, N, scale=0.3, seed=11)

@@ -56,7 +56,7 @@ def main():
         ops.join_side()
 
     def opt():
-        tr._seg_optimizer()
+        tr._adamw(1); tr._adamw(0)
 
     phases = [('front fwd', front_f), ('trunk fwd', trunk_f), ('decoder fwd', dec_f), ('decoder bwd', dec_b),
               ('trunk bwd', trunk_b), ('front bwd', front_b), ('adamw', opt)]
