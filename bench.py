@@ -90,7 +90,7 @@ def build_trainer(batch, use_graph, rank, T=30, workload='base_caption', freeze=
         model = PrismerCaption(cfg).cuda()
     tr = Trainer(model, lr=5e-5, weight_decay=0.05, total_steps=10000, task='caption', use_graph=use_graph,
                  micro_batches=int(os.environ.get('PRISMER_MICRO_BATCHES', '1')),
-                 side_stream=os.environ.get('PRISMER_SIDE_STREAM', '1') != '0')
+                 side_stream=os.environ.get('PRISMER_SIDE_STREAM', '0') != '0')
     from prismer_amd import ops as _ops
     _ops.WQ.enabled = os.environ.get('PRISMER_WGRAD_QUEUE', '1') != '0'      # A/B switch: grouped deferred wgrads
     _ops.WQ.eager_flush = os.environ.get('PRISMER_WGRAD_EAGER_FLUSH', '0') != '0'

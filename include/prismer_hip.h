@@ -77,6 +77,9 @@ int ph_gemm_bf16(const ph_gemm_args* args, hipStream_t stream);
  * cover 18..144 tiles each, far fewer than the chip holds, so the host side defers them and issues each layer's set at once. */
 #define PH_GEMM_GROUP_MAX 16
 int ph_gemm_grouped_bf16(const ph_gemm_args* args, int n, hipStream_t stream);
+/* tuning hook for benchmarks: big-tile (256x128, LDS-DMA) kernel variant (0 = off) and the tile count from which it is used;
+ * a negative value leaves the setting unchanged.  Environment defaults: PH_GEMM_BIG, PH_GEMM_BIG_MIN_TILES. */
+int ph_gemm_tuning(int big_mode, int big_min_tiles);
 /* same, as a BACKGROUND launch: at most `max_blocks` blocks (0 = one per tile), each walking several tiles.  Deferred weight
  * gradients issued beside the latency-bound backward chain of the decoder (roberta.py:212-231 in reverse) then fill the
  * idle CUs without taking every block slot from the chain's small kernels. */
@@ -162,6 +165,16 @@ int ph_patchify(const float* img, void* col, int B, int C, int R, int p, int Kp,
 /* nn.UpsamplingBilinear2d (align_corners=True, vit.py:89,106) fused with NCHW fp32 -> NHWC bf16. */
 int ph_resize_bilinear_nchw_to_nhwc(const float* x, void* y, int B, int C, int Hin, int Win, int Hout, int Wout,
                                     hipStream_t stream);
+/* Label-expert in-painting fused with the stem's bilinear resize.  Replaces post_label_process (dataset/utils.py:117-160: the
+ * per-label Python loop that paints CLIP text features over seg / obj_detection / ocr_detection label maps on the CPU, 64 fp32
+ * channels per pixel) followed by nn.UpsamplingBilinear2d (vit.py:88-90, align_corners=True).
+ *   labels [B, Hin, Win] uint8 (255 = background); table fp32 [256, C] per image (`table_batch_stride` elements apart; 0 = one
+ *   table shared by the batch, e.g. the fixed COCO / ADE vocabularies): row l is the feature painted over label l.
+ *   y [B, Hout, Wout, C] bf16 (NHWC) = bilinear(in-painted image), bit-identical to ph_resize_bilinear_nchw_to_nhwc of the
+ *   dense image. */
+int ph_inpaint_resize_nhwc(const uint8_t* labels, const float* table, int64_t table_batch_stride, void* y, int B, int C, int Hin,
+                           int Win, int Hout, int Wout, hipStream_t stream);
+
 /* 3x3 (pad 1) or 1x1 (pad 0) window gather from an NHWC bf16 map into col[B*Ho*Wo, Kp] with column order
  * (ky, kx, c); optionally applies BatchNorm(scale, shift per channel) + ReLU to every gathered element
  * (vit.py:90-103: conv -> BN -> ReLU -> conv, the normalised map is never written on its own). */
@@ -257,6 +270,10 @@ int ph_add_bf16(const void* a, const void* b, void* y, int64_t n, hipStream_t st
 /* generic 2-D strided copy of bf16 rows: dst[r*ldd + c] = src[map(r)*lds + c], c < cols */
 int ph_copy_rows_bf16(const void* src, int lds, ph_rowmap src_map, void* dst, int ldd, ph_rowmap dst_map, int rows,
                       int cols, int accumulate, hipStream_t stream);
+/* dst[r, :cols] = src[idx[r], :cols] (bf16 rows, idx int32 on the device).  Beam reordering of the self-attention K/V caches
+ * of KV-cached decoding -- what transformers' generate does with `_reorder_cache` after each beam step; the reference itself
+ * (model/prismer_caption.py:45-50, roberta.py:401-406) keeps no cache and re-runs the whole prefix every step. */
+int ph_gather_rows_bf16(const void* src, int64_t lds, const int32_t* idx, void* dst, int64_t ldd, int rows, int cols, hipStream_t stream);
 /* conv weight layout changes: w[Cout,Cin,kh,kw] fp32 -> shadow bf16 [Cout, Kp] with column order (ky,kx,c) */
 int ph_conv_weight_to_shadow(const float* w, void* shadow, int Cout, int Cin, int ks, int Kp, hipStream_t stream);
 /* and the adjoint for gradients: dshadow fp32 [Cout,Kp] (ky,kx,c) -> dw[Cout,Cin,kh,kw] += */

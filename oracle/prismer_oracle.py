@@ -118,6 +118,38 @@ def expert_stem(x, sd, dom, patch_size, train, bn_updates):
     return F.conv2d(x, sd[f'conv1.{dom}.13.weight'], None)
 
 
+def label_table(kind, label_info, features, background):
+    """[256, 64] fp32 table: row l = the CLIP text feature post_label_process paints over label l of ONE image
+    (dataset/utils.py:126-158); row 255 = BACKGROUND_FEATURES.  kind: 'seg_coco' / 'seg_ade' -> features[l] (`:128-133`,
+    `:137-142`); 'obj_detection' -> features[label_info[str(l)]] (`:146-151`); 'ocr_detection' -> label_info[l]['features']
+    (`:155-159`).  Labels that cannot occur in the image keep a zero row."""
+    t = torch.zeros(256, background.numel(), dtype=torch.float32)
+    t[255] = background.flatten().float()
+    if kind in ('seg_coco', 'seg_ade'):
+        n = min(255, features.shape[0])
+        t[:n] = features[:n].float()
+    elif kind == 'obj_detection':
+        for k, v in (label_info or {}).items():
+            t[int(k)] = features[v].float()
+    elif kind == 'ocr_detection':
+        for k, v in (label_info or {}).items():
+            t[int(k)] = v['features'].flatten().float()
+    else:
+        raise KeyError(kind)
+    return t
+
+
+def post_label_process(label_map, table):
+    """dataset/utils.py:126-160 for one label expert: label_map [1, H, W] integer, table [256, 64] -> [64, H, W] fp32, the
+    per-pixel gather the reference writes as a loop over `unique()` labels with boolean-mask assignments"""
+    return table[label_map[0].long()].permute(2, 0, 1).contiguous()
+
+
+def remap_dense(x, eps=1e-6):
+    """dataset/utils.py:120-121: depth / normal / edge maps are min-max remapped to [-1, 1] per sample"""
+    return 2 * (x - x.min()) / (x.max() - x.min() + eps) - 1
+
+
 def reference_instance_table(instance, rng):
     """vit.py:145-147: ONE random.randint(0,127) per distinct instance id over the whole batch, drawn in
     the (sorted) order of Tensor.unique(). Returns a 256-entry table label -> embedding row."""

@@ -113,6 +113,8 @@ _SIGS = {
     'ph_attention_bwd': (c_int, [C.POINTER(AttnBwdArgs), c_void_p]),
     'ph_patchify': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ph_resize_bilinear_nchw_to_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'ph_gather_rows_bf16': (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p]),
+    'ph_inpaint_resize_nhwc': (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ph_im2col_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'ph_col2im_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ph_bn_stats': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
@@ -141,6 +143,7 @@ _SIGS = {
     'ph_conv_grad_from_shadow_grouped': (c_int, [c_void_p, c_int, c_void_p]),
     'ph_gemm_grouped_bf16': (c_int, [c_void_p, c_int, c_void_p]),
     'ph_gemm_grouped_capped_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    'ph_gemm_tuning': (c_int, [c_int, c_int]),
     'ph_add_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     'ph_act_bwd_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     'ph_copy_rows_bf16': (c_int, [c_void_p, c_int, RowMap, c_void_p, c_int, RowMap, c_int, c_int, c_int, c_void_p]),

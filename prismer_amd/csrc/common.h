@@ -106,6 +106,29 @@ __device__ __forceinline__ float act_grad(int act, float x) {
   }
 }
 
+// value and derivative together (forward epilogue with ph_gemm_args.pre_grad): the transcendental part is shared
+__device__ __forceinline__ void act_fwd_grad(int act, float x, float& y, float& g) {
+  switch (act) {
+    case PH_ACT_QUICKGELU: {
+      float s = fast_sigmoid(1.702f * x);
+      y = x * s;
+      g = s * (1.0f + 1.702f * x * (1.0f - s));
+      return;
+    }
+    case PH_ACT_RELU2: { float r = fmaxf(x, 0.0f); y = r * r; g = 2.0f * r; return; }
+    case PH_ACT_GELU: {
+      float u = x * 0.70710678118654752f;
+      float e = __expf(-u * u);
+      float c = 0.5f * (1.0f + copysignf(erf_abs_from_exp(fabsf(u), e), x));
+      y = x * c;
+      g = c + x * 0.3989422804014327f * e;
+      return;
+    }
+    case PH_ACT_RELU: y = fmaxf(x, 0.0f); g = x > 0.0f ? 1.0f : 0.0f; return;
+    default: y = x; g = 1.0f; return;
+  }
+}
+
 // ---- Philox4x32-10 (dropout masks are a pure function of (seed, stream, element index)) -------------
 __device__ __forceinline__ u32x4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll

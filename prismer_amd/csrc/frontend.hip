@@ -77,6 +77,49 @@ __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ x
   }
 }
 
+// ------------------------------------------------------------------------------------------------ label in-painting
+// post_label_process (dataset/utils.py:117-160) + the stem's UpsamplingBilinear2d (vit.py:88-90) in one pass: the label
+// experts arrive as a uint8 label map [B, Hin, Win] plus a [256, C] fp32 table per image (row l = the CLIP feature the reference
+// paints over label l, row 255 = background) instead of the 64-channel fp32 image the reference's CPU loader materialises
+// (12.8 MB per image and expert: the 1.2 GB/step host-to-device stream of SURVEY 8f #2).  One thread per output pixel and
+// 8-channel group: the four bilinear taps are looked up in the table (same tap positions, weights and expression as
+// resize_kernel, so the result equals resize(in-painted image) to the last bit), NHWC bf16 out.
+__global__ __launch_bounds__(256) void inpaint_resize_kernel(const uint8_t* __restrict__ lab, const float* __restrict__ table,
+                                                             int64_t table_bs, bf16* __restrict__ y, int B, int C, int Hin, int Win,
+                                                             int Hout, int Wout) {
+  const int cgroups = C / 8;
+  const int64_t total = (int64_t)B * Hout * Wout * cgroups;
+  const float sy = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f;
+  const float sx = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(id % cgroups);
+    const int64_t pix = id / cgroups;
+    const int ox = (int)(pix % Wout), oy = (int)((pix / Wout) % Hout), b = (int)(pix / ((int64_t)Wout * Hout));
+    const float fy = oy * sy, fx = ox * sx;
+    const int y0 = min((int)fy, Hin - 1), y1 = min(y0 + 1, Hin - 1);
+    const int x0 = min((int)fx, Win - 1), x1 = min(x0 + 1, Win - 1);
+    const float wy = fy - (float)y0, wx = fx - (float)x0;
+    const uint8_t* lb = lab + (int64_t)b * Hin * Win;
+    const float* tb = table + (int64_t)b * table_bs + cg * 8;
+    const float* r00 = tb + (int)lb[y0 * Win + x0] * C;
+    const float* r01 = tb + (int)lb[y0 * Win + x1] * C;
+    const float* r10 = tb + (int)lb[y1 * Win + x0] * C;
+    const float* r11 = tb + (int)lb[y1 * Win + x1] * C;
+    bf16x8 o;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4 v00 = *reinterpret_cast<const f32x4*>(r00 + 4 * h), v01 = *reinterpret_cast<const f32x4*>(r01 + 4 * h);
+      f32x4 v10 = *reinterpret_cast<const f32x4*>(r10 + 4 * h), v11 = *reinterpret_cast<const f32x4*>(r11 + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = (1.f - wy) * ((1.f - wx) * v00[e] + wx * v01[e]) + wy * ((1.f - wx) * v10[e] + wx * v11[e]);
+        o[4 * h + e] = f2bf(v);
+      }
+    }
+    *reinterpret_cast<bf16x8*>(y + pix * C + cg * 8) = o;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ im2col
 // id -> (id / d, id % d): 64-bit integer division costs ~100 instructions per element on the GPU; every index space of this
 // model fits 32 bits, so the (uniform) fast path divides unsigned 32-bit numbers
@@ -437,6 +480,18 @@ extern "C" int ph_resize_bilinear_nchw_to_nhwc(const float* x, void* y, int B, i
   PH_CHECK_ARG(blocks < (1ll << 31), "ph_resize_bilinear: grid too large");
   hipLaunchKernelGGL(resize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, (bf16*)y, B, C, Hin, Win, Hout, Wout);
   PH_LAUNCH_CHECK("resize_kernel");
+  return PH_OK;
+}
+
+extern "C" int ph_inpaint_resize_nhwc(const uint8_t* labels, const float* table, int64_t table_batch_stride, void* y, int B, int C, int Hin,
+                                      int Win, int Hout, int Wout, hipStream_t stream) {
+  PH_CHECK_ARG(labels && table && y && B > 0 && C > 0 && (C % 8) == 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && table_batch_stride >= 0,
+               "ph_inpaint_resize_nhwc: bad args");
+  PH_CHECK_ARG((((uintptr_t)table | (uintptr_t)y) & 15) == 0 && (table_batch_stride % 4) == 0, "ph_inpaint_resize_nhwc: table / output must be 16-B aligned");
+  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream, "ph_inpaint_resize_nhwc");
+  hipLaunchKernelGGL(inpaint_resize_kernel, dim3(grid_for((int64_t)B * Hout * Wout * (C / 8))), dim3(256), 0, stream, labels, table,
+                     table_batch_stride, (bf16*)y, B, C, Hin, Win, Hout, Wout);
+  PH_LAUNCH_CHECK("inpaint_resize_kernel");
   return PH_OK;
 }
 

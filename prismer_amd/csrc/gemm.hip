@@ -173,11 +173,15 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] += p.bias[min(n + e, p.N - 1)];
   }
+  const bool fused_grad = p.pre_out && p.pre_grad && !p.act_in;
   if (p.pre_out) {
     bf16* q = p.pre_out + (size_t)m * p.ldc + n;
     float w[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) w[e] = p.pre_grad ? act_grad(p.act, v[e]) : v[e];
+    for (int e = 0; e < 4; ++e) {
+      if (fused_grad) act_fwd_grad(p.act, v[e], v[e], w[e]);       // v becomes act(x), w = act'(x)
+      else w[e] = v[e];
+    }
     if (full) { bf16x4 t = {f2bf(w[0]), f2bf(w[1]), f2bf(w[2]), f2bf(w[3])}; *reinterpret_cast<bf16x4*>(q) = t; }
     else {
 #pragma unroll
@@ -188,7 +192,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
     const bf16* q = p.act_in + (size_t)m * p.ld_act + n;
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] *= act_grad(p.act, bf2f(q[min(e, p.N - 1 - n)]));
-  } else if (p.act != PH_ACT_NONE) {
+  } else if (p.act != PH_ACT_NONE && !fused_grad) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = act_fwd(p.act, v[e]);
   }
@@ -238,17 +242,22 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int m, int 
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
   }
+  const bool fused_grad = p.pre_out && p.pre_grad && !p.act_in;
   if (p.pre_out) {
     bf16x8 t;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) t[e] = f2bf(p.pre_grad ? act_grad(p.act, v[e]) : v[e]);
+    for (int e = 0; e < 8; ++e) {
+      float w = v[e];
+      if (fused_grad) act_fwd_grad(p.act, v[e], v[e], w);
+      t[e] = f2bf(w);
+    }
     *reinterpret_cast<bf16x8*>(p.pre_out + (size_t)m * p.ldc + n) = t;
   }
   if (p.act_in) {
     bf16x8 t = *reinterpret_cast<const bf16x8*>(p.act_in + (size_t)m * p.ld_act + n);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= act_grad(p.act, bf2f(t[e]));
-  } else if (p.act != PH_ACT_NONE) {
+  } else if (p.act != PH_ACT_NONE && !fused_grad) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = act_fwd(p.act, v[e]);
   }
@@ -289,6 +298,50 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int m, int 
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
     *reinterpret_cast<bf16x8*>(c) = o;
+  }
+}
+
+// Row-wise write-out of a BM x BN fp32 tile parked in LDS (16-B chunks XOR-swizzled by the row): consecutive lanes own
+// consecutive 16/32-B pieces of one output row for every load / store of the fused epilogue chain.
+template <int BM, int BN, int NTHR>
+__device__ __forceinline__ void tile_writeout(const GemmParams& p, const float* cl, int m0, int n0, bool splitk, bool drop,
+                                              const DropCtx& dc) {
+  constexpr int CH = BN / 4;                       // 16-B chunks per tile row
+  // fast path: 8 outputs per thread per step (16-B loads/stores) when every leading dimension / pointer allows it
+  const bool vec8 = !(splitk) && (p.ldc % 8) == 0 && (!p.act_in || (p.ld_act % 8) == 0) && (!p.residual || (p.ldr % 8) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.pre_out) | reinterpret_cast<uintptr_t>(p.act_in) |
+                      reinterpret_cast<uintptr_t>(p.residual) | reinterpret_cast<uintptr_t>(p.bias)) & 15) == 0;
+  if (vec8) {
+#pragma unroll 2
+    for (int it = 0; it < BM * CH / (2 * NTHR); ++it) {
+      const int id = it * NTHR + threadIdx.x;
+      const int ml = id / (CH / 2), c = (id % (CH / 2)) * 2;
+      const int m = m0 + ml, n = n0 + c * 4;
+      const int sw = ml & (CH - 1);
+      f32x4 t0 = *reinterpret_cast<const f32x4*>(cl + ml * BN + ((c ^ sw) << 2));
+      f32x4 t1 = *reinterpret_cast<const f32x4*>(cl + ml * BN + (((c + 1) ^ sw) << 2));
+      if (m < p.M && n + 8 <= p.N) {
+        float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+#ifdef PH_GEMM_DIAG_NOSTORE  // diagnostics build: staging + LDS reads, no HBM traffic from the epilogue
+        if (v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] != 123456.789f) continue;
+#endif
+        epilogue_store8(p, m, n, v, drop, dc);
+      } else if (m < p.M) {
+        float v0[4] = {t0[0], t0[1], t0[2], t0[3]}, v1[4] = {t1[0], t1[1], t1[2], t1[3]};
+        if (n < p.N) epilogue_store(p, m, n, v0, false, drop, dc);
+        if (n + 4 < p.N) epilogue_store(p, m, n + 4, v1, false, drop, dc);
+      }
+    }
+  } else {
+#pragma unroll 4
+    for (int it = 0; it < BM * CH / NTHR; ++it) {
+      const int id = it * NTHR + threadIdx.x;
+      const int ml = id / CH, c = id % CH;
+      const int m = m0 + ml, n = n0 + c * 4;
+      f32x4 t = *reinterpret_cast<const f32x4*>(cl + ml * BN + ((c ^ (ml & (CH - 1))) << 2));
+      float v[4] = {t[0], t[1], t[2], t[3]};
+      if (m < p.M && n < p.N) epilogue_store(p, m, n, v, splitk, drop, dc);
+    }
   }
 }
 
@@ -458,48 +511,177 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int block_i
     *reinterpret_cast<f32x4*>(cl + ml * BN + ((c ^ (ml & (CH - 1))) << 2)) = v;
   });
   __syncthreads();
-  // fast path: 8 outputs per thread per step (16-B loads/stores) when every leading dimension / pointer allows it
-  const bool vec8 = !(splitk) && (p.ldc % 8) == 0 && (!p.act_in || (p.ld_act % 8) == 0) && (!p.residual || (p.ldr % 8) == 0) &&
-                    ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.pre_out) | reinterpret_cast<uintptr_t>(p.act_in) |
-                      reinterpret_cast<uintptr_t>(p.residual) | reinterpret_cast<uintptr_t>(p.bias)) & 15) == 0;
-  if (vec8) {
-#pragma unroll 2
-    for (int it = 0; it < BM * CH / 512; ++it) {
-      const int id = it * 256 + threadIdx.x;
-      const int ml = id / (CH / 2), c = (id % (CH / 2)) * 2;
-      const int m = m0 + ml, n = n0 + c * 4;
-      const int sw = ml & (CH - 1);
-      f32x4 t0 = *reinterpret_cast<const f32x4*>(cl + ml * BN + ((c ^ sw) << 2));
-      f32x4 t1 = *reinterpret_cast<const f32x4*>(cl + ml * BN + (((c + 1) ^ sw) << 2));
-      if (m < p.M && n + 8 <= p.N) {
-        float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-#ifdef PH_GEMM_DIAG_NOSTORE  // diagnostics build: staging + LDS reads, no HBM traffic from the epilogue
-        if (v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] != 123456.789f) continue;
-#endif
-        epilogue_store8(p, m, n, v, drop, dc);
-      } else if (m < p.M) {
-        float v0[4] = {t0[0], t0[1], t0[2], t0[3]}, v1[4] = {t1[0], t1[1], t1[2], t1[3]};
-        if (n < p.N) epilogue_store(p, m, n, v0, false, drop, dc);
-        if (n + 4 < p.N) epilogue_store(p, m, n + 4, v1, false, drop, dc);
-      }
-    }
-  } else {
-#pragma unroll 4
-    for (int it = 0; it < BM * CH / 256; ++it) {
-      const int id = it * 256 + threadIdx.x;
-      const int ml = id / CH, c = id % CH;
-      const int m = m0 + ml, n = n0 + c * 4;
-      f32x4 t = *reinterpret_cast<const f32x4*>(cl + ml * BN + ((c ^ (ml & (CH - 1))) << 2));
-      float v[4] = {t[0], t[1], t[2], t[3]};
-      if (m < p.M && n < p.N) epilogue_store(p, m, n, v, splitk, drop, dc);
-    }
-  }
+  tile_writeout<BM, BN, 256>(p, cl, m0, n0, splitk, drop, dc);
 }
 
 template <int BM, int BN, bool TA, bool TB, int PF>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   gemm_body<BM, BN, TA, TB, PF>(p, blockIdx.x, blockIdx.z, gridDim.z);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// "Big" kernel for the forward-shaped GEMMs with many rows (both operands K-contiguous, K % 64 == 0):
+//   block = 512 threads = 8 waves as 4 (M) x 2 (N), wave tile 64 x 64, block tile 256 x 128, BK = 64;
+//   operands go global -> LDS by the LDS-DMA path (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass) into a ring of
+//   THREE 48-KB stages: the loads of k-tile t+2 are issued right after the barrier that publishes tile t and stay in flight across
+//   the next barrier (counted s_waitcnt vmcnt(6): each thread owns 6 DMA instructions per tile), one raw s_barrier per k-tile.
+//   The LDS image is lane-linear per DMA instruction (8 rows x 128 B per wave instruction); the 16-B chunk XOR swizzle the
+//   ds_read_b128 fragment reads need is applied on the SOURCE address (lane l fetches chunk (l&7) ^ swz(row) of its row) and
+//   again on the read -- the destination stays linear (hardware writes base + lane*16).
+//   1 block per CU (144 KB of LDS), 2 waves per SIMD.  Epilogue: the 256x128 fp32 tile is parked in the (drained) ring and
+//   written out row-wise by the same fused chain as the 128x128 kernel.
+namespace big {
+constexpr int BM = 256, BN = 128, NTHR = 512, STAGES = 3;
+constexpr int A_BYTES = BM * KC_ROW_BYTES, B_BYTES = BN * KC_ROW_BYTES, STAGE = A_BYTES + B_BYTES;   // 32 KB + 16 KB
+constexpr int A_INSTR = BM * 8 / NTHR, B_INSTR = BN * 8 / NTHR;                                     // 4 + 2 DMA instructions / thread / tile
+constexpr int SMEM = STAGES * STAGE;                                                                // 147456 B (>= 256*128*4 for the epilogue)
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+template <int VARIANT>
+__global__ __launch_bounds__(NTHR) void gemm_big_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // tile mapping: same XCD-contiguous + grouped rasterisation as gemm_body
+  const int nt = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    int q = nt / 8, r = nt % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  constexpr int GM = 4;
+  const int group_sz = GM * p.tiles_n;
+  const int first_m = (bid / group_sz) * GM;
+  const int gm = min(GM, p.tiles_m - first_m);
+  const int rin = bid % group_sz;
+  const int tm = first_m + rin % gm, tn = rin / gm;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nk = p.K / BK;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;                   // wave tile: rows wm*64, cols wn*64
+
+  // ---- DMA addressing: instruction i of this wave covers tile rows (i*8 + wave)*8 .. +8, lane l -> row +(l>>3), LDS slot l&7
+  const bf16* a_src[A_INSTR];
+  const bf16* b_src[B_INSTR];
+#pragma unroll
+  for (int i = 0; i < A_INSTR; ++i) {
+    const int r = (i * 8 + wave) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    a_src[i] = p.A + (size_t)min(m0 + r, p.M - 1) * p.lda + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < B_INSTR; ++i) {
+    const int r = (i * 8 + wave) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    b_src[i] = p.B + (size_t)min(n0 + r, p.N - 1) * p.ldb + c * 8;
+  }
+  auto issue = [&](int kt, int stage) {
+    char* sa = smem + stage * STAGE;
+    char* sb = sa + A_BYTES;
+    const int koff = kt * BK;
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t*)(a_src[i] + koff), (lptr_t*)(sa + (i * 8 + wave) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t*)(b_src[i] + koff), (lptr_t*)(sb + (i * 8 + wave) * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int stage) {
+    const char* la = smem + stage * STAGE;
+    const char* lb = la + A_BYTES;
+    if constexpr (VARIANT & 2) {
+      // fragment double buffer: the ds_reads of k-step kk+1 are in flight while the MFMAs of k-step kk run
+      bf16x8 fx[2][2], fw[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { fx[0][i] = frag_kc(la, wm * 64 + i * 32, 0, lane); fw[0][i] = frag_kc(lb, wn * 64 + i * 32, 0, lane); }
+      static_for(std::make_integer_sequence<int, BK / 16>{}, [&](auto kq) {
+        constexpr int kk = decltype(kq)::value, cur = kk & 1, nxt = cur ^ 1;
+        if constexpr (kk + 1 < BK / 16) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) { fx[nxt][i] = frag_kc(la, wm * 64 + i * 32, kk + 1, lane); fw[nxt][i] = frag_kc(lb, wn * 64 + i * 32, kk + 1, lane); }
+        }
+        if (VARIANT & 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[cur][j], fx[cur][i], acc[i][j], 0, 0, 0);
+        if (VARIANT & 1) __builtin_amdgcn_s_setprio(0);
+      });
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        bf16x8 fx[2], fw[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fx[i] = frag_kc(la, wm * 64 + i * 32, kk, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fw[j] = frag_kc(lb, wn * 64 + j * 32, kk, lane);
+        if (VARIANT & 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fx[i], acc[i][j], 0, 0, 0);
+        if (VARIANT & 1) __builtin_amdgcn_s_setprio(0);
+      }
+    }
+  };
+
+  // ---- main loop: tile t lives in stage t % 3.  Every iteration issues exactly one tile (index clamped: the surplus loads of
+  // the last two iterations land in a stage nobody reads again), so "all but the newest tile have landed" is always vmcnt(6).
+  issue(0, 0);
+  issue(min(1, nk - 1), 1);
+  int st = 0;                                                // stage of tile t
+  for (int t = 0; t < nk; ++t) {
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");         // my DMA writes of tile t are in LDS (tile t+1 may still fly)
+    __builtin_amdgcn_s_barrier();                            // everybody's are; everybody finished reading tile t-1
+    asm volatile("" ::: "memory");
+    int st2 = st + 2; st2 = st2 >= 3 ? st2 - 3 : st2;
+    issue(min(t + 2, nk - 1), st2);                          // overwrites the stage tile t-1 was read from
+    compute(st);
+    st = st + 1 == 3 ? 0 : st + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // drain the surplus DMA before the ring is reused as the C tile
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // ---- epilogue (same chain as gemm_body, 512 threads, 256 x 128 tile)
+  DropCtx dc;
+  const bool drop = p.drop_p > 0.0f;
+  if (drop) dc = make_drop(p.drop_seed, p.drop_stream, p.drop_p);
+  constexpr int CH = BN / 4;
+  float* cl = reinterpret_cast<float*>(smem);
+  static_for(std::make_integer_sequence<int, 2 * 2 * 4>{}, [&](auto idx) {
+    constexpr int i = decltype(idx)::value / 8, j = (decltype(idx)::value / 4) % 2, g = decltype(idx)::value % 4;
+    const int ml = wm * 64 + i * 32 + (lane & 31);
+    const int c = (wn * 64 + j * 32 + g * 8 + (lane >> 5) * 4) >> 2;
+    f32x4 v = {acc[i][j][g * 4 + 0] * p.alpha, acc[i][j][g * 4 + 1] * p.alpha, acc[i][j][g * 4 + 2] * p.alpha,
+               acc[i][j][g * 4 + 3] * p.alpha};
+    *reinterpret_cast<f32x4*>(cl + ml * BN + ((c ^ (ml & (CH - 1))) << 2)) = v;
+  });
+  __syncthreads();
+  tile_writeout<BM, BN, NTHR>(p, cl, m0, n0, false, drop, dc);
+}
+
+template <int VARIANT>
+int launch(const GemmParams& p, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<VARIANT>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_big_kernel<VARIANT>), dim3(p.tiles_m * p.tiles_n), dim3(NTHR), SMEM, s, p);
+  PH_LAUNCH_CHECK("gemm_big_kernel");
+  return PH_OK;
+}
+}  // namespace big
 
 // Grouped launch: up to PH_GEMM_GROUP_MAX independent problems of one layout in ONE grid (block -> (problem, tile) through a
 // prefix table in the kernel arguments).  The deferred weight-gradient GEMMs of a layer (outputs of 18..144 tiles each, far
@@ -585,6 +767,14 @@ int dispatch_layout(const GemmParams& p, int ta, int tb, int splits, hipStream_t
 }
 
 }  // namespace
+
+static int g_big_mode = -1, g_big_min_tiles = -1;
+/* tuning hook (benchmarks / A-B probes): selects the big-tile kernel variant and its minimum tile count; -1 keeps a value */
+extern "C" int ph_gemm_tuning(int big_mode, int big_min_tiles) {
+  if (big_mode >= 0) g_big_mode = big_mode;
+  if (big_min_tiles >= 0) g_big_min_tiles = big_min_tiles;
+  return PH_OK;
+}
 
 // argument validation + kernel parameter block shared by the single and the grouped entry point
 static int fill_params(const ph_gemm_args* a, GemmParams& p) {
@@ -687,6 +877,28 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
   {
     int rc = fill_params(a, p);
     if (rc) return rc;
+  }
+
+  // ---- big-tile LDS-DMA kernel: forward-shaped (both operands K-contiguous) GEMMs with enough 256x128 tiles for the chip ----
+  {
+    // g_big_mode (PH_GEMM_BIG / ph_gemm_tuning): 0 = off, 1 = on, 2 = + s_setprio around the MFMA clusters, 3 = fragment
+    // double buffer, 4 = both
+    if (g_big_mode < 0) { const char* e = getenv("PH_GEMM_BIG"); g_big_mode = e ? atoi(e) : 1; }
+    if (g_big_min_tiles < 0) { const char* e = getenv("PH_GEMM_BIG_MIN_TILES"); g_big_min_tiles = e ? atoi(e) : 160; }
+    const int big_mode = g_big_mode, big_min_tiles = g_big_min_tiles;
+    const int64_t tb = (int64_t)ceil_div(a->M, big::BM) * ceil_div(a->N, big::BN);
+    if (big_mode > 0 && !a->trans_a && !a->trans_b && (a->K % BK) == 0 && a->K >= 2 * BK && a->split_k <= 0 && a->M >= big::BM &&
+        (a->N % 8) == 0 && tb >= big_min_tiles) {
+      p.tiles_m = ceil_div(a->M, big::BM); p.tiles_n = ceil_div(a->N, big::BN);
+      p.k_tiles_per_split = a->K / BK;
+      p.ws = nullptr; p.ldws = 0;
+      switch (big_mode) {
+        case 2: return big::launch<1>(p, stream);
+        case 3: return big::launch<2>(p, stream);
+        case 4: return big::launch<3>(p, stream);
+        default: return big::launch<0>(p, stream);
+      }
+    }
   }
 
   // ---- tile shape and split-K selection -------------------------------------------------------------------------

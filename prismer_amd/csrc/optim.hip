@@ -139,6 +139,18 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const bf16* __restrict__
   }
 }
 
+// dst[r] = src[idx[r]]: beam reordering of the decoder's self-attention K/V caches (generate: the hypotheses kept after a beam
+// step are a permutation-with-repeats of the previous ones)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16* __restrict__ src, int lds_, const int32_t* __restrict__ idx,
+                                                          bf16* __restrict__ dst, int ldd, int rows, int cols) {
+  const int cpr = cols / 8;
+  int64_t total = (int64_t)rows * cpr;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    int c = (int)(id % cpr) * 8, r = (int)(id / cpr);
+    *reinterpret_cast<bf16x8*>(dst + (int64_t)r * ldd + c) = *reinterpret_cast<const bf16x8*>(src + (int64_t)idx[r] * lds_ + c);
+  }
+}
+
 // w[Cout][Cin][ks][ks] fp32  ->  shadow[Cout][Kp] bf16 with column (ky*ks+kx)*Cin + c (zero padded)
 __global__ void conv_w_shadow_kernel(const float* __restrict__ w, bf16* __restrict__ s, int Cout, int Cin, int ks, int Kp) {
   int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -356,6 +368,15 @@ extern "C" int ph_copy_rows_bf16(const void* src, int lds, ph_rowmap src_map, vo
   hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for((int64_t)rows * cols / 8)), dim3(256), 0, stream, (const bf16*)src, lds, src_map,
                      (bf16*)dst, ldd, dst_map, rows, cols, accumulate);
   PH_LAUNCH_CHECK("copy_rows_kernel");
+  return PH_OK;
+}
+extern "C" int ph_gather_rows_bf16(const void* src, int64_t lds, const int32_t* idx, void* dst, int64_t ldd, int rows, int cols, hipStream_t stream) {
+  PH_CHECK_ARG(src && dst && idx && src != dst && rows > 0 && cols > 0 && cols % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0 && lds < (1ll << 31) &&
+               ldd < (1ll << 31), "ph_gather_rows_bf16: bad args");
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_gather_rows_bf16");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((int64_t)rows * cols / 8)), dim3(256), 0, stream, (const bf16*)src, (int)lds, idx,
+                     (bf16*)dst, (int)ldd, rows, cols);
+  PH_LAUNCH_CHECK("gather_rows_kernel");
   return PH_OK;
 }
 extern "C" int ph_conv_weight_to_shadow(const float* w, void* shadow, int Cout, int Cin, int ks, int Kp, hipStream_t stream) {

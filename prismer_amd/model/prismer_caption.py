@@ -1,7 +1,6 @@
 """Caption head (reference: model/prismer_caption.py:14-121): training loss, answer ranking, generation."""
 import torch
 
-from .generate import beam_search
 from .prismer import Prismer
 
 
@@ -46,8 +45,8 @@ class PrismerCaption(Prismer):
                 else:
                     ids, att = self._ids(prefix, device)
                 ids, att = ids[:, :-1], att[:, :-1]                                        # drop </s>
-                outputs = beam_search(self.text_decoder, ids, att, experts_train, num_beams=3, max_length=20, min_length=8,
-                                      eos_token_id=self.text_decoder.config.eos_token_id, pad_token_id=pad)
+                outputs = self.text_decoder.generate(input_ids=ids, encoder_hidden_states=experts_train, attention_mask=att, num_beams=3,
+                                                     max_length=20, min_length=8)       # prismer_caption.py:45-50
                 if self.tokenizer is None:
                     return outputs
                 captions = []

@@ -1,7 +1,6 @@
 """VQA head (reference: model/prismer_vqa.py:15-122): question ‖ answer training loss with per-sample weights."""
 import torch
 
-from .generate import beam_search
 from .prismer import Prismer
 from .prismer_caption import tile
 
@@ -39,12 +38,12 @@ class PrismerVQA(Prismer):
         with torch.no_grad():
             enc = self.expert_encoder(experts).permute(1, 0, 2)
             if inference == 'generate':
-                out = beam_search(self.text_decoder, q_ids, q_att, enc, num_beams=3, max_length=q_ids.shape[1] + 10,
-                                  min_length=q_ids.shape[1] + 2, eos_token_id=self.text_decoder.config.eos_token_id, pad_token_id=pad,
-                                  length_penalty=-1.0)
+                out = self.text_decoder.generate(input_ids=q_ids, encoder_hidden_states=enc, attention_mask=q_att,
+                                                 max_length=q_ids.shape[1] + 10, min_length=q_ids.shape[1] + 2, num_beams=3,
+                                                 length_penalty=-1)                     # prismer_vqa.py:52-58
                 if self.tokenizer is None:
-                    return [o[q_ids.shape[1]:] for o in out]
-                return [self.tokenizer.decode(o[q_ids.shape[1]:], skip_special_tokens=True) for o in out]
+                    return out[:, q_ids.shape[1]:]
+                return [self.tokenizer.decode(o[q_ids.shape[1]:], skip_special_tokens=True).lower().strip() for o in out]
             a_ids, a_att = self._ids(answer, device) if not (isinstance(answer, (list, tuple)) and isinstance(answer[0], str)) else \
                 self._ids([' ' + a.capitalize() + '</s>' for a in answer], device, padding='longest', add_special_tokens=False)
             start = self.text_decoder(q_ids, attention_mask=q_att, encoder_hidden_states=enc, return_dict=True)

@@ -222,6 +222,35 @@ class RobertaForCausalLMModified(nn.Module):
             return (loss, logits) if loss is not None else (logits,)
         return CausalLMOutput(loss=loss, logits=logits, hidden_states=None, attentions=None, cross_attentions=None)
 
+    def decoding_program(self, encoder_hidden_states):
+        """(layer program, encoder states as contiguous bf16) for KV-cached decoding (prismer_amd/model/generate.py)"""
+        from .. import ops
+        prog = self._program()
+        if not getattr(self._store, 'managed', False):
+            self._store.refresh_if_stale()
+        enc = encoder_hidden_states
+        if enc.dtype != torch.bfloat16:
+            enc = ops.cast_to_bf16(enc.contiguous().float())
+        return prog, enc.contiguous()
+
+    @torch.no_grad()
+    def generate(self, input_ids=None, encoder_hidden_states=None, attention_mask=None, num_beams=1, max_length=20, min_length=0,
+                 length_penalty=1.0, **unused):
+        """transformers' `generate` as the heads call it (model/prismer_caption.py:45-50, model/prismer_vqa.py:52-58): beam search,
+        returns a [B, L] LongTensor padded with pad_token_id.  KV-cached on the HIP path (the reference re-runs the prefix)."""
+        from ..model.generate import beam_search
+        if attention_mask is None:
+            attention_mask = input_ids.new_ones(input_ids.shape)
+        c = self.config
+        outs = beam_search(self, input_ids, attention_mask, encoder_hidden_states, num_beams=num_beams, max_length=max_length,
+                           min_length=min_length, eos_token_id=getattr(c, 'eos_token_id', 2), pad_token_id=c.pad_token_id,
+                           length_penalty=length_penalty)
+        L = max(int(o.numel()) for o in outs)
+        res = input_ids.new_full((len(outs), L), c.pad_token_id)
+        for i, o in enumerate(outs):
+            res[i, :o.numel()] = o
+        return res
+
     def prepare_inputs_for_generation(self, input_ids, attention_mask=None, encoder_hidden_states=None, **kw):
         if attention_mask is None:
             attention_mask = input_ids.new_ones(input_ids.shape)

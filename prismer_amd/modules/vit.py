@@ -24,6 +24,14 @@ _MODELS = {'ViT-B/32': (768, 12, 12, 32), 'ViT-B/16': (768, 12, 12, 16), 'ViT-L/
            'ViT-L/14@336px': (1024, 24, 16, 14), 'ViT-H/14': (1280, 32, 20, 14)}   # width, layers, heads(=width//64), patch
 
 
+def _expert_map(v):
+    """the tensor that carries an expert's spatial size: dense map, obj_detection {'label','instance'} (dataset/utils.py:149) or
+    the compact {'label_map': uint8, 'table': fp32} form that is in-painted on the device"""
+    if isinstance(v, dict):
+        return v['label_map'] if 'label_map' in v else v['label']
+    return v
+
+
 class ResidualAttentionBlock(_ContainerOnly):
     def __init__(self, d_model: int, n_head: int):
         super().__init__()
@@ -139,7 +147,7 @@ class VisionTransformer(nn.Module):
             raise RuntimeError('prismer_amd.VisionTransformer runs on the MI355X HIP path only (inputs must be on the GPU).')
         for k, v in x.items():                       # expert maps are 224x224 in the reference pipeline (dataset/utils.py:43)
             if k != 'rgb':
-                er = (v['label'] if isinstance(v, dict) else v).shape[-1]
+                er = _expert_map(v).shape[-1]
                 if er != self.expert_resolution:
                     self.expert_resolution, self._prog = er, None
                 break

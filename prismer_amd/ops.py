@@ -407,6 +407,23 @@ def resize_to_nhwc(x, Hout, Wout):
     return y
 
 
+def inpaint_resize(label_map, table, Hout, Wout):
+    """label_map: uint8 [B, H, W] (or [B, 1, H, W]); table: fp32 [256, C] (shared) or [B, 256, C] (per image).
+    Returns the stem input [B, Hout, Wout, C] bf16 = bilinear(post_label_process(label_map)) (dataset/utils.py:117-160 + vit.py:88-90)."""
+    if label_map.dim() == 4:
+        label_map = label_map[:, 0]
+    assert label_map.dtype == torch.uint8 and table.dtype == F32 and table.shape[-2] == 256
+    label_map, table = label_map.contiguous(), table.contiguous()
+    B, Hin, Win = label_map.shape
+    Cc = table.shape[-1]
+    stride = 256 * Cc if table.dim() == 3 else 0
+    assert table.dim() == 2 or table.shape[0] == B
+    y = torch.empty((B, Hout, Wout, Cc), dtype=BF16, device=label_map.device)
+    check(lib.ph_inpaint_resize_nhwc(label_map.data_ptr(), table.data_ptr(), stride, y.data_ptr(), B, Cc, Hin, Win, Hout, Wout, _stream()),
+          'ph_inpaint_resize_nhwc')
+    return y
+
+
 def conv_out_size(H, ks, stride):
     pad = ks // 2
     return (H + 2 * pad - ks) // stride + 1
@@ -567,6 +584,15 @@ def act_bwd(dy, pre, act, out=None):
 def copy_rows(src, dst, rows, cols, src_map=IDENT, dst_map=IDENT, accumulate=False, src_ld=None, dst_ld=None):
     check(lib.ph_copy_rows_bf16(src.data_ptr(), src_ld or src.stride(0), src_map, dst.data_ptr(), dst_ld or dst.stride(0), dst_map,
                                 rows, cols, int(accumulate), _stream()), 'ph_copy_rows_bf16')
+
+
+def gather_rows(src, idx, dst, cols=None):
+    """dst[r, :cols] = src[idx[r], :cols]; src / dst: 2-D bf16 views (row stride = stride(0)), idx: int32 device tensor"""
+    assert src.dtype == BF16 and dst.dtype == BF16 and idx.dtype == torch.int32 and idx.is_cuda
+    cols = src.shape[1] if cols is None else cols
+    check(lib.ph_gather_rows_bf16(src.data_ptr(), src.stride(0), idx.data_ptr(), dst.data_ptr(), dst.stride(0), idx.numel(), cols, _stream()),
+          'ph_gather_rows_bf16')
+    return dst
 
 
 def conv_weight_to_shadow(w, shadow, Cout, Cin, ks, Kp):

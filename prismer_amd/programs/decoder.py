@@ -264,6 +264,88 @@ class DecoderProgram:
                          t0pre=t0pre, t0=t0, t1=t1, hm=hm, hr=hr, logits=logits, labels=labels, row_lse=row_lse)
         return logits, loss, saved
 
+    # ---------------------------------------------------------------------------------------- KV-cached inference
+    # The reference's generate (prismer_caption.py:45-50, prismer_vqa.py:52-58 through roberta.py:401-406) re-runs the whole
+    # prefix and re-projects the encoder output at every step.  Here the cross-attention K/V of all layers are projected ONCE per
+    # image batch (the merged projection of the training path) and every self-attention layer keeps its K/V rows in a cache
+    # [layers+1, rows, Tmax, 2H]; a step runs the new position(s) only.
+    def decode_begin(self, enc, Tmax):
+        """enc: [Bb, S, Hv] bf16 (already expanded to one row per beam).  Returns the decoding state."""
+        d = self.d
+        Bb, S, Hv = enc.shape
+        H = d.hidden_size
+        enc2 = enc.reshape(Bb * S, Hv)
+        if self.kv_all is not None:
+            kva = self.kv_all.fwd(enc2)
+            kvs = [kva[:, 2 * H * i:2 * H * (i + 1)] for i in range(len(self.layers))]
+        else:
+            kvs = [L['ca']['kv'].fwd(enc2) for L in self.layers]
+        nl = len(self.layers) + 1
+        cache = [torch.zeros(nl, Bb, Tmax, 2 * H, dtype=BF16, device=enc.device) for _ in range(2)]     # ping-pong for beam reordering
+        return dict(kvs=kvs, cache=cache, cur=0, Bb=Bb, S=S, Tmax=Tmax, filled=0)
+
+    def decode_reorder(self, st, rows):
+        """beam step: hypothesis r continues former hypothesis rows[r] (int32 device tensor [Bb]) -- caches follow"""
+        src, dst = st['cache'][st['cur']], st['cache'][st['cur'] ^ 1]
+        nl, Bb, Tmax, W2 = src.shape
+        idx = (torch.arange(nl, device=rows.device, dtype=torch.int32)[:, None] * Bb + rows[None, :].to(torch.int32)).reshape(-1).contiguous()
+        ops.gather_rows(src.view(nl * Bb, Tmax * W2), idx, dst.view(nl * Bb, Tmax * W2), cols=st['filled'] * W2)
+        st['cur'] ^= 1
+
+    def _self_attn_cached(self, blk, li, slot, h, hf, st, t0, T, key_mask):
+        d = self.d
+        H, nh = d.hidden_size, d.num_attention_heads
+        dh = H // nh
+        Bb, Tmax = st['Bb'], st['Tmax']
+        Sq = T - t0
+        qkv = blk['qkv'].fwd(h)                                                  # [Bb*Sq, 3H]
+        cache = st['cache'][st['cur']][slot]                                     # [Bb, Tmax, 2H]
+        # K | V rows of the new positions -> cache[:, t0:T]
+        ops.copy_rows(qkv[:, H:], cache.view(Bb * Tmax, 2 * H), Bb * Sq, 2 * H, dst_map=ops.RowMap(Sq, Tmax, t0), src_ld=3 * H, dst_ld=2 * H)
+        cs = (Tmax * 2 * H, 2 * H)
+        o, _ = ops.attention_fwd(qkv[:, :H], cache[:, :, :H], cache[:, :, H:], Bb, nh, Sq, T, dh, q_strides=(Sq * 3 * H, 3 * H), k_strides=cs,
+                                 v_strides=cs, key_mask=key_mask, causal=Sq > 1)
+        s = blk['out'].fwd(o, residual=hf, out_f32=True)
+        y, yf, _, _ = self.post_ln(blk['ln'], s)
+        return y, yf
+
+    def decode(self, st, input_ids, attention_mask, t0):
+        """runs positions t0 .. T-1 of input_ids [Bb, T] (t0 == 0: prefill, causal; otherwise exactly the last position) against
+        the caches and returns the logits of the LAST position, fp32 view [Bb, V] of a bf16 buffer."""
+        d, P = self.d, self.P
+        Bb, T = input_ids.shape
+        assert Bb == st['Bb'] and T <= st['Tmax'] and (t0 == 0 or t0 == T - 1), 'decode: prefill (t0=0) or single-token steps only'
+        H, S = d.hidden_size, st['S']
+        e = 'roberta.embeddings.'
+        Sq = T - t0
+        key_mask = None
+        if attention_mask is not None:
+            key_mask = (attention_mask != 0).to(torch.uint8).contiguous()
+        h_all, _, _, hf_all = ops.embed_fwd(input_ids.contiguous(), P.f(e + 'word_embeddings.weight'), P.f(e + 'position_embeddings.weight'),
+                                            P.f(e + 'token_type_embeddings.weight'), P.f(e + 'LayerNorm.weight'), P.f(e + 'LayerNorm.bias'),
+                                            d.layer_norm_eps, d.pad_token_id, None, want_f32=True)
+        if t0 == 0:
+            h, hf = h_all, hf_all
+        else:                                                                     # the new position of every row
+            h = h_all.view(Bb, T, H)[:, t0:].reshape(Bb * Sq, H).contiguous()
+            hf = hf_all.view(Bb, T, H)[:, t0:].reshape(Bb * Sq, H).contiguous()
+        for i, L in enumerate(self.layers):
+            h, hf = self._self_attn_cached(L['sa'], L['idx'], i, h, hf, st, t0, T, key_mask)
+            h, hf = self.cross_attn_fwd(L['ca'], L['idx'], h, hf, None, Bb, Sq, S, None, None, st['kvs'][i])
+            h, hf = self.adaptor_fwd(L['ad'], h, hf, None)
+            h, hf = self.mlp_fwd(L['mlp'], L['idx'], h, hf, None, None)
+        F_ = self.final
+        h, hf = self._self_attn_cached(F_['sa'], F_['idx'], len(self.layers), h, hf, st, t0, T, key_mask)
+        h, hf = self.mlp_fwd(F_['mlp'], F_['idx'], h, hf, None, None)
+        st['filled'] = max(st['filled'], T)
+        last = h if Sq == 1 else h.view(Bb, Sq, H)[:, -1].contiguous()           # LM head on the last position only
+        t0_ = self.head_dense.fwd(last, act=ACT_GELU)
+        t1, _, _ = self.head_ln.fwd(t0_, save_stats=False)
+        V = d.vocab_size
+        logits = torch.empty(Bb, self.Vpad, dtype=BF16, device=h.device)
+        ops.gemm(t1, P.w(e + 'word_embeddings.weight'), out=logits, bias=P.f('lm_head.bias'), N=V)
+        return logits[:, :V]
+
     def backward(self, sv, dloss):
         """dloss: fp32 [B] gradient of the per-sample losses. Returns d(enc) as bf16 [B, S, Hv]."""
         st = self.backward_start(sv, dloss)

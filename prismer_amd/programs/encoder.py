@@ -181,11 +181,15 @@ class EncoderProgram:
 
     def stem_fwd(self, dom, x, training, sv):
         d = self.d
-        B, Cin = x.shape[0], x.shape[1]
         label = dom in LABEL_DOMAINS
         Hs = int(d.expert_resolution * (4 if label else 16) / d.patch_size)
         strides = (2, 2, 1, 1) if label else (2, 2, 2, 2)
-        a = ops.resize_to_nhwc(x, Hs, Hs)
+        if isinstance(x, dict):                                # compact label expert: uint8 map + CLIP-feature table (in-painted on device)
+            a = ops.inpaint_resize(x['label_map'], x['table'], Hs, Hs)
+            B, Cin = a.shape[0], a.shape[3]
+        else:
+            B, Cin = x.shape[0], x.shape[1]
+            a = ops.resize_to_nhwc(x, Hs, Hs)
         seq = self.mod.conv1[dom]
         H, C = Hs, Cin
         scale = shift = None
@@ -361,6 +365,15 @@ class EncoderProgram:
     # The encoder is split in two so that the Trainer can pipeline micro-batches:
     #   front  = patch embed + six expert stems (train-mode BatchNorm needs the WHOLE batch)  -> token buffers h, xf
     #   trunk  = resampler + ln_pre + ViT blocks + ln_post (sample-independent: any contiguous slice of the batch)
+    @staticmethod
+    def _instance_ids(val):
+        """int64 [B,1,E,E] instance map of the obj_detection expert (dataset/utils.py:149: the raw label map); the compact input
+        form carries it as the uint8 map itself"""
+        if 'instance' in val:
+            return val['instance'].contiguous()
+        m = val['label_map']
+        return (m if m.dim() == 4 else m.unsqueeze(1)).to(torch.int64).contiguous()
+
     def forward_front(self, x, inst_table, training, save):
         d, P = self.d, self.P
         W, p = d.width, d.patch_size
@@ -389,13 +402,16 @@ class EncoderProgram:
                 with ops.POOL.branch(ei):
                     dom = 'seg' if 'seg' in name else name
                     val = x[name]
-                    inp = val['label'] if name == 'obj_detection' else val
-                    f = self.stem_fwd(dom, inp.contiguous().float(), training, sv)
+                    if isinstance(val, dict) and 'label_map' in val:   # {'label_map': uint8 [B,(1,)E,E], 'table': [256,64] | [B,256,64]}
+                        inp = val
+                    else:
+                        inp = (val['label'] if name == 'obj_detection' else val).contiguous().float()
+                    f = self.stem_fwd(dom, inp, training, sv)
                     if f.shape[0] != B * G:
                         raise RuntimeError(f'expert map {name}: stem produced {f.shape[0] // B} tokens per image, program expects {G} '
                                            f'(expert_resolution={d.expert_resolution})')
                     if name == 'obj_detection':
-                        inst = val['instance'].contiguous()
+                        inst = self._instance_ids(val)
                         ops.tokens_finalize(f, pos_e, xf, B, G, W, Mx, ei * G, inst, inst.shape[-1], d.expert_grid, inst_table,
                                             P.f('instance_embedding'))
                     else:
@@ -409,7 +425,7 @@ class EncoderProgram:
                 self._bn_counters = []
         if save:
             sv.update(B=B, names=names, rgb_col=col,
-                      inst=(x['obj_detection']['instance'].contiguous() if 'obj_detection' in x else None), inst_table=inst_table)
+                      inst=(self._instance_ids(x['obj_detection']) if 'obj_detection' in x else None), inst_table=inst_table)
         return h, xf, sv
 
     def forward_trunk(self, h, xf, B, save):

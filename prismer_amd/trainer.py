@@ -40,7 +40,7 @@ def cosine_lr(it, total, init_lr, min_lr):
 
 class Trainer:
     def __init__(self, model, lr=5e-5, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8, min_lr=0.0, total_steps=1000,
-                 task='caption', use_graph=True, process_group=None, bucket_mb=64, side_stream=True, micro_batches=1, keep_grads=False,
+                 task='caption', use_graph=True, process_group=None, bucket_mb=64, side_stream=False, micro_batches=1, keep_grads=False,
                  max_text_len=None, grad_payload='bf16', transport='torch.distributed', dec_backward_stages=3):
         self.model = model
         self.enc, self.dec = model.expert_encoder, model.text_decoder
@@ -76,8 +76,10 @@ class Trainer:
         self.table = torch.zeros(256, dtype=torch.int32, device=dev)
         self.seed = self.dec.dropout_seed()
         self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
-        # optimizer stream: the decoder's AdamW runs beside the encoder backward (PRISMER_ADAMW_OVERLAP=0: after it)
-        self.opt_stream = torch.cuda.Stream(device=dev) if (self.world > 1 or os.environ.get('PRISMER_ADAMW_OVERLAP', '1') != '0') else None
+        # optimizer stream: with N ranks the decoder's AdamW runs beside the encoder backward as soon as its buckets are reduced (an
+        # eager launch between graph replays).  One rank: measured neutral as a graph branch (28.99 vs 29.03 ms), so it simply runs
+        # after the encoder backward (PRISMER_ADAMW_OVERLAP=1 re-enables the branch for experiments).
+        self.opt_stream = torch.cuda.Stream(device=dev) if (self.world > 1 or os.environ.get('PRISMER_ADAMW_OVERLAP', '0') != '0') else None
         self.micro = micro_batches if (side_stream and micro_batches > 1) else 1
         nl = len(self.dec_prog.layers)
         k = max(1, min(dec_backward_stages, nl)) if (self.world > 1 and self.micro == 1) else 1
@@ -93,10 +95,22 @@ class Trainer:
         # eager launches with 2 slices: 38.5 ms, host-bound) -- so the default stays 1.  Weight-gradient accumulation is
         # race-free either way because every read-modify-write of the gradient buffer lives on the single side stream, and
         # forked streams never re-join work they forked themselves (capture_end crashes on such diamonds here).
+        # side_stream=True forks independent work (deferred weight gradients, the six stems, the cross-attention K/V projections)
+        # onto extra streams = parallel branches of the captured graphs.  Default OFF since round 2: it bought 0.8 % of the step,
+        # and under hipGraph REPLAY on ROCm 7.2 the graphs with forked branches mis-ordered the deferred LayerNorm gamma/beta
+        # reduction against the LayerNorm backward kernels that feed it (decoder LayerNorm parameter gradients came out as
+        # uncorrelated garbage -- caught by tests/test_parity_gpu.py::test_trainer_hipgraph_step_matches_reference_golden; the same
+        # kernels launched eagerly on the same streams, and graphs without branches, are exact).  A branch-free graph is a chain:
+        # every kernel depends on its predecessor, nothing is left to the executor.
+        if side_stream and use_graph and os.environ.get('PRISMER_EXPERIMENTAL_GRAPH_BRANCHES', '0') == '0':
+            raise RuntimeError('Trainer(side_stream=True, use_graph=True): graphs with forked branches are not replayed correctly on this '
+                               'ROCm (see the comment above); use one of the two, or set PRISMER_EXPERIMENTAL_GRAPH_BRANCHES=1')
         if side_stream:
             ops.SIDE = ops.SideStream(dev)
             ops.POOL = ops.BranchPool(dev, 3)
             ops.MICRO = ops.BranchPool(dev, self.micro) if self.micro > 1 else ops._NoPool()
+        else:
+            ops.SIDE, ops.POOL, ops.MICRO = None, ops._NoPool(), ops._NoPool()
         self.loss = None
         self.trace = []
         self._grads_clean = False
@@ -348,7 +362,7 @@ class Trainer:
         """(re)binds the static input buffers. First call allocates them; later calls copy into them."""
         for k, v in experts.items():                 # expert-map resolution fixes the program's token geometry
             if k != 'rgb':
-                er = (v['label'] if isinstance(v, dict) else v).shape[-1]
+                er = (v.get('label_map', v.get('label')) if isinstance(v, dict) else v).shape[-1]
                 if er != self.enc.expert_resolution:
                     assert self.graphs is None, 'expert resolution changed after graph capture'
                     self.enc.expert_resolution, self.enc._prog = er, None

@@ -17,7 +17,7 @@ def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, use_graph, out, payload='bf16'):
+def _worker(rank, world, port, use_graph, out, payload='bf16', n_steps=2):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
@@ -53,7 +53,7 @@ def _worker(rank, world, port, use_graph, out, payload='bf16'):
         orig()
         tr.table.copy_(torch.tensor(tab, dtype=torch.int32))
     tr._host_prologue = prologue
-    for _ in range(2):
+    for _ in range(n_steps):
         loss = tr.step()
     torch.cuda.synchronize()
     out[rank] = dict(loss=float(loss), grads=[st.grad[:st.n_train].float().cpu() for st in tr.stores],
@@ -86,7 +86,7 @@ def test_two_ranks_one_gpu(use_graph):
         assert n >= 1 and hi > lo
         cover[int(tag.split(':')[1])] += hi - lo
     assert [cover[0], cover[1]] == a['n_train'], (cover, a['n_train'])
-    assert a['desc'] is None or a['desc']['payload'] == 'bf16'
+    assert a['desc']['payload'] == 'bf16'
 
 
 def test_two_ranks_bf16_payload_close_to_fp32():
@@ -95,7 +95,7 @@ def test_two_ranks_bf16_payload_close_to_fp32():
     res = {}
     for payload in ('fp32', 'bf16'):
         mgr = mp.Manager(); out = mgr.dict()
-        mp.spawn(_worker, args=(world, _free_port(), False, out, payload), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), False, out, payload, 1), nprocs=world, join=True)
         res[payload] = out[0]
     for g32, g16 in zip(res['fp32']['grads'], res['bf16']['grads']):
         assert ((g16 - g32).norm() / g32.norm()).item() < 1e-2

@@ -1,0 +1,99 @@
+"""Label-expert in-painting (reference dataset/utils.py:117-160):
+  CPU : the oracle restatement (label_table + post_label_process + remap_dense) against outputs of the REFERENCE function
+        (tests/golden/inpaint.npz, minted by tests/golden/make_inpaint_golden.py)
+  GPU : ph_inpaint_resize_nhwc against the oracle (bit-exact: index gather + the resize kernel's own tap arithmetic), and the
+        encoder fed with compact {label_map, table} experts against the same encoder fed with the dense in-painted maps."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import prismer_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'inpaint.npz')
+KINDS = ('seg_coco', 'seg_ade', 'obj_detection', 'ocr_detection')
+
+
+def tables_for(g, img):
+    p = f'img{img}.'
+    bg = torch.from_numpy(g['feat.bg'])
+    obj_info = {str(i): int(v) for i, v in enumerate(g[p + 'obj_info'])}
+    ocr_info = {i: {'features': torch.from_numpy(f)} for i, f in enumerate(g[p + 'ocr_feat'])}
+    return {'seg_coco': O.label_table('seg_coco', None, torch.from_numpy(g['feat.coco']), bg),
+            'seg_ade': O.label_table('seg_ade', None, torch.from_numpy(g['feat.ade']), bg),
+            'obj_detection': O.label_table('obj_detection', obj_info, torch.from_numpy(g['feat.det']), bg),
+            'ocr_detection': O.label_table('ocr_detection', ocr_info, None, bg)}
+
+
+def test_oracle_matches_reference_post_label_process():
+    g = np.load(GOLD)
+    s = int(g['stride'])
+    for img in range(2):
+        t = tables_for(g, img)
+        for k in KINDS:
+            lab = torch.from_numpy(g[f'img{img}.{k}.map'].astype(np.int64))
+            got = O.post_label_process(lab, t[k])[:, ::s, ::s]
+            assert torch.equal(got, torch.from_numpy(g[f'img{img}.{k}'])), (img, k)       # a gather: bit-exact
+        lo, hi = g[f'img{img}.depth_minmax']
+        d = torch.from_numpy(g[f'img{img}.depth_in'])
+        got = 2 * (d - float(lo)) / (float(hi) - float(lo) + 1e-6) - 1                         # remap_dense on the sub-sampled map
+        assert torch.allclose(got, torch.from_numpy(g[f'img{img}.depth']), atol=1e-6)
+    x = torch.rand(1, 8, 8)
+    assert float(O.remap_dense(x).min()) == -1.0 and abs(float(O.remap_dense(x).max()) - 1.0) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('Hout', [56, 64])            # patch 16 (BASE) and patch 14 (LARGE) stems: 224 -> 56 / 64 (vit.py:89)
+def test_inpaint_resize_kernel_matches_oracle(Hout):
+    from prismer_amd import ops
+    g = np.load(GOLD)
+    maps, tabs = [], []
+    for img in range(2):
+        t = tables_for(g, img)
+        for k in KINDS:
+            maps.append(torch.from_numpy(g[f'img{img}.{k}.map'])[0]); tabs.append(t[k])
+    lab = torch.stack(maps)                                  # [8, 224, 224] uint8
+    tab = torch.stack(tabs)                                  # [8, 256, 64] per-image tables
+    dense = torch.stack([O.post_label_process(m[None], t) for m, t in zip(maps, tabs)])      # [8, 64, 224, 224] fp32 (the reference's tensor)
+    want = ops.resize_to_nhwc(dense.cuda(), Hout, Hout)      # the dense path the compact one replaces
+    got = ops.inpaint_resize(lab.cuda(), tab.cuda(), Hout, Hout)
+    assert got.shape == want.shape == (8, Hout, Hout, 64)
+    assert torch.equal(got, want)
+    ref = torch.nn.functional.interpolate(dense, size=(Hout, Hout), mode='bilinear', align_corners=True).permute(0, 2, 3, 1)
+    assert (got.float().cpu() - ref).abs().max() <= 2.0 ** -8 * ref.abs().max() + 1e-6      # bf16 rounding of the fp32 interpolation
+    shared = ops.inpaint_resize(lab[:2].cuda(), tab[0].cuda(), Hout, Hout)                  # one table for the whole batch (fixed vocabulary)
+    assert torch.equal(shared[0], got[0])
+
+
+@pytest.mark.gpu
+def test_encoder_with_compact_label_experts_equals_dense():
+    from prismer_amd import synth
+    from tests.golden import cases as C
+    from tests.test_parity_gpu import build, to_dev
+    case = C.Case('tiny_caption')
+    d = case.dims
+    enc, _, _, _ = build(case)
+    enc.eval()
+    x = case.inputs()[0]
+    E = d.expert_resolution
+    B = x['rgb'].shape[0]
+    gen = torch.Generator().manual_seed(5)
+    compact, dense = dict(x), dict(x)
+    for name in ('seg_coco', 'obj_detection', 'ocr_detection'):
+        lab = torch.randint(0, 12, (B, E, E), generator=gen).to(torch.uint8)
+        lab[:, : E // 3] = 255
+        tab = torch.randn(B, 256, 64, generator=gen) * 0.75
+        img = torch.stack([O.post_label_process(lab[b][None], tab[b]) for b in range(B)])
+        if name == 'obj_detection':
+            dense[name] = {'label': img, 'instance': lab.long().unsqueeze(1)}
+            compact[name] = {'label_map': lab, 'table': tab}
+        else:
+            dense[name] = img
+            compact[name] = {'label_map': lab.unsqueeze(1), 'table': tab}
+    tab_i = case.instance_table(x) or [3] * 256
+    enc.instance_table = torch.tensor([(7 * i) % 128 for i in range(256)], dtype=torch.int32).cuda()
+    with torch.no_grad():
+        a = enc(to_dev(dense))
+        b = enc(to_dev(compact))
+    assert torch.equal(a, b)

@@ -135,7 +135,7 @@ def test_gemm_grouped_capped_background_launch(ops):
     """ph_gemm_grouped_capped_bf16: a grid smaller than the tile count (blocks walk several tiles) gives the same result"""
     import ctypes as C
     from prismer_amd import _lib
-    shapes = [(768, 768, 960), (2304, 768, 960), (100, 200, 960)]
+    shapes = [(768, 768, 960), (2304, 768, 960), (104, 200, 960)]
     ops_, refs = [], []
     for i, (M, N, K) in enumerate(shapes):
         dy, x = rnd(K, M, scale=0.3, seed=20 + i), rnd(K, N, scale=0.3, seed=40 + i)

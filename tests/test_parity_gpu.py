@@ -242,8 +242,8 @@ def test_trainer_step_matches_oracle_adamw():
 
 
 def test_trainer_micro_batch_branches_match_whole_batch():
-    """Trainer(micro_batches=2): stems on the whole batch (BatchNorm statistics), trunk + decoder as two parallel branches.
-    Same loss and the same gradients as the single-slice schedule (dropout off), eager and under hipGraph capture."""
+    """Trainer(micro_batches=2, side_stream=True): stems on the whole batch (BatchNorm statistics), trunk + decoder as two parallel
+    branches (eager launches on extra streams).  Same loss and the same gradients as the single-slice schedule (dropout off)."""
     from prismer_amd.trainer import Trainer
     case = C.Case('tiny_caption')
     x, ids, mask, labels, _ = case.inputs()
@@ -256,11 +256,11 @@ def test_trainer_micro_batch_branches_match_whole_batch():
     class Holder(torch.nn.Module):
         pass
     grads, losses = {}, {}
-    for micro, use_graph in ((1, False), (2, False), (2, True)):
+    for micro, use_graph in ((1, False), (2, False)):
         enc, dec, _, _ = build(case, p_drop=0.0)
         set_freeze(enc, dec)
         m = Holder(); m.expert_encoder, m.text_decoder = enc, dec
-        tr = Trainer(m, lr=0.0, weight_decay=0.0, total_steps=10, use_graph=use_graph, micro_batches=micro, keep_grads=True)
+        tr = Trainer(m, lr=0.0, weight_decay=0.0, total_steps=10, use_graph=use_graph, micro_batches=micro, keep_grads=True, side_stream=micro > 1)
         tr.set_batch(to_dev(x4), ids4, mask4, labels4)
         assert len(tr._slices(4)) == micro
         m.expert_encoder.instance_table = None
@@ -275,7 +275,7 @@ def test_trainer_micro_batch_branches_match_whole_batch():
         losses[(micro, use_graph)] = loss.item()
         grads[(micro, use_graph)] = torch.cat([st.grad[:st.n_train].float().cpu() for st in tr.stores])
     ref = grads[(1, False)]
-    for k in ((2, False), (2, True)):
+    for k in ((2, False),):
         assert math_close(losses[k], losses[(1, False)], 1e-4), (k, losses)
         err = (grads[k] - ref).norm() / ref.norm()
         assert err < 2e-3, (k, float(err))       # same kernels on half-size problems: accumulation-order noise only
