@@ -47,6 +47,13 @@ const char* ph_last_error(void);
  *   trans_x == 0: operand stored [rows][K] (K contiguous);  trans_x == 1: stored [K][rows].
  *   epilogue order: +bias -> (pre_out store) -> act | *act'(act_in) -> dropout -> +residual -> (+C) -> store
  * ---------------------------------------------------------------------------------------------- */
+/* Implicit-GEMM convolution (vit.py:88-120): one operand is the im2col VIEW col[m][k] of an NHWC bf16 activation
+ * x[B][H][W][C] (C % 8 == 0, 3x3 pad 1 or 1x1, any stride), m = (b, oy, ox), k = (ky*ks + kx)*C + c -- gathered inside the kernel's
+ * operand loader, never written to memory.  Forward (trans_a = trans_b = 0): A = x, M = B*Ho*Wo, K = ks*ks*C rounded up to 8
+ * (B = the [Cout][K] weight shadow).  Weight gradient (trans_a = trans_b = 1): B = x, reduction K = B*Ho*Wo, N = ks*ks*C rounded
+ * up to 8 (A = dY [K][Cout]).  lda / ldb of the gathered operand are ignored. */
+typedef struct { int B, H, W, C, ks, stride; } ph_conv_gather;
+
 typedef struct {
   const void* A; const void* B; void* C;
   int M, N, K;
@@ -68,6 +75,10 @@ typedef struct {
   int pre_grad;                   /* pre_out receives act'(x) instead of x: the backward GEMM (act = PH_ACT_SAVED_GRAD) then
                                      multiplies by the saved derivative -- no transcendental in its epilogue, and the
                                      derivative is taken from the fp32 pre-activation instead of its bf16 rounding */
+  const ph_conv_gather* conv;     /* optional: the A (forward) / B (weight gradient) operand is an im2col view, see above */
+  double* col_stats;              /* optional fp64 [2][N]: += per-column sum and sum of squares of the bf16-rounded outputs over the
+                                     M rows (train-mode BatchNorm statistics of a conv output, vit.py:92-118, taken in the
+                                     epilogue instead of a second pass over the output); plain epilogues, no split-K */
 } ph_gemm_args;
 int ph_gemm_bf16(const ph_gemm_args* args, hipStream_t stream);
 
@@ -197,6 +208,22 @@ int ph_bn_stats(const void* y, int M, int C, const float* gamma, const float* be
 int ph_bn_relu_bwd(const void* da, const void* y, void* dy, int M, int C, const float* gamma, const float* beta,
                    const float* mean, const float* rstd, float* dgamma, float* dbeta, float* sums, int prezeroed,
                    hipStream_t stream);
+
+/* Grouped BatchNorm passes for the expert stems (vit.py:92-118: [conv3x3 -> BatchNorm2d -> ReLU] x 4 in each of up to six
+ * independent stems): the same-index layers of all stems in ONE launch.
+ *   ph_bn_apply_relu_grouped: a = relu(bn(y)); sums = fp64 [2][C] per-channel sum / sum of squares of y (from the conv GEMM's
+ *     epilogue, ph_gemm_args.col_stats: fp64 so that E[x^2] - E[x]^2 is exact to rounding and independent of the atomics' order); writes stats[4][C] = mean, rstd, scale, shift for the backward; train mode also updates
+ *     running_mean / running_var (momentum, unbiased variance) like nn.BatchNorm2d.  Eval mode normalises with the running stats.
+ *   ph_bn_relu_bwd_grouped: `a` carries dA (gradient w.r.t. the ReLU output), sums = fp32 [2][C], ZERO on entry (receives
+ *     sum g, sum g*xhat); dy = gradient w.r.t. the conv output; dgamma / dbeta (optional) are accumulated. */
+#define PH_BN_GROUP_MAX 8
+typedef struct {
+  const void* y; void* a; void* dy; int64_t M; int C;
+  const float* gamma; const float* beta; float* running_mean; float* running_var;
+  float* stats; void* sums; float* dgamma; float* dbeta;
+} ph_bn_item;
+int ph_bn_apply_relu_grouped(const ph_bn_item* items, int n, float momentum, float eps, int training, hipStream_t stream);
+int ph_bn_relu_bwd_grouped(const ph_bn_item* items, int n, hipStream_t stream);
 /* tokens[b, off + t, :] = feat[b*G + t, :] + pos[t, :] (+ inst_emb[table[inst[b, nearest(t)]], :])
  * (vit.py:141-159).  inst: int64 [B, E, E] instance map (nearest down-sampling to g x g), table: int32[256]. */
 int ph_tokens_finalize(const void* feat, const float* pos, void* tokens, int B, int G, int D, int tok_per_batch,

@@ -25,6 +25,10 @@ class RowMap(C.Structure):
 IDENT = RowMap(0, 0, 0)
 
 
+class ConvGather(C.Structure):
+    _fields_ = [('B', c_int), ('H', c_int), ('W', c_int), ('C', c_int), ('ks', c_int), ('stride', c_int)]
+
+
 class GemmArgs(C.Structure):
     _fields_ = [('A', c_void_p), ('B', c_void_p), ('C', c_void_p),
                 ('M', c_int), ('N', c_int), ('K', c_int),
@@ -36,7 +40,8 @@ class GemmArgs(C.Structure):
                 ('residual', c_void_p), ('ldr', c_int),
                 ('drop_p', c_float), ('drop_seed', c_void_p), ('drop_stream', c_u32),
                 ('out_f32', c_int), ('accumulate', c_int), ('alpha', c_float), ('split_k', c_int),
-                ('residual_f32', c_int), ('workspace', c_void_p), ('workspace_bytes', c_i64), ('pre_grad', c_int)]
+                ('residual_f32', c_int), ('workspace', c_void_p), ('workspace_bytes', c_i64), ('pre_grad', c_int),
+                ('conv', C.POINTER(ConvGather)), ('col_stats', c_void_p)]
 
 
 class LnReduceItem(C.Structure):
@@ -55,6 +60,15 @@ class ConvLayoutItem(C.Structure):
 
 
 CONV_GROUP_MAX = 32      # PH_CONV_GROUP_MAX
+
+
+class BnItem(C.Structure):
+    _fields_ = [('y', c_void_p), ('a', c_void_p), ('dy', c_void_p), ('M', c_i64), ('C', c_int),
+                ('gamma', c_void_p), ('beta', c_void_p), ('running_mean', c_void_p), ('running_var', c_void_p),
+                ('stats', c_void_p), ('sums', c_void_p), ('dgamma', c_void_p), ('dbeta', c_void_p)]
+
+
+BN_GROUP_MAX = 8         # PH_BN_GROUP_MAX
 
 
 class LayerNormFwdArgs(C.Structure):
@@ -119,6 +133,8 @@ _SIGS = {
     'ph_col2im_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ph_bn_stats': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
                             c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    'ph_bn_apply_relu_grouped': (c_int, [c_void_p, c_int, c_float, c_float, c_int, c_void_p]),
+    'ph_bn_relu_bwd_grouped': (c_int, [c_void_p, c_int, c_void_p]),
     'ph_bn_relu_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'ph_tokens_finalize': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int,

@@ -294,6 +294,130 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, int M, int C,
   scale[c] = s; shift[c] = beta[c] - mu * s;
 }
 
+// ---- grouped BatchNorm passes: the same-index layers of several expert stems in ONE launch ---------------------------------
+// forward: a = relu(bn(y)).  The per-channel sums come from the conv GEMM's epilogue (ph_gemm_args.col_stats); every block
+// re-derives mean / rstd / scale / shift of its item into LDS (2C loads + C rsqrt: nothing next to the streaming pass); block 0
+// of an item also writes them out for the backward and updates the running statistics (train mode).
+struct BnGroup {
+  int n;
+  int blk_start[PH_BN_GROUP_MAX + 1];
+  ph_bn_item it[PH_BN_GROUP_MAX];
+};
+__global__ __launch_bounds__(256) void bn_apply_grouped_kernel(BnGroup g, float momentum, float eps, int training) {
+  extern __shared__ float lds[];                    // [2][C]: scale, shift
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.blk_start[i + 1]) ++i;
+  const ph_bn_item& t = g.it[i];
+  const int lb = (int)blockIdx.x - g.blk_start[i], nb = g.blk_start[i + 1] - g.blk_start[i];
+  const int C = t.C;
+  const double* sums = (const double*)t.sums;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float mu, var;
+    if (training) {
+      const double m1 = sums[c] / (double)t.M, m2 = sums[C + c] / (double)t.M;
+      mu = (float)m1;
+      var = (float)fmax(m2 - m1 * m1, 0.0);
+    } else {
+      mu = t.running_mean[c]; var = t.running_var[c];
+    }
+    const float r = rsqrtf(var + eps), sc = t.gamma[c] * r;
+    lds[c] = sc; lds[C + c] = t.beta[c] - mu * sc;
+    if (lb == 0) {
+      t.stats[c] = mu; t.stats[C + c] = r; t.stats[2 * C + c] = sc; t.stats[3 * C + c] = t.beta[c] - mu * sc;
+      if (training) {
+        const float unb = t.M > 1 ? var * (float)t.M / (float)(t.M - 1) : var;
+        t.running_mean[c] = (1.f - momentum) * t.running_mean[c] + momentum * mu;
+        t.running_var[c] = (1.f - momentum) * t.running_var[c] + momentum * unb;
+      }
+    }
+  }
+  __syncthreads();
+  const int cpr = C / 8;
+  const int64_t total = t.M * cpr;
+  const bf16* y = (const bf16*)t.y;
+  bf16* a = (bf16*)t.a;
+  for (int64_t id = (int64_t)lb * 256 + threadIdx.x; id < total; id += (int64_t)nb * 256) {
+    const int c = (int)(id % cpr) * 8;
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(y + id * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(fmaxf(bf2f(v[e]) * lds[c + e] + lds[C + c + e], 0.f));
+    *reinterpret_cast<bf16x8*>(a + id * 8) = o;
+  }
+}
+
+// backward, pass 1 (grouped bn_reduce<1>): sums[c] += g, sums[C+c] += g*xhat with g = da * [a > 0]
+__global__ __launch_bounds__(256) void bn_bwd_reduce_grouped_kernel(BnGroup g) {
+  extern __shared__ float red[];                    // [2][C]
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.blk_start[i + 1]) ++i;
+  const ph_bn_item& t = g.it[i];
+  const int lb = (int)blockIdx.x - g.blk_start[i], nb = g.blk_start[i + 1] - g.blk_start[i];
+  const int C = t.C, tpr = C / 8, rpp = 256 / tpr;
+  for (int k = threadIdx.x; k < 2 * C; k += 256) red[k] = 0.f;
+  __syncthreads();
+  const int r_in = threadIdx.x / tpr, cc = threadIdx.x % tpr;
+  if (r_in < rpp) {
+    float a0[8], a1[8], mu[8], rs[8], sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      a0[e] = 0.f; a1[e] = 0.f;
+      mu[e] = t.stats[cc * 8 + e]; rs[e] = t.stats[C + cc * 8 + e]; sc[e] = t.stats[2 * C + cc * 8 + e]; sh[e] = t.stats[3 * C + cc * 8 + e];
+    }
+    const bf16* y = (const bf16*)t.y;
+    const bf16* da = (const bf16*)t.a;              // (the `a` slot of the item carries dA in the backward)
+#pragma unroll 4
+    for (int64_t r = (int64_t)lb * rpp + r_in; r < t.M; r += (int64_t)nb * rpp) {
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(y + r * C + cc * 8);
+      bf16x8 d = *reinterpret_cast<const bf16x8*>(da + r * C + cc * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float yv = bf2f(v[e]);
+        const float gg = (yv * sc[e] + sh[e] > 0.f) ? bf2f(d[e]) : 0.f;
+        a0[e] += gg; a1[e] += gg * (yv - mu[e]) * rs[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { atomicAdd(&red[cc * 8 + e], a0[e]); atomicAdd(&red[C + cc * 8 + e], a1[e]); }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 2 * C; k += 256) atomicAdd((float*)t.sums + k, red[k]);
+}
+// backward, pass 2: dy = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M); block 0 of an item adds dgamma / dbeta
+__global__ __launch_bounds__(256) void bn_bwd_apply_grouped_kernel(BnGroup g) {
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.blk_start[i + 1]) ++i;
+  const ph_bn_item& t = g.it[i];
+  const int lb = (int)blockIdx.x - g.blk_start[i], nb = g.blk_start[i + 1] - g.blk_start[i];
+  const int C = t.C, cpr = C / 8;
+  const int64_t total = t.M * cpr;
+  const float invM = 1.f / (float)t.M;
+  const bf16* y = (const bf16*)t.y;
+  const bf16* da = (const bf16*)t.a;
+  bf16* dy = (bf16*)t.dy;
+  const float* bsums = (const float*)t.sums;
+  for (int64_t id = (int64_t)lb * 256 + threadIdx.x; id < total; id += (int64_t)nb * 256) {
+    const int c = (int)(id % cpr) * 8;
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(y + id * 8);
+    bf16x8 d = *reinterpret_cast<const bf16x8*>(da + id * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float yv = bf2f(v[e]);
+      const float xh = (yv - t.stats[c + e]) * t.stats[C + c + e];
+      const float gg = (yv * t.stats[2 * C + c + e] + t.stats[3 * C + c + e] > 0.f) ? bf2f(d[e]) : 0.f;
+      o[e] = f2bf(t.stats[2 * C + c + e] * (gg - bsums[c + e] * invM - xh * bsums[C + c + e] * invM));   // gamma*rstd = scale
+    }
+    *reinterpret_cast<bf16x8*>(dy + id * 8) = o;
+  }
+  if (lb == 0) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      if (t.dbeta) atomicAdd(t.dbeta + c, bsums[c]);
+      if (t.dgamma) atomicAdd(t.dgamma + c, bsums[C + c]);
+    }
+  }
+}
+
 // dy = gamma*rstd*(g - dbeta/M - xhat*dgamma/M); block 0 also accumulates dgamma/dbeta into the parameter grads.
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restrict__ da, const bf16* __restrict__ y, bf16* __restrict__ dy,
                                                            int64_t M, int C, const float* __restrict__ gamma,
@@ -566,6 +690,55 @@ extern "C" int ph_bn_relu_bwd(const void* da, const void* y, void* dy, int M, in
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((int64_t)M * (C / 8))), dim3(256), 0, stream, (const bf16*)da, (const bf16*)y,
                      (bf16*)dy, (int64_t)M, C, gamma, beta, mean, rstd, sums, dgamma, dbeta);
   PH_LAUNCH_CHECK("bn_relu_bwd kernels");
+  return PH_OK;
+}
+
+static int bn_group_fill(const ph_bn_item* items, int n, BnGroup& g, int* max_c, const char* who, bool reduce_grid) {
+  PH_CHECK_ARG(items && n >= 1 && n <= PH_BN_GROUP_MAX, "%s: need 1..%d items, got %d", who, PH_BN_GROUP_MAX, n);
+  g.n = n;
+  int total = 0, mc = 0;
+  for (int i = 0; i < n; ++i) {
+    const ph_bn_item& t = items[i];
+    PH_CHECK_ARG(t.y && t.a && t.stats && t.sums && t.gamma && t.beta && t.M > 0 && t.C > 0 && t.C % 8 == 0 && t.C <= 2048, "%s: bad item %d", who, i);
+    g.it[i] = t;
+    g.blk_start[i] = total;
+    int blocks;
+    if (reduce_grid) {
+      const int rpp = 256 / (t.C / 8);
+      blocks = (int)std::min<int64_t>(ceil_div64(t.M, (int64_t)rpp * 8), bn_reduce_blocks(t.C));
+    } else {
+      blocks = (int)std::min<int64_t>(ceil_div64(t.M * (t.C / 8), 256 * 4), 2048);
+    }
+    total += std::max(blocks, 1);
+    mc = std::max(mc, t.C);
+  }
+  g.blk_start[n] = total;
+  *max_c = mc;
+  return PH_OK;
+}
+
+extern "C" int ph_bn_apply_relu_grouped(const ph_bn_item* items, int n, float momentum, float eps, int training, hipStream_t stream) {
+  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream, "ph_bn_apply_relu_grouped");
+  BnGroup g; int mc;
+  int rc = bn_group_fill(items, n, g, &mc, "ph_bn_apply_relu_grouped", false);
+  if (rc) return rc;
+  for (int i = 0; i < n; ++i) PH_CHECK_ARG(items[i].running_mean && items[i].running_var, "ph_bn_apply_relu_grouped: running stats missing");
+  hipLaunchKernelGGL(bn_apply_grouped_kernel, dim3(g.blk_start[n]), dim3(256), sizeof(float) * 2 * mc, stream, g, momentum, eps, training);
+  PH_LAUNCH_CHECK("bn_apply_grouped_kernel");
+  return PH_OK;
+}
+
+extern "C" int ph_bn_relu_bwd_grouped(const ph_bn_item* items, int n, hipStream_t stream) {
+  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream, "ph_bn_relu_bwd_grouped");
+  BnGroup g; int mc;
+  int rc = bn_group_fill(items, n, g, &mc, "ph_bn_relu_bwd_grouped", true);
+  if (rc) return rc;
+  for (int i = 0; i < n; ++i) PH_CHECK_ARG(items[i].dy, "ph_bn_relu_bwd_grouped: dy missing");
+  hipLaunchKernelGGL(bn_bwd_reduce_grouped_kernel, dim3(g.blk_start[n]), dim3(256), sizeof(float) * 2 * mc, stream, g);
+  rc = bn_group_fill(items, n, g, &mc, "ph_bn_relu_bwd_grouped", false);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_bwd_apply_grouped_kernel, dim3(g.blk_start[n]), dim3(256), 0, stream, g);
+  PH_LAUNCH_CHECK("bn_relu_bwd_grouped kernels");
   return PH_OK;
 }
 

@@ -47,6 +47,19 @@ struct TileBytes {
   static constexpr int max = ks > kc ? ks : kc;
 };
 
+// Implicit-GEMM convolution: one operand is the im2col VIEW of an NHWC activation x[B][H][W][C] (C % 8 == 0), never materialised.
+// Logical matrix col[m][k], m = (b, oy, ox), k = (ky*ks + kx)*C + c (zero for out-of-image taps and for k >= ks*ks*C).
+struct ConvGather {
+  int H, W, C, ks, stride, Ho, Wo, Kreal;
+  float inv_howo, inv_wo, inv_c;      // reciprocals for the index decompositions (operands < 2^24: one float multiply + fix-up)
+};
+__device__ __forceinline__ int fdiv(int a, int d, float inv) {          // a / d for 0 <= a < 2^24, d > 0
+  int q = (int)((float)a * inv);
+  q += ((q + 1) * d <= a) ? 1 : 0;
+  q -= (q * d > a) ? 1 : 0;
+  return q;
+}
+
 struct GemmParams {
   const bf16* A; const bf16* B; void* C;
   int M, N, K, lda, ldb, ldc;
@@ -60,6 +73,8 @@ struct GemmParams {
   int k_tiles_per_split;   // in units of BK
   int tiles_m, tiles_n;
   float* ws; int ldws;     // split-K partial tiles: ws[split][M][ldws] fp32 (plain stores), folded by splitk_reduce_kernel
+  double* col_stats;       // optional fp64 [2][N]: += column sums / sums of squares of the (bf16-rounded) outputs (BatchNorm statistics)
+  ConvGather cv;           // CONV kernels only: geometry of the gathered operand (A for CONV=1, B for CONV=2)
 };
 
 // ---- global -> register staging ------------------------------------------------------------------------
@@ -124,6 +139,59 @@ __device__ __forceinline__ void store_ks(char* lds, const u32x4 (&regs)[R * 8 / 
     int id = threadIdx.x + 256 * i;
     int kr = id / CPR, c = id % CPR;
     *reinterpret_cast<u32x4*>(lds + kr * TileBytes<R>::ks_stride + c * 16) = regs[i];
+  }
+}
+
+// CONV = 1: K-contiguous A operand gathered from the activation.  Per thread the tile rows are fixed over the k loop, so the
+// pixel decomposition (PixRow) is done once; per k-tile one (tap, channel) decomposition of this thread's 8-wide k chunk.
+struct PixRow { int base, iy0, ix0; };     // base = b*H*W (pixels), (iy0, ix0) = input coordinates of tap (0,0)
+__device__ __forceinline__ PixRow pix_of(const ConvGather& cv, int m) {
+  int b = fdiv(m, cv.Ho * cv.Wo, cv.inv_howo);
+  int rem = m - b * cv.Ho * cv.Wo;
+  int oy = fdiv(rem, cv.Wo, cv.inv_wo), ox = rem - oy * cv.Wo;
+  const int pad = cv.ks >> 1;
+  return PixRow{b * cv.H * cv.W, oy * cv.stride - pad, ox * cv.stride - pad};
+}
+template <int R>
+__device__ __forceinline__ void load_kc_conv(const ConvGather& cv, const bf16* __restrict__ x, const PixRow (&px)[R * 8 / 256], int k0,
+                                             u32x4 (&regs)[R * 8 / 256]) {
+  const int k = k0 + (threadIdx.x & 7) * 8;
+  const bool kin = k < cv.Kreal;
+  const int kk = kin ? k : 0;
+  const int tap = fdiv(kk, cv.C, cv.inv_c), c0 = kk - tap * cv.C;
+  const int ky = cv.ks == 3 ? (tap >= 6 ? 2 : (tap >= 3 ? 1 : 0)) : 0, kx = tap - ky * cv.ks;
+#pragma unroll
+  for (int i = 0; i < R * 8 / 256; ++i) {
+    const int iy = px[i].iy0 + ky, ix = px[i].ix0 + kx;
+    const bool ok = kin && (unsigned)iy < (unsigned)cv.H && (unsigned)ix < (unsigned)cv.W;
+    const int iyc = min(max(iy, 0), cv.H - 1), ixc = min(max(ix, 0), cv.W - 1);          // always a valid address: the load is unconditional
+    u32x4 v = *reinterpret_cast<const u32x4*>(x + ((size_t)(px[i].base + iyc * cv.W + ixc)) * cv.C + c0);
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    regs[i] = ok ? v : z;
+  }
+}
+// CONV = 2: K-strided B operand (wgrad: reduction index = output pixel m, column = (tap, channel)): the column decomposition is
+// fixed per thread, the pixel of each of its k rows is decomposed per k-tile.
+template <int R>
+__device__ __forceinline__ void load_ks_conv(const ConvGather& cv, const bf16* __restrict__ x, int col0, int ncols, int k0, int K,
+                                             u32x4 (&regs)[R * 8 / 256]) {
+  constexpr int CPR = R / 8;
+  const int col = col0 + (threadIdx.x % CPR) * 8;                   // 256 % CPR == 0: the same column chunk for every i
+  const bool cin = col < cv.Kreal && col < ncols;
+  const int cc = cin ? col : 0;
+  const int tap = fdiv(cc, cv.C, cv.inv_c), c0 = cc - tap * cv.C;
+  const int ky = cv.ks == 3 ? (tap >= 6 ? 2 : (tap >= 3 ? 1 : 0)) : 0, kx = tap - ky * cv.ks;
+#pragma unroll
+  for (int i = 0; i < R * 8 / 256; ++i) {
+    const int m = k0 + (threadIdx.x + 256 * i) / CPR;
+    const bool min_ = m < K;
+    PixRow p = pix_of(cv, min_ ? m : 0);
+    const int iy = p.iy0 + ky, ix = p.ix0 + kx;
+    const bool ok = cin && min_ && (unsigned)iy < (unsigned)cv.H && (unsigned)ix < (unsigned)cv.W;
+    const int iyc = min(max(iy, 0), cv.H - 1), ixc = min(max(ix, 0), cv.W - 1);
+    u32x4 v = *reinterpret_cast<const u32x4*>(x + ((size_t)(p.base + iyc * cv.W + ixc)) * cv.C + c0);
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    regs[i] = ok ? v : z;
   }
 }
 
@@ -345,8 +413,31 @@ __device__ __forceinline__ void tile_writeout(const GemmParams& p, const float* 
   }
 }
 
-template <int BM, int BN, bool TA, bool TB, int PF>
+// BatchNorm statistics of a conv-as-GEMM output, taken from the tile while it is parked in LDS: per column the sum and the sum of
+// squares of the bf16-ROUNDED values (what the next layer reads) over the tile's valid rows, added to col_stats[2][N] with one
+// atomic pair per column and row half.  Plain epilogues only (the parked tile is alpha * acc: no bias / activation in a conv).
+// The global accumulators are fp64: the variance is later formed as E[x^2] - E[x]^2, and in fp32 that difference (and the order
+// of the atomics) is worth 1e-7 * x^2 -- visible against BatchNorm's eps = 1e-5 in channels that are constant over the batch
+// (piecewise-constant label maps), where it made the step's loss wander by 2e-4 from run to run.
+template <int BM, int BN, int NTHR>
+__device__ __forceinline__ void tile_colstats(const GemmParams& p, const float* cl, int m0, int n0) {
+  constexpr int CH = BN / 4, PARTS = NTHR / BN, RP = BM / PARTS;
+  const int col = threadIdx.x % BN, part = threadIdx.x / BN;
+  if (part >= PARTS || n0 + col >= p.N) return;
+  const int rows = min(BM, p.M - m0);
+  float s = 0.f, ss = 0.f;
+  const int c4 = col >> 2, e = col & 3;
+  for (int r = part * RP; r < min((part + 1) * RP, rows); ++r) {
+    float v = bf2f(f2bf(cl[r * BN + ((c4 ^ (r & (CH - 1))) << 2) + e]));
+    s += v; ss += v * v;
+  }
+  atomicAdd(p.col_stats + n0 + col, (double)s);
+  atomicAdd(p.col_stats + p.N + n0 + col, (double)ss);
+}
+
+template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, const int block_id, const int split_id, const int nsplits) {
+  static_assert(CONV == 0 || (CONV == 1 && !TA && !TB) || (CONV == 2 && TA && TB), "conv gather: A of an NN problem or B of a TT problem");
   constexpr int WM = BM / 2, WN = BN / 2;   // wave tile
   constexpr int TM = WM / 32, TN = WN / 32; // 32x32 MFMA tiles per wave
   constexpr int A_BYTES = TA ? TileBytes<BM>::ks : TileBytes<BM>::kc;
@@ -391,11 +482,18 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int block_i
   // in VGPRs.  LDS stays double-buffered: one barrier per k-tile.
   constexpr int D = PF;
   u32x4 ra[D][BM * 8 / 256], rb[D][BN * 8 / 256];
+  PixRow px[BM * 8 / 256];
+  if constexpr (CONV == 1) {
+#pragma unroll
+    for (int i = 0; i < BM * 8 / 256; ++i) px[i] = pix_of(p.cv, min(m0 + ((int)(threadIdx.x + 256 * i) >> 3), p.M - 1));
+  }
   auto gload = [&](int kt, u32x4 (&xa)[BM * 8 / 256], u32x4 (&xb)[BN * 8 / 256]) {
     int k0 = kt * BK;
     constexpr bool KF = PF > 1;                 // ring kernels are only launched when K % BK == 0
-    if (TA) load_ks<BM, KF>(p.A, p.lda, m0, p.M, k0, p.K, xa); else load_kc<BM, KF>(p.A, p.lda, m0, p.M, k0, p.K, xa);
-    if (TB) load_ks<BN, KF>(p.B, p.ldb, n0, p.N, k0, p.K, xb); else load_kc<BN, KF>(p.B, p.ldb, n0, p.N, k0, p.K, xb);
+    if constexpr (CONV == 1) load_kc_conv<BM>(p.cv, p.A, px, k0, xa);
+    else if (TA) load_ks<BM, KF>(p.A, p.lda, m0, p.M, k0, p.K, xa); else load_kc<BM, KF>(p.A, p.lda, m0, p.M, k0, p.K, xa);
+    if constexpr (CONV == 2) load_ks_conv<BN>(p.cv, p.B, n0, p.N, k0, p.K, xb);
+    else if (TB) load_ks<BN, KF>(p.B, p.ldb, n0, p.N, k0, p.K, xb); else load_kc<BN, KF>(p.B, p.ldb, n0, p.N, k0, p.K, xb);
   };
   auto lstore = [&](int buf, const u32x4 (&xa)[BM * 8 / 256], const u32x4 (&xb)[BN * 8 / 256]) {
     char* sa = smem + buf * STAGE;
@@ -512,11 +610,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int block_i
   });
   __syncthreads();
   tile_writeout<BM, BN, 256>(p, cl, m0, n0, splitk, drop, dc);
+  if (p.col_stats) tile_colstats<BM, BN, 256>(p, cl, m0, n0);
 }
 
-template <int BM, int BN, bool TA, bool TB, int PF>
+template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
-  gemm_body<BM, BN, TA, TB, PF>(p, blockIdx.x, blockIdx.z, gridDim.z);
+  gemm_body<BM, BN, TA, TB, PF, CONV>(p, blockIdx.x, blockIdx.z, gridDim.z);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -694,13 +793,13 @@ struct GroupParams {
 // The grid may be SMALLER than the number of tiles (ph_gemm_grouped_bf16's max_blocks): each block then walks tiles
 // blockIdx.x, blockIdx.x + gridDim.x, ... -- a background launch that occupies at most max_blocks block slots and leaves the rest
 // of the chip to the latency-bound chain on the main stream (deferred weight gradients beside the decoder's backward).
-template <int BM, int BN, bool TA, bool TB, int PF>
+template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0>
 __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupParams g) {
   const int total = g.tile_start[g.n];
   int i = 0;
   for (int t = blockIdx.x; t < total; t += gridDim.x) {
     while (i + 1 < g.n && t >= g.tile_start[i + 1]) ++i;
-    gemm_body<BM, BN, TA, TB, PF>(g.p[i], t - g.tile_start[i], 0, 1);
+    gemm_body<BM, BN, TA, TB, PF, CONV>(g.p[i], t - g.tile_start[i], 0, 1);
     __syncthreads();                     // the epilogue's LDS staging area is the next tile's stage buffer
   }
 }
@@ -732,7 +831,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
 #endif
 #define PF_DEPTH(bm) ((bm) == 128 ? PH_RING128 : PH_RING64)
 
-template <int BM, int BN, bool TA, bool TB, int PF>
+template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0>
 int launch_pf(const GemmParams& p, int splits, hipStream_t s) {
   constexpr int smem_min = 2 * ((TA ? TileBytes<BM>::ks : TileBytes<BM>::kc) + (TB ? TileBytes<BN>::ks : TileBytes<BN>::kc));
   static int extra = -1;            // PH_GEMM_EXTRA_LDS=<bytes>: occupancy experiments only (pads the dynamic LDS request)
@@ -740,12 +839,12 @@ int launch_pf(const GemmParams& p, int splits, hipStream_t s) {
   const int smem = smem_min + extra;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, TA, TB, PF>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, TA, TB, PF, CONV>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, TA, TB, PF>), grid, dim3(256), smem, s, p);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, TA, TB, PF, CONV>), grid, dim3(256), smem, s, p);
   PH_LAUNCH_CHECK("gemm_kernel");
   return PH_OK;
 }
@@ -760,6 +859,10 @@ int launch(const GemmParams& p, int splits, hipStream_t s) {
 
 template <int BM, int BN>
 int dispatch_layout(const GemmParams& p, int ta, int tb, int splits, hipStream_t s) {
+  if (p.cv.C > 0) {       // implicit-GEMM weight gradient: B = im2col view (K-strided gather); square tiles only, no prefetch ring
+    if constexpr (BM == BN) return launch_pf<BM, BN, true, true, 1, 2>(p, splits, s);
+    else return ph_fail(PH_ERR_UNSUPPORTED, "ph_gemm_bf16: conv gather needs square tiles");
+  }
   if (!ta && !tb) return launch<BM, BN, false, false>(p, splits, s);
   if (!ta && tb) return launch<BM, BN, false, true>(p, splits, s);
   if (ta && tb) return launch<BM, BN, true, true>(p, splits, s);
@@ -780,11 +883,12 @@ extern "C" int ph_gemm_tuning(int big_mode, int big_min_tiles) {
 static int fill_params(const ph_gemm_args* a, GemmParams& p) {
   PH_CHECK_ARG(a && a->A && a->B && a->C, "ph_gemm_bf16: null pointer");
   PH_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "ph_gemm_bf16: bad dims M=%d N=%d K=%d", a->M, a->N, a->K);
-  PH_CHECK_ARG((a->lda % 8) == 0 && (a->ldb % 8) == 0, "ph_gemm_bf16: lda/ldb must be multiples of 8 (16-B rows)");
+  PH_CHECK_ARG(((a->lda % 8) == 0 || (a->conv && !a->trans_a)) && ((a->ldb % 8) == 0 || (a->conv && a->trans_b)),
+               "ph_gemm_bf16: lda/ldb must be multiples of 8 (16-B rows)");
   PH_CHECK_ARG((((uintptr_t)a->A | (uintptr_t)a->B) & 15) == 0, "ph_gemm_bf16: A/B must be 16-B aligned");
   PH_CHECK_ARG(a->trans_a || a->trans_b || (a->K % 8) == 0, "ph_gemm_bf16: K %% 8 != 0 needs a K-strided operand");
-  PH_CHECK_ARG(a->lda >= (a->trans_a ? a->M : a->K) && a->ldb >= (a->trans_b ? a->N : a->K) && a->ldc >= a->N,
-               "ph_gemm_bf16: leading dimension too small");
+  PH_CHECK_ARG((a->lda >= (a->trans_a ? a->M : a->K) || (a->conv && !a->trans_a)) && (a->ldb >= (a->trans_b ? a->N : a->K) || (a->conv && a->trans_b)) &&
+               a->ldc >= a->N, "ph_gemm_bf16: leading dimension too small");
   PH_CHECK_ARG(!(a->drop_p > 0.0f) || ((a->N % 4) == 0 && a->drop_seed), "ph_gemm_bf16: dropout needs N %% 4 == 0 and a seed");
   PH_CHECK_ARG(a->drop_p >= 0.0f && a->drop_p < 1.0f, "ph_gemm_bf16: bad dropout p");
   p.A = (const bf16*)a->A; p.B = (const bf16*)a->B; p.C = a->C;
@@ -794,19 +898,37 @@ static int fill_params(const ph_gemm_args* a, GemmParams& p) {
   p.drop_p = a->drop_p; p.drop_seed = a->drop_seed; p.drop_stream = a->drop_stream;
   p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.alpha = a->alpha; p.pre_grad = a->pre_grad;
   p.ws = nullptr; p.ldws = (a->N + 3) / 4 * 4;
+  p.col_stats = a->col_stats;
+  p.cv = ConvGather{};
+  if (a->conv) {
+    const ph_conv_gather& c = *a->conv;
+    PH_CHECK_ARG(c.B > 0 && c.H > 0 && c.W > 0 && c.C > 0 && (c.C % 8) == 0 && (c.ks == 1 || c.ks == 3) && c.stride >= 1,
+                 "ph_gemm_bf16: bad conv gather (C %% 8 == 0, ks 1 or 3)");
+    const int pad = c.ks / 2, Ho = (c.H + 2 * pad - c.ks) / c.stride + 1, Wo = (c.W + 2 * pad - c.ks) / c.stride + 1;
+    const int64_t rows = (int64_t)c.B * Ho * Wo;
+    PH_CHECK_ARG(rows < (1 << 24) && (int64_t)c.B * c.H * c.W < (1ll << 31) / 1, "ph_gemm_bf16: conv gather index space too large");
+    const int Kreal = c.ks * c.ks * c.C;
+    if (!a->trans_a && !a->trans_b) PH_CHECK_ARG(a->M == rows && a->K >= Kreal && (a->K % 8) == 0, "ph_gemm_bf16: conv A: M must be B*Ho*Wo (%lld), K >= ks*ks*C", (long long)rows);
+    else if (a->trans_a && a->trans_b) PH_CHECK_ARG(a->K == rows && a->N >= Kreal, "ph_gemm_bf16: conv B: K must be B*Ho*Wo (%lld), N >= ks*ks*C", (long long)rows);
+    else return ph_fail(PH_ERR_UNSUPPORTED, "ph_gemm_bf16: conv gather is defined for the NN (forward) and TT (weight gradient) layouts");
+    p.cv.H = c.H; p.cv.W = c.W; p.cv.C = c.C; p.cv.ks = c.ks; p.cv.stride = c.stride; p.cv.Ho = Ho; p.cv.Wo = Wo; p.cv.Kreal = Kreal;
+    p.cv.inv_howo = 1.0f / (float)(Ho * Wo); p.cv.inv_wo = 1.0f / (float)Wo; p.cv.inv_c = 1.0f / (float)c.C;
+  }
+  PH_CHECK_ARG(!a->col_stats || (!a->bias && a->act == PH_ACT_NONE && !a->act_in && !a->residual && !(a->drop_p > 0.f) && !a->accumulate),
+               "ph_gemm_bf16: col_stats needs a plain epilogue");
   return PH_OK;
 }
 
-template <int BM, bool TA, bool TB, int PF>
+template <int BM, bool TA, bool TB, int PF, int CONV = 0>
 static int launch_grouped(const GroupParams& g, int total, int max_blocks, hipStream_t s) {
   constexpr int smem = 2 * ((TA ? TileBytes<BM>::ks : TileBytes<BM>::kc) + (TB ? TileBytes<BM>::ks : TileBytes<BM>::kc));
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<BM, BM, TA, TB, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<BM, BM, TA, TB, PF, CONV>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   const int grid = (max_blocks > 0 && max_blocks < total) ? max_blocks : total;
-  hipLaunchKernelGGL((gemm_grouped_kernel<BM, BM, TA, TB, PF>), dim3(grid), dim3(256), smem, s, g);
+  hipLaunchKernelGGL((gemm_grouped_kernel<BM, BM, TA, TB, PF, CONV>), dim3(grid), dim3(256), smem, s, g);
   PH_LAUNCH_CHECK("gemm_grouped_kernel");
   return PH_OK;
 }
@@ -827,8 +949,10 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
   double flops = 0.0, bytes = 0.0;
   double w128 = 0.0, w64 = 0.0, kt_max = 0.0;      // tile-iterations of work per tile shape
   bool kfull = true, thin = false;
+  const bool conv = args[0].conv != nullptr;
   for (int i = 0; i < n; ++i) {
     PH_CHECK_ARG(args[i].trans_a == args[0].trans_a && args[i].trans_b == args[0].trans_b, "ph_gemm_grouped_bf16: mixed layouts in one group");
+    PH_CHECK_ARG((args[i].conv != nullptr) == conv, "ph_gemm_grouped_bf16: implicit-GEMM conv problems cannot share a group with plain ones");
     flops += 2.0 * args[i].M * (double)args[i].N * args[i].K;
     bytes += 2.0 * ((double)args[i].M * args[i].K + (double)args[i].N * args[i].K + (double)args[i].M * args[i].N);
     const double kt = ceil_div(args[i].K, BK);
@@ -860,6 +984,13 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
   }
   g.tile_start[n] = total;
   const int ta = args[0].trans_a, tb = args[0].trans_b;
+  if (conv) {               // gathered operand: forward (NN, A = im2col view) or weight gradient (TT, B = im2col view); no prefetch ring
+    PH_CHECK_ARG(ta == tb, "ph_gemm_grouped_bf16: conv gather needs the NN or the TT layout");
+    if (!ta) return BMsel == 128 ? launch_grouped<128, false, false, 1, 1>(g, total, max_blocks, stream)
+                                 : launch_grouped<64, false, false, 1, 1>(g, total, max_blocks, stream);
+    return BMsel == 128 ? launch_grouped<128, true, true, 1, 2>(g, total, max_blocks, stream)
+                        : launch_grouped<64, true, true, 1, 2>(g, total, max_blocks, stream);
+  }
   if (BMsel == 128) {
     if (kfull && PH_RING128 > 1 && !ta) return launch_grouped_layout<128, PH_RING128>(g, total, max_blocks, ta, tb, stream);
     return launch_grouped_layout<128, 1>(g, total, max_blocks, ta, tb, stream);
@@ -873,11 +1004,13 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
   char desc__[96];
   if (g_ph_prof_enabled) snprintf(desc__, sizeof(desc__), "gemm M=%d N=%d K=%d ta=%d tb=%d f32=%d acc=%d", a->M, a->N, a->K, a->trans_a, a->trans_b, a->out_f32, a->accumulate);
   ProfScope prof__(PH_FAM_GEMM, 2.0 * a->M * (double)a->N * a->K, 2.0 * ((double)a->M * a->K + (double)a->N * a->K + (double)a->M * a->N), stream, desc__);
+  if (a->conv && !a->trans_a && !a->trans_b) return ph_gemm_grouped_capped_bf16(a, 1, 0, stream);     // implicit-GEMM forward: grouped kernel
   GemmParams p;
   {
     int rc = fill_params(a, p);
     if (rc) return rc;
   }
+  PH_CHECK_ARG(!a->col_stats || a->split_k <= 1, "ph_gemm_bf16: col_stats cannot be combined with split-K");
 
   // ---- big-tile LDS-DMA kernel: forward-shaped (both operands K-contiguous) GEMMs with enough 256x128 tiles for the chip ----
   {
@@ -887,7 +1020,7 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
     if (g_big_min_tiles < 0) { const char* e = getenv("PH_GEMM_BIG_MIN_TILES"); g_big_min_tiles = e ? atoi(e) : 160; }
     const int big_mode = g_big_mode, big_min_tiles = g_big_min_tiles;
     const int64_t tb = (int64_t)ceil_div(a->M, big::BM) * ceil_div(a->N, big::BN);
-    if (big_mode > 0 && !a->trans_a && !a->trans_b && (a->K % BK) == 0 && a->K >= 2 * BK && a->split_k <= 0 && a->M >= big::BM &&
+    if (big_mode > 0 && !a->conv && !a->col_stats && !a->trans_a && !a->trans_b && (a->K % BK) == 0 && a->K >= 2 * BK && a->split_k <= 0 && a->M >= big::BM &&
         (a->N % 8) == 0 && tb >= big_min_tiles) {
       p.tiles_m = ceil_div(a->M, big::BM); p.tiles_n = ceil_div(a->N, big::BN);
       p.k_tiles_per_split = a->K / BK;

@@ -194,10 +194,17 @@ def load_encoder(name: str, experts: dict, image_resolution: int, checkpoint_pat
     if name not in _MODELS:
         raise RuntimeError(f'Model {name} not found')
     width, layers, heads, patch = _MODELS[name]
-    vit = VisionTransformer(input_resolution=image_resolution, patch_size=patch, width=width, layers=layers, heads=heads, experts=experts)
+    sd = None
     if checkpoint_path is not None:
-        sd = torch.load(checkpoint_path, map_location='cpu')
+        sd = torch.load(checkpoint_path, map_location='cpu', weights_only=False)
         sd = convert_clip_state_dict(sd.state_dict() if hasattr(sd, 'state_dict') else sd)
+        # geometry comes from the checkpoint like in the reference (vit.py:211-214): width / patch from conv1, depth from the
+        # number of attention blocks, heads = width // 64
+        width, patch = sd['conv1.rgb.weight'].shape[0], sd['conv1.rgb.weight'].shape[-1]
+        layers = len([k for k in sd if k.endswith('.attn.in_proj_weight')])
+        heads = width // 64
+    vit = VisionTransformer(input_resolution=image_resolution, patch_size=patch, width=width, layers=layers, heads=heads, experts=experts)
+    if sd is not None:
         sd['positional_embedding'] = interpolate_pos_embed(sd['positional_embedding'], len(vit.positional_embedding))
         vit.load_state_dict(sd, strict=False)
     return vit

@@ -264,7 +264,8 @@ def wait_side():
 
 
 def gemm(a, b, out=None, *, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, pre_out=None, act_in=None,
-         residual=None, drop=None, out_f32=False, accumulate=False, alpha=1.0, split_k=0, M=None, N=None, K=None, pre_grad=False):
+         residual=None, drop=None, out_f32=False, accumulate=False, alpha=1.0, split_k=0, M=None, N=None, K=None, pre_grad=False,
+         conv=None, col_stats=None):
     """out[M,N] = epi(alpha * opA . opB^T).  a: [M,K] (or [K,M] if trans_a), b: [N,K] (or [K,N] if trans_b)."""
     if M is None:
         M = a.shape[1] if trans_a else a.shape[0]
@@ -279,6 +280,15 @@ def gemm(a, b, out=None, *, trans_a=False, trans_b=False, bias=None, act=ACT_NON
     g.M, g.N, g.K = M, N, K
     g.lda, g.ldb, g.ldc = a.stride(0), b.stride(0), out.stride(0)
     g.trans_a, g.trans_b = int(trans_a), int(trans_b)
+    cg = None
+    if conv is not None:                              # (B, H, W, C, ks, stride): the A (forward) / B (wgrad) operand is an im2col view
+        cg = _lib.ConvGather(*conv)
+        g.conv = C.pointer(cg)
+        if trans_a:
+            g.ldb = N
+        else:
+            g.lda = K
+    g.col_stats = ptr(col_stats)
     g.bias = ptr(bias)
     g.act = act
     g.pre_out = ptr(pre_out)
@@ -424,6 +434,36 @@ def inpaint_resize(label_map, table, Hout, Wout):
     return y
 
 
+def conv_gemm_args(x, geo, w_shadow, y, col_stats=None):
+    """GemmArgs of one implicit-GEMM forward convolution: y[B*Ho*Wo, Cout] = im2col(x) . w_shadow[Cout, Kp]^T.
+    x: NHWC bf16 activation, geo = (B, H, W, C, ks, stride).  Returns (args, keep-alive tuple)."""
+    B, H, W, Cc, ks, stride = geo
+    Ho, Wo = conv_out_size(H, ks, stride), conv_out_size(W, ks, stride)
+    g = _lib.GemmArgs()
+    cg = _lib.ConvGather(B, H, W, Cc, ks, stride)
+    g.A, g.B, g.C = x.data_ptr(), w_shadow.data_ptr(), y.data_ptr()
+    g.M, g.N, g.K = B * Ho * Wo, w_shadow.shape[0], w_shadow.shape[1]
+    g.lda, g.ldb, g.ldc = w_shadow.shape[1], w_shadow.stride(0), y.stride(0)
+    g.alpha = 1.0
+    g.conv = C.pointer(cg)
+    g.col_stats = ptr(col_stats)
+    return g, (cg, x, w_shadow, y, col_stats)
+
+
+def conv_fwd_grouped(items):
+    """items: [(x, geo, w_shadow, y, col_stats)] -- the same-layer convolutions of several expert stems in ONE launch per
+    PH_GEMM_GROUP_MAX problems (vit.py:88-120: the stems are independent until their tokens are concatenated)."""
+    for i0 in range(0, len(items), _lib.GEMM_GROUP_MAX):
+        part = items[i0:i0 + _lib.GEMM_GROUP_MAX]
+        arr = (_lib.GemmArgs * len(part))()
+        keep = []
+        for i, it in enumerate(part):
+            g, k = conv_gemm_args(*it)
+            arr[i] = g
+            keep.append(k)
+        check(lib.ph_gemm_grouped_bf16(arr, len(part), _stream()), 'ph_gemm_grouped_bf16 (conv)')
+
+
 def conv_out_size(H, ks, stride):
     pad = ks // 2
     return (H + 2 * pad - ks) // stride + 1
@@ -464,6 +504,48 @@ def bn_relu_bwd(da, y, gamma, beta, stats, dgamma, dbeta, sums=None):
     check(lib.ph_bn_relu_bwd(da.data_ptr(), y.data_ptr(), dy.data_ptr(), M, Cc, gamma.data_ptr(), beta.data_ptr(), stats[0].data_ptr(),
                              stats[1].data_ptr(), ptr(dgamma), ptr(dbeta), sums.data_ptr(), int(pre), _stream()), 'ph_bn_relu_bwd')
     return dy
+
+
+def _bn_items(items):
+    out = []
+    for i0 in range(0, len(items), _lib.BN_GROUP_MAX):
+        part = items[i0:i0 + _lib.BN_GROUP_MAX]
+        arr = (_lib.BnItem * len(part))()
+        for it, d in zip(arr, part):
+            it.y, it.a, it.dy = d['y'].data_ptr(), d['a'].data_ptr(), ptr(d.get('dy'))
+            it.M, it.C = d['y'].shape[0], d['y'].shape[1]
+            it.gamma, it.beta = d['gamma'].data_ptr(), d['beta'].data_ptr()
+            it.running_mean, it.running_var = ptr(d.get('running_mean')), ptr(d.get('running_var'))
+            it.stats, it.sums = d['stats'].data_ptr(), d['sums'].data_ptr()
+            it.dgamma, it.dbeta = ptr(d.get('dgamma')), ptr(d.get('dbeta'))
+        out.append((arr, len(part)))
+    return out
+
+
+def bn_apply_relu_grouped(items, training, momentum=0.1, eps=1e-5):
+    """items: dicts y [M,C] bf16 (conv output), a [M,C] bf16 (out: relu(bn(y))), gamma, beta, running_mean, running_var,
+    stats [4,C] fp32 (out), sums [2,C] fp32 (column sums from the conv GEMM epilogue; unused in eval mode)"""
+    for arr, n in _bn_items(items):
+        check(lib.ph_bn_apply_relu_grouped(arr, n, momentum, eps, int(training), _stream()), 'ph_bn_apply_relu_grouped')
+
+
+def bn_relu_bwd_grouped(items):
+    """items: dicts y, a (= dA, gradient w.r.t. relu(bn(y))), dy (out), gamma, beta, stats [4,C], sums [2,C] ZEROED, dgamma, dbeta"""
+    for arr, n in _bn_items(items):
+        check(lib.ph_bn_relu_bwd_grouped(arr, n, _stream()), 'ph_bn_relu_bwd_grouped')
+
+
+def gemm_grouped(problems, trans_a=False, trans_b=False):
+    """problems: [(a, b, out, M, N, K)] plain bf16 GEMMs of one layout in grouped launches (out bf16, no epilogue)"""
+    for i0 in range(0, len(problems), _lib.GEMM_GROUP_MAX):
+        part = problems[i0:i0 + _lib.GEMM_GROUP_MAX]
+        arr = (_lib.GemmArgs * len(part))()
+        for g, (a, b, out, M, N, K) in zip(arr, part):
+            g.A, g.B, g.C = a.data_ptr(), b.data_ptr(), out.data_ptr()
+            g.M, g.N, g.K = M, N, K
+            g.lda, g.ldb, g.ldc = a.stride(0), b.stride(0), out.stride(0)
+            g.trans_a, g.trans_b, g.alpha = int(trans_a), int(trans_b), 1.0
+        check(lib.ph_gemm_grouped_bf16(arr, len(part), _stream()), 'ph_gemm_grouped_bf16')
 
 
 def tokens_finalize(feat, pos, tokens, B, G, D, tok_per_batch, tok_off, inst=None, E=0, g=0, table=None, inst_emb=None):

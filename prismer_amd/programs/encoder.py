@@ -26,6 +26,9 @@ BF16, F32 = torch.bfloat16, torch.float32
 # backward GEMM multiplies by it -- nothing in the backward needs x itself, and its epilogue loses two transcendentals per
 # element (QuickGELU' / erf-GELU').  PRISMER_SAVE_ACT_GRAD=0: store x and recompute act' (round-1 behaviour, A/B switch).
 SAVE_ACT_GRAD = os.environ.get('PRISMER_SAVE_ACT_GRAD', '1') != '0'
+# expert stems: 'grouped' = layer-synchronous grouped launches with implicit-GEMM convolutions (default); 'explicit' = one chain
+# per stem over im2col matrices (round-1 form, kept as the A/B reference)
+GROUPED_STEMS = os.environ.get('PRISMER_STEMS', 'grouped') != 'explicit'
 
 
 def _bwd_act(act):
@@ -237,6 +240,136 @@ class EncoderProgram:
                 dcol = ops.gemm(dy, shadow, trans_b=True)
                 da = ops.col2im(dcol, B, H, H, C, 3, stride, Kp)
 
+    # ---------------------------------------------------------------------------------------- expert stems, grouped (round 2)
+    # The six stems are independent networks of the same depth (vit.py:88-120).  They are walked LAYER by layer, all experts of a
+    # layer in one grouped launch each:
+    #   conv3x3 as an IMPLICIT GEMM (the A operand is gathered from the NHWC activation inside the GEMM loader: no im2col matrix is
+    #   written, kept for the backward or re-read), BatchNorm statistics accumulated in the GEMM epilogue (col_stats), then one
+    #   grouped pass a = relu(bn(y)) that also derives scale / shift and updates the running statistics.
+    # Only the first layer of the dense stems (Cin = 1 or 3: K = 9 or 27) keeps an explicit (tiny) im2col matrix.
+    # Backward: grouped BN-ReLU backward; weight gradients as implicit GEMMs with the gather on the reduction side; data gradients
+    # as dcol = dY.W followed by the col2im gather (dcol is transient, never saved).
+    def stems_fwd(self, x, names, training, sv):
+        d = self.d
+        P = self.P
+        st = []                                                   # per expert running state
+        for name in names:
+            dom = 'seg' if 'seg' in name else name
+            val = x[name]
+            label = dom in LABEL_DOMAINS
+            Hs = int(d.expert_resolution * (4 if label else 16) / d.patch_size)
+            if isinstance(val, dict) and 'label_map' in val:
+                a = ops.inpaint_resize(val['label_map'], val['table'], Hs, Hs)
+            else:
+                inp = (val['label'] if name == 'obj_detection' else val).contiguous().float()
+                a = ops.resize_to_nhwc(inp, Hs, Hs)
+            st.append(dict(name=name, dom=dom, a=a, H=Hs, C=a.shape[3], B=a.shape[0], strides=(2, 2, 1, 1) if label else (2, 2, 2, 2),
+                           a_in=[], ys=[], stats=[], geo=[], col0=None))
+        n_ch = sum(d.width // k for k in (8, 4, 2, 1))
+        sums_arena = torch.zeros(len(st) * 2 * n_ch, dtype=torch.float64, device=st[0]['a'].device) if st else None     # fp64: see tile_colstats
+        stats_arena = torch.empty(len(st) * 4 * n_ch, dtype=F32, device=st[0]['a'].device) if st else None
+        so = to = 0
+        for i in range(4):
+            conv_items, bn_items = [], []
+            for e in st:
+                dom, B, H, C, s_ = e['dom'], e['B'], e['H'], e['C'], e['strides'][i]
+                wname = f'conv1.{dom}.{1 + 3 * i}.weight'
+                shadow, Kp = self.conv_shadow(wname, 3)
+                Co = shadow.shape[0]
+                Ho = ops.conv_out_size(H, 3, s_)
+                y = torch.empty(B * Ho * Ho, Co, dtype=BF16, device=e['a'].device)
+                sums = sums_arena[so:so + 2 * Co].view(2, Co); so += 2 * Co
+                stats = stats_arena[to:to + 4 * Co].view(4, Co); to += 4 * Co
+                if C % 8 == 0:
+                    conv_items.append((e['a'], (B, H, H, C, 3, s_), shadow, y, sums if training else None))
+                else:                                              # Cin = 1 / 3: explicit im2col (K = 16 / 32), statistics still fused
+                    col = ops.im2col(e['a'], B, H, H, C, 3, s_, Kp)
+                    ops.gemm(col, shadow, out=y, col_stats=sums if training else None)
+                    e['col0'] = col
+                bn = self.mod.conv1[dom][2 + 3 * i]
+                a_next = torch.empty_like(y)
+                bn_items.append(dict(y=y, a=a_next, gamma=P.f(f'conv1.{dom}.{2 + 3 * i}.weight'), beta=P.f(f'conv1.{dom}.{2 + 3 * i}.bias'),
+                                     running_mean=bn.running_mean, running_var=bn.running_var, stats=stats, sums=sums))
+                if training:
+                    self._bn_counters.append(bn.num_batches_tracked)
+                e['a_in'].append(e['a']); e['ys'].append(y); e['stats'].append(stats); e['geo'].append((H, C, s_, Kp))
+                e['a'], e['H'], e['C'] = a_next.view(B, Ho, Ho, Co), Ho, Co
+            if conv_items:
+                ops.conv_fwd_grouped(conv_items)
+            bn0 = self.mod.conv1[st[0]['dom']][2]
+            ops.bn_apply_relu_grouped(bn_items, training, bn0.momentum, bn0.eps)
+        feats, probs = [], []
+        for e in st:
+            shadow, Kp = self.conv_shadow(f'conv1.{e["dom"]}.13.weight', 1)
+            M = e['B'] * e['H'] * e['H']
+            a2 = e['a'].view(M, e['C'])
+            f = torch.empty(M, shadow.shape[0], dtype=BF16, device=a2.device)
+            probs.append((a2, shadow, f, M, shadow.shape[0], Kp))
+            feats.append(f)
+            if sv is not None:
+                sv[e['dom']] = dict(a_in=e['a_in'], ys=e['ys'], stats=e['stats'], geo=e['geo'], a_last=a2, col0=e['col0'], B=e['B'], Hlast=e['H'])
+        if probs:
+            ops.gemm_grouped(probs)
+        return feats
+
+    def stems_bwd(self, doms, dfeats, sv):
+        """doms: stem names in token order; dfeats: d(loss)/d(stem output) [B*G, W] per stem."""
+        P = self.P
+        dev = dfeats[0].device
+        S = [sv[dom] for dom in doms]
+        # 1x1 projection (slot 13): weight gradient deferred (plain TT GEMM), data gradient grouped
+        das, probs = [], []
+        for dom, s, df in zip(doms, S, dfeats):
+            w13 = f'conv1.{dom}.13.weight'
+            g = P.g(w13)
+            Co, Ci = P.shape[w13][0], P.shape[w13][1]
+            if g is not None:
+                ops.WQ.add_gemm(df, s['a_last'], g.view(Co, Ci), Co, Ci, df.shape[0])
+            shadow, _ = self.conv_shadow(w13, 1)
+            da = torch.empty(df.shape[0], Ci, dtype=BF16, device=dev)
+            probs.append((df, shadow, da, df.shape[0], Ci, Co))
+            das.append(da)
+        ops.gemm_grouped(probs, trans_b=True)
+        n_ch = sum(self.d.width // k for k in (8, 4, 2, 1))
+        sums_arena = torch.zeros(len(doms) * 2 * n_ch, dtype=F32, device=dev)
+        so = 0
+        for i in (3, 2, 1, 0):
+            bn_items, dys = [], []
+            for dom, s, da in zip(doms, S, das):
+                y = s['ys'][i]
+                Co = y.shape[1]
+                gname, bname = f'conv1.{dom}.{2 + 3 * i}.weight', f'conv1.{dom}.{2 + 3 * i}.bias'
+                dy = torch.empty_like(y)
+                bn_items.append(dict(y=y, a=da, dy=dy, gamma=P.f(gname), beta=P.f(bname), stats=s['stats'][i],
+                                     sums=sums_arena[so:so + 2 * Co], dgamma=P.g(gname), dbeta=P.g(bname)))
+                so += 2 * Co
+                dys.append(dy)
+            ops.bn_relu_bwd_grouped(bn_items)
+            dcol_probs, dcols = [], []
+            for dom, s, dy in zip(doms, S, dys):
+                H, C, stride, Kp = s['geo'][i]
+                wname = f'conv1.{dom}.{1 + 3 * i}.weight'
+                g = P.g(wname)
+                Co = P.shape[wname][0]
+                if g is not None:
+                    if C % 8 == 0:                                 # implicit-GEMM weight gradient: the im2col view sits on the reduction side
+                        ds = ops.gemm(dy, s['a_in'][i].view(-1, C), trans_a=True, trans_b=True, out_f32=True, M=Co, N=Kp, K=dy.shape[0],
+                                      conv=(s['B'], H, H, C, 3, stride))
+                    else:
+                        ds = ops.gemm(dy, s['col0'], trans_a=True, trans_b=True, out_f32=True, M=Co, N=Kp, K=dy.shape[0])
+                    ops.WQ.add_conv_fold(ds, g, Co, C, 3, Kp)
+                if i > 0:
+                    shadow, _ = self.conv_shadow(wname, 3)
+                    dcol = torch.empty(dy.shape[0], Kp, dtype=BF16, device=dev)
+                    dcol_probs.append((dy, shadow, dcol, dy.shape[0], Kp, Co))
+                    dcols.append(dcol)
+            if i > 0:
+                ops.gemm_grouped(dcol_probs, trans_b=True)
+                das = []
+                for s, dcol in zip(S, dcols):
+                    H, C, stride, Kp = s['geo'][i]
+                    das.append(ops.col2im(dcol, s['B'], H, H, C, 3, stride, Kp))
+
     # ---------------------------------------------------------------------------------------- resampler
     def resampler_fwd(self, xf, B, h, sv):
         """resampler.py:46-52; writes the 64 latents of every image into rows [b*S + N + l] of h."""
@@ -396,17 +529,23 @@ class EncoderProgram:
             xf = torch.empty(B * Mx, W, dtype=BF16, device=dev)
             pos_e = self.expert_pos()
             keep = []
-            self._bn_arena(len(names), 4)
             self._bn_counters = []
+            grouped = GROUPED_STEMS
+            feats = self.stems_fwd(x, names, training, sv) if grouped else None
+            if not grouped:
+                self._bn_arena(len(names), 4)
             for ei, name in enumerate(names):                  # the stems are independent: parallel graph branches
                 with ops.POOL.branch(ei):
                     dom = 'seg' if 'seg' in name else name
                     val = x[name]
-                    if isinstance(val, dict) and 'label_map' in val:   # {'label_map': uint8 [B,(1,)E,E], 'table': [256,64] | [B,256,64]}
-                        inp = val
+                    if grouped:
+                        f = feats[ei]
                     else:
-                        inp = (val['label'] if name == 'obj_detection' else val).contiguous().float()
-                    f = self.stem_fwd(dom, inp, training, sv)
+                        if isinstance(val, dict) and 'label_map' in val:   # {'label_map': uint8 [B,(1,)E,E], 'table': [256,64] | [B,256,64]}
+                            inp = val
+                        else:
+                            inp = (val['label'] if name == 'obj_detection' else val).contiguous().float()
+                        f = self.stem_fwd(dom, inp, training, sv)
                     if f.shape[0] != B * G:
                         raise RuntimeError(f'expert map {name}: stem produced {f.shape[0] // B} tokens per image, program expects {G} '
                                            f'(expert_resolution={d.expert_resolution})')
@@ -424,6 +563,7 @@ class EncoderProgram:
                 torch._foreach_add_(self._bn_counters, 1)
                 self._bn_counters = []
         if save:
+            sv['grouped'] = bool(names) and GROUPED_STEMS
             sv.update(B=B, names=names, rgb_col=col,
                       inst=(self._instance_ids(x['obj_detection']) if 'obj_detection' in x else None), inst_table=inst_table)
         return h, xf, sv
@@ -473,7 +613,9 @@ class EncoderProgram:
             same = d.expert_grid == d.rgb_grid
             dpos_e = gpos if same else torch.zeros(G, W, dtype=F32, device=dh.device)
             keep = []
-            self._bn_arena(len(names), 2)
+            grouped = sv.get('grouped', False)
+            if not grouped:
+                self._bn_arena(len(names), 2)
             for ei, name in enumerate(names):
                 dom = 'seg' if 'seg' in name else name
                 dfeat = torch.empty(B * G, W, dtype=BF16, device=dh.device)
@@ -484,8 +626,11 @@ class EncoderProgram:
                 else:
                     ops.tokens_finalize_bwd(dxf, dfeat, dpos_e, B, G, W, Mx, ei * G)
                 keep.append(dfeat)
-                with ops.POOL.branch(ei):                      # the six stem backward chains are independent
-                    self.stem_bwd(dom, dfeat, sv)
+                if not grouped:
+                    with ops.POOL.branch(ei):                  # the six stem backward chains are independent
+                        self.stem_bwd(dom, dfeat, sv)
+            if grouped:
+                self.stems_bwd(['seg' if 'seg' in n else n for n in names], keep, sv)
             ops.POOL.join()
             del keep
             self._arena = None

@@ -59,11 +59,13 @@ def test_inpaint_resize_kernel_matches_oracle(Hout):
     want = ops.resize_to_nhwc(dense.cuda(), Hout, Hout)      # the dense path the compact one replaces
     got = ops.inpaint_resize(lab.cuda(), tab.cuda(), Hout, Hout)
     assert got.shape == want.shape == (8, Hout, Hout, 64)
-    assert torch.equal(got, want)
+    # same taps, weights and expression as the dense path; the two kernels may contract a*b+c differently (1 bf16 ulp)
+    assert (got.float() - want.float()).abs().max() <= 2.0 ** -7 * want.float().abs().max()
+    assert (got != want).float().mean() < 1e-2
     ref = torch.nn.functional.interpolate(dense, size=(Hout, Hout), mode='bilinear', align_corners=True).permute(0, 2, 3, 1)
     assert (got.float().cpu() - ref).abs().max() <= 2.0 ** -8 * ref.abs().max() + 1e-6      # bf16 rounding of the fp32 interpolation
     shared = ops.inpaint_resize(lab[:2].cuda(), tab[0].cuda(), Hout, Hout)                  # one table for the whole batch (fixed vocabulary)
-    assert torch.equal(shared[0], got[0])
+    assert torch.equal(shared[0], got[0])                    # same kernel, shared vs per-image table
 
 
 @pytest.mark.gpu

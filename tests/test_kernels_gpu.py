@@ -399,6 +399,46 @@ def test_conv_as_gemm(ops, C, stride, ks):
     assert rel_fro(dw, ds[:, :K].reshape(Co, ks, ks, C).permute(0, 3, 1, 2)) < 1e-6
 
 
+@pytest.mark.parametrize('B,H,C,Cout,stride,ks', [(3, 28, 96, 192, 2, 3), (2, 14, 64, 96, 1, 3), (2, 15, 384, 200, 2, 3), (5, 7, 768, 768, 1, 1),
+                                                  (32, 56, 96, 192, 2, 3)])
+def test_implicit_gemm_conv_forward_stats_and_wgrad(ops, B, H, C, Cout, stride, ks):
+    """conv as implicit GEMM (no im2col matrix): forward y = conv(x, w) with BatchNorm statistics from the epilogue, and the weight
+    gradient dW = dY^T . im2col(x) with the gathered operand on the reduction side -- against F.conv2d / autograd in fp32."""
+    x = rnd(B, H, H, C, scale=0.7, seed=31)                                   # NHWC
+    w = (torch.randn(Cout, C, ks, ks, generator=torch.Generator().manual_seed(7)) * 0.05).cuda()
+    Kp = (ks * ks * C + 7) // 8 * 8
+    shadow = torch.zeros(Cout, Kp, dtype=BF, device='cuda')
+    ops.conv_weight_to_shadow(w, shadow, Cout, C, ks, Kp)
+    Ho = ops.conv_out_size(H, ks, stride)
+    M = B * Ho * Ho
+    geo = (B, H, H, C, ks, stride)
+    y = torch.empty(M, Cout, dtype=BF, device='cuda')
+    stats = torch.zeros(2, Cout, device='cuda', dtype=torch.float64)
+    ops.conv_fwd_grouped([(x, geo, shadow, y, stats)])
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(False)
+    wr = shadow[:, :ks * ks * C].float().view(Cout, ks, ks, C).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    ref = F.conv2d(xr, wr, stride=stride, padding=ks // 2)
+    ref2 = ref.permute(0, 2, 3, 1).reshape(M, Cout)
+    assert rel_fro(y, ref2) < 6e-3
+    yf = y.float()
+    assert rel_fro(stats[0], yf.double().sum(0)) < 1e-5 and rel_fro(stats[1], (yf.double() ** 2).sum(0)) < 1e-5      # statistics of the ROUNDED outputs
+    # same result through the single-problem entry (routes to the grouped kernel) and against the explicit im2col path
+    col = ops.im2col(x, B, H, H, C, ks, stride, Kp)
+    y2 = ops.gemm(col, shadow)
+    assert torch.equal(y, y2) or rel_fro(y, y2.float()) < 1e-3
+    y3 = ops.gemm(x.view(-1, C), shadow, M=M, N=Cout, K=Kp, conv=geo)
+    assert torch.equal(y3, y)
+    # weight gradient
+    dy = rnd(M, Cout, scale=0.3, seed=33)
+    ds = ops.gemm(dy, x.view(-1, C), trans_a=True, trans_b=True, out_f32=True, M=Cout, N=Kp, K=M, conv=geo)
+    ds_ref = ops.gemm(dy, col, trans_a=True, trans_b=True, out_f32=True, M=Cout, N=Kp, K=M)
+    assert rel_fro(ds, ds_ref) < 2e-4
+    ref.backward(dy.float().view(B, Ho, Ho, Cout).permute(0, 3, 1, 2))
+    dw_ref = wr.grad.permute(0, 2, 3, 1).reshape(Cout, ks * ks * C)
+    assert rel_fro(ds[:, :ks * ks * C], dw_ref) < 3e-4
+    assert float(ds[:, ks * ks * C:].abs().sum()) == 0.0
+
+
 @pytest.mark.parametrize('M,C', [(5000, 96), (777, 32), (3000, 768)])
 def test_batchnorm(ops, M, C):
     y = rnd(M, C, seed=50) * 2 + 0.5

@@ -502,8 +502,9 @@ def test_trainer_graph_equals_eager_first_step():
                         m=[t.clone() for t in tr.m], bufs=[b.clone().float() for b in enc.buffers()]))
     a, b = res
     assert a['it'] == b['it'] == 2 and a['seed'] == b['seed']
-    for la, lb in zip(a['losses'], b['losses']):
-        assert math_close(la, lb, 1e-4), (a['losses'], b['losses'])
+    assert math_close(a['losses'][0], b['losses'][0], 1e-5), (a['losses'], b['losses'])     # same state, same masks, same table
+    # step 2 sees parameters after one AdamW step: near-zero gradients (atomics-order noise) can take either sign of the +-lr move
+    assert math_close(a['losses'][1], b['losses'][1], 1e-3), (a['losses'], b['losses'])
     for ta, tb in zip(a['p'] + a['m'] + a['bufs'], b['p'] + b['m'] + b['bufs']):
         assert rel_fro(tb, ta) < 2e-3                           # same kernels; fp32 atomics order differs between runs
 
