@@ -128,13 +128,17 @@ def kernel_family_pass(tr, steps):
 
 
 def pmc_traffic():
-    """HBM bytes per GEMM launch from the committed PMC passes (profiles/r1_pmc_gemm.json: rocprofv3 --pmc FETCH_SIZE and
-    WRITE_SIZE in separate runs, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md); counters cannot be read from
-    inside the process, so this is null when the file is absent."""
-    p = os.path.join(ROOT, 'profiles', 'r1_pmc_gemm.json')
-    if not os.path.isfile(p):
-        return None
-    return round(json.load(open(p))['hbm_bytes_per_launch'])
+    """HBM bytes per GEMM launch from the committed PMC passes (profiles/r2_pmc_gemm.json: rocprofv3 --pmc FETCH_SIZE and
+    WRITE_SIZE in separate runs of this bench, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md; tools/run13.sh is the
+    recipe); counters cannot be read from inside the process, so this is (None, None) when the file is absent.  Returns the
+    per-launch bytes and the launch count the passes saw, so that a stale file shows next to the live launch count."""
+    for name in ('r2_pmc_gemm.json', 'r1_pmc_gemm.json'):
+        p = os.path.join(ROOT, 'profiles', name)
+        if os.path.isfile(p):
+            d = json.load(open(p))
+            return round(d['hbm_bytes_per_launch']), dict(file='profiles/' + name, launches_per_step=d['launches_per_step'],
+                                                          whole_step_hbm_gb=round(d['whole_step_hbm_gb'], 1))
+    return None, None
 
 
 def cpu_baseline(seconds_budget=20.0):
@@ -292,7 +296,7 @@ def main():
             ach = g['tflop_per_step'] / (g['ms_per_step'] / 1e3) if g['ms_per_step'] > 0 else 0.0
             out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_kernel<*> (all bf16 MFMA GEMM launches of one step)',
                                'achieved': round(ach, 1), 'peak': PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_TFLOPS, 4),
-                               'traffic': pmc_traffic(), 'algorithmic_bytes_per_launch': round(g['gbytes_per_step'] * 1e9 / max(g['launches_per_step'], 1)),
+                               'traffic': pmc_traffic()[0], 'traffic_source': pmc_traffic()[1], 'algorithmic_bytes_per_launch': round(g['gbytes_per_step'] * 1e9 / max(g['launches_per_step'], 1)),
                                'avg_launch_us': round(g['ms_per_step'] * 1e3 / max(g['launches_per_step'], 1), 2),
                                'launches_per_step': g['launches_per_step'], 'gemm_tflop_per_step': round(g['tflop_per_step'], 3)}
             out['kernel_families_ms_per_step'] = {k: round(v['ms_per_step'], 3) for k, v in fam.items()}

@@ -53,6 +53,7 @@ const char* ph_last_error(void);
  * (B = the [Cout][K] weight shadow).  Weight gradient (trans_a = trans_b = 1): B = x, reduction K = B*Ho*Wo, N = ks*ks*C rounded
  * up to 8 (A = dY [K][Cout]).  lda / ldb of the gathered operand are ignored. */
 typedef struct { int B, H, W, C, ks, stride; } ph_conv_gather;
+#define PH_COLSTAT_SLABS 8
 
 typedef struct {
   const void* A; const void* B; void* C;
@@ -76,9 +77,11 @@ typedef struct {
                                      multiplies by the saved derivative -- no transcendental in its epilogue, and the
                                      derivative is taken from the fp32 pre-activation instead of its bf16 rounding */
   const ph_conv_gather* conv;     /* optional: the A (forward) / B (weight gradient) operand is an im2col view, see above */
-  double* col_stats;              /* optional fp64 [2][N]: += per-column sum and sum of squares of the bf16-rounded outputs over the
+  double* col_stats;              /* optional fp64 [PH_COLSTAT_SLABS][2][N]: += per-column sum and sum of squares of the bf16-rounded outputs over the
                                      M rows (train-mode BatchNorm statistics of a conv output, vit.py:92-118, taken in the
-                                     epilogue instead of a second pass over the output); plain epilogues, no split-K */
+                                     epilogue instead of a second pass over the output); plain epilogues, no split-K.  The
+                                     accumulators are replicated PH_COLSTAT_SLABS times (a block adds to slab id % SLABS) to
+                                     spread the atomics; consumers sum the slabs */
 } ph_gemm_args;
 int ph_gemm_bf16(const ph_gemm_args* args, hipStream_t stream);
 
@@ -211,7 +214,7 @@ int ph_bn_relu_bwd(const void* da, const void* y, void* dy, int M, int C, const 
 
 /* Grouped BatchNorm passes for the expert stems (vit.py:92-118: [conv3x3 -> BatchNorm2d -> ReLU] x 4 in each of up to six
  * independent stems): the same-index layers of all stems in ONE launch.
- *   ph_bn_apply_relu_grouped: a = relu(bn(y)); sums = fp64 [2][C] per-channel sum / sum of squares of y (from the conv GEMM's
+ *   ph_bn_apply_relu_grouped: a = relu(bn(y)); sums = fp64 [PH_COLSTAT_SLABS][2][C] per-channel sum / sum of squares of y (from the conv GEMM's
  *     epilogue, ph_gemm_args.col_stats: fp64 so that E[x^2] - E[x]^2 is exact to rounding and independent of the atomics' order); writes stats[4][C] = mean, rstd, scale, shift for the backward; train mode also updates
  *     running_mean / running_var (momentum, unbiased variance) like nn.BatchNorm2d.  Eval mode normalises with the running stats.
  *   ph_bn_relu_bwd_grouped: `a` carries dA (gradient w.r.t. the ReLU output), sums = fp32 [2][C], ZERO on entry (receives

@@ -69,6 +69,7 @@ class BnItem(C.Structure):
 
 
 BN_GROUP_MAX = 8         # PH_BN_GROUP_MAX
+COLSTAT_SLABS = 8        # PH_COLSTAT_SLABS
 
 
 class LayerNormFwdArgs(C.Structure):

@@ -314,7 +314,10 @@ __global__ __launch_bounds__(256) void bn_apply_grouped_kernel(BnGroup g, float 
   for (int c = threadIdx.x; c < C; c += 256) {
     float mu, var;
     if (training) {
-      const double m1 = sums[c] / (double)t.M, m2 = sums[C + c] / (double)t.M;
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int sl = 0; sl < PH_COLSTAT_SLABS; ++sl) { s1 += sums[(size_t)sl * 2 * C + c]; s2 += sums[(size_t)sl * 2 * C + C + c]; }
+      const double m1 = s1 / (double)t.M, m2 = s2 / (double)t.M;
       mu = (float)m1;
       var = (float)fmax(m2 - m1 * m1, 0.0);
     } else {

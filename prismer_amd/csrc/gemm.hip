@@ -170,29 +170,43 @@ __device__ __forceinline__ void load_kc_conv(const ConvGather& cv, const bf16* _
     regs[i] = ok ? v : z;
   }
 }
-// CONV = 2: K-strided B operand (wgrad: reduction index = output pixel m, column = (tap, channel)): the column decomposition is
-// fixed per thread, the pixel of each of its k rows is decomposed per k-tile.
+// CONV = 2: K-strided B operand (wgrad: reduction index = output pixel m, column = (tap, channel)).  Thread -> ONE k row
+// (pixel) per k-tile and R/32 column chunks 4j + (tid & 3): the pixel decomposition (two divisions) is paid once per thread and
+// k-tile, the column decompositions are loop invariants (ColTap, computed before the k loop).
+struct ColTap { int dy, dx, c0, ok; };
 template <int R>
-__device__ __forceinline__ void load_ks_conv(const ConvGather& cv, const bf16* __restrict__ x, int col0, int ncols, int k0, int K,
-                                             u32x4 (&regs)[R * 8 / 256]) {
-  constexpr int CPR = R / 8;
-  const int col = col0 + (threadIdx.x % CPR) * 8;                   // 256 % CPR == 0: the same column chunk for every i
-  const bool cin = col < cv.Kreal && col < ncols;
-  const int cc = cin ? col : 0;
-  const int tap = fdiv(cc, cv.C, cv.inv_c), c0 = cc - tap * cv.C;
-  const int ky = cv.ks == 3 ? (tap >= 6 ? 2 : (tap >= 3 ? 1 : 0)) : 0, kx = tap - ky * cv.ks;
+__device__ __forceinline__ void coltaps_of(const ConvGather& cv, int col0, int ncols, ColTap (&ct)[R * 8 / 256]) {
 #pragma unroll
-  for (int i = 0; i < R * 8 / 256; ++i) {
-    const int m = k0 + (threadIdx.x + 256 * i) / CPR;
-    const bool min_ = m < K;
-    PixRow p = pix_of(cv, min_ ? m : 0);
-    const int iy = p.iy0 + ky, ix = p.ix0 + kx;
-    const bool ok = cin && min_ && (unsigned)iy < (unsigned)cv.H && (unsigned)ix < (unsigned)cv.W;
-    const int iyc = min(max(iy, 0), cv.H - 1), ixc = min(max(ix, 0), cv.W - 1);
-    u32x4 v = *reinterpret_cast<const u32x4*>(x + ((size_t)(p.base + iyc * cv.W + ixc)) * cv.C + c0);
-    const u32x4 z = {0u, 0u, 0u, 0u};
-    regs[i] = ok ? v : z;
+  for (int j = 0; j < R * 8 / 256; ++j) {
+    const int col = col0 + (4 * j + (threadIdx.x & 3)) * 8;
+    const bool cin = col < cv.Kreal && col < ncols;
+    const int cc = cin ? col : 0;
+    const int tap = fdiv(cc, cv.C, cv.inv_c);
+    const int ky = cv.ks == 3 ? (tap >= 6 ? 2 : (tap >= 3 ? 1 : 0)) : 0;
+    ct[j] = ColTap{ky, tap - ky * cv.ks, cc - tap * cv.C, cin ? 1 : 0};
   }
+}
+template <int R>
+__device__ __forceinline__ void load_ks_conv(const ConvGather& cv, const bf16* __restrict__ x, const ColTap (&ct)[R * 8 / 256], int k0, int K,
+                                             u32x4 (&regs)[R * 8 / 256]) {
+  const int m = k0 + ((int)threadIdx.x >> 2);
+  const bool min_ = m < K;
+  const PixRow p = pix_of(cv, min_ ? m : 0);
+#pragma unroll
+  for (int j = 0; j < R * 8 / 256; ++j) {
+    const int iy = p.iy0 + ct[j].dy, ix = p.ix0 + ct[j].dx;
+    const bool ok = ct[j].ok && min_ && (unsigned)iy < (unsigned)cv.H && (unsigned)ix < (unsigned)cv.W;
+    const int iyc = min(max(iy, 0), cv.H - 1), ixc = min(max(ix, 0), cv.W - 1);
+    u32x4 v = *reinterpret_cast<const u32x4*>(x + ((size_t)(p.base + iyc * cv.W + ixc)) * cv.C + ct[j].c0);
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    regs[j] = ok ? v : z;
+  }
+}
+template <int R>
+__device__ __forceinline__ void store_ks_conv(char* lds, const u32x4 (&regs)[R * 8 / 256]) {
+#pragma unroll
+  for (int j = 0; j < R * 8 / 256; ++j)
+    *reinterpret_cast<u32x4*>(lds + ((int)threadIdx.x >> 2) * TileBytes<R>::ks_stride + (4 * j + (threadIdx.x & 3)) * 16) = regs[j];
 }
 
 // ---- LDS -> MFMA fragment ------------------------------------------------------------------------------
@@ -431,8 +445,11 @@ __device__ __forceinline__ void tile_colstats(const GemmParams& p, const float* 
     float v = bf2f(f2bf(cl[r * BN + ((c4 ^ (r & (CH - 1))) << 2) + e]));
     s += v; ss += v * v;
   }
-  atomicAdd(p.col_stats + n0 + col, (double)s);
-  atomicAdd(p.col_stats + p.N + n0 + col, (double)ss);
+  // PH_COLSTAT_SLABS interleaved copies of the accumulators (slab = block id mod 8): a tall conv output (401408 x 96: 3136 tiles)
+  // otherwise queues thousands of atomics on each of its 192 addresses (measured: 49 -> 158 us for that GEMM)
+  double* st = p.col_stats + (size_t)(blockIdx.x % PH_COLSTAT_SLABS) * 2 * p.N;
+  atomicAdd(st + n0 + col, (double)s);
+  atomicAdd(st + p.N + n0 + col, (double)ss);
 }
 
 template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0>
@@ -483,23 +500,26 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int block_i
   constexpr int D = PF;
   u32x4 ra[D][BM * 8 / 256], rb[D][BN * 8 / 256];
   PixRow px[BM * 8 / 256];
+  ColTap ct[BN * 8 / 256];
   if constexpr (CONV == 1) {
 #pragma unroll
     for (int i = 0; i < BM * 8 / 256; ++i) px[i] = pix_of(p.cv, min(m0 + ((int)(threadIdx.x + 256 * i) >> 3), p.M - 1));
   }
+  if constexpr (CONV == 2) coltaps_of<BN>(p.cv, n0, p.N, ct);
   auto gload = [&](int kt, u32x4 (&xa)[BM * 8 / 256], u32x4 (&xb)[BN * 8 / 256]) {
     int k0 = kt * BK;
     constexpr bool KF = PF > 1;                 // ring kernels are only launched when K % BK == 0
     if constexpr (CONV == 1) load_kc_conv<BM>(p.cv, p.A, px, k0, xa);
     else if (TA) load_ks<BM, KF>(p.A, p.lda, m0, p.M, k0, p.K, xa); else load_kc<BM, KF>(p.A, p.lda, m0, p.M, k0, p.K, xa);
-    if constexpr (CONV == 2) load_ks_conv<BN>(p.cv, p.B, n0, p.N, k0, p.K, xb);
+    if constexpr (CONV == 2) load_ks_conv<BN>(p.cv, p.B, ct, k0, p.K, xb);
     else if (TB) load_ks<BN, KF>(p.B, p.ldb, n0, p.N, k0, p.K, xb); else load_kc<BN, KF>(p.B, p.ldb, n0, p.N, k0, p.K, xb);
   };
   auto lstore = [&](int buf, const u32x4 (&xa)[BM * 8 / 256], const u32x4 (&xb)[BN * 8 / 256]) {
     char* sa = smem + buf * STAGE;
     char* sb = sa + A_BYTES;
     if (TA) store_ks<BM>(sa, xa); else store_kc<BM>(sa, xa);
-    if (TB) store_ks<BN>(sb, xb); else store_kc<BN>(sb, xb);
+    if constexpr (CONV == 2) store_ks_conv<BN>(sb, xb);
+    else if (TB) store_ks<BN>(sb, xb); else store_kc<BN>(sb, xb);
   };
   auto compute = [&](int buf) {
     const char* la = smem + buf * STAGE;

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 import os
 
 from .. import ops
-from .._lib import ACT_QUICKGELU, ACT_RELU2, ACT_SAVED_GRAD, IDENT, RowMap
+from .._lib import ACT_QUICKGELU, ACT_RELU2, ACT_SAVED_GRAD, COLSTAT_SLABS, IDENT, RowMap
 from ..config import LABEL_DOMAINS
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -266,7 +266,8 @@ class EncoderProgram:
             st.append(dict(name=name, dom=dom, a=a, H=Hs, C=a.shape[3], B=a.shape[0], strides=(2, 2, 1, 1) if label else (2, 2, 2, 2),
                            a_in=[], ys=[], stats=[], geo=[], col0=None))
         n_ch = sum(d.width // k for k in (8, 4, 2, 1))
-        sums_arena = torch.zeros(len(st) * 2 * n_ch, dtype=torch.float64, device=st[0]['a'].device) if st else None     # fp64: see tile_colstats
+        SL = COLSTAT_SLABS
+        sums_arena = torch.zeros(len(st) * SL * 2 * n_ch, dtype=torch.float64, device=st[0]['a'].device) if st else None     # fp64: see tile_colstats
         stats_arena = torch.empty(len(st) * 4 * n_ch, dtype=F32, device=st[0]['a'].device) if st else None
         so = to = 0
         for i in range(4):
@@ -278,7 +279,7 @@ class EncoderProgram:
                 Co = shadow.shape[0]
                 Ho = ops.conv_out_size(H, 3, s_)
                 y = torch.empty(B * Ho * Ho, Co, dtype=BF16, device=e['a'].device)
-                sums = sums_arena[so:so + 2 * Co].view(2, Co); so += 2 * Co
+                sums = sums_arena[so:so + SL * 2 * Co].view(SL, 2, Co); so += SL * 2 * Co
                 stats = stats_arena[to:to + 4 * Co].view(4, Co); to += 4 * Co
                 if C % 8 == 0:
                     conv_items.append((e['a'], (B, H, H, C, 3, s_), shadow, y, sums if training else None))

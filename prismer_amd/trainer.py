@@ -33,18 +33,20 @@ from .store import ALIGN
 F32, BF16 = torch.float32, torch.bfloat16
 
 
-def cosine_lr(it, total, init_lr, min_lr):
-    """utils.py:13-17 of the reference."""
-    return (init_lr - min_lr) * 0.5 * (1.0 + math.cos(math.pi * it / total)) + min_lr
+from .schedules import cosine_lr                          # noqa: E402  (utils.py:13-17 of the reference; re-exported)
 
 
 class Trainer:
     def __init__(self, model, lr=5e-5, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8, min_lr=0.0, total_steps=1000,
                  task='caption', use_graph=True, process_group=None, bucket_mb=64, side_stream=False, micro_batches=1, keep_grads=False,
-                 max_text_len=None, grad_payload='bf16', transport='torch.distributed', dec_backward_stages=3):
+                 max_text_len=None, grad_payload='bf16', transport='torch.distributed', dec_backward_stages=3, lr_schedule=None,
+                 shard_optimizer=False):
         self.model = model
         self.enc, self.dec = model.expert_encoder, model.text_decoder
         self.init_lr, self.min_lr, self.total_steps = lr, min_lr, total_steps
+        # lr(it) for it = 0, 1, ...: default = the fine-tuning scripts' per-iteration cosine; prismer_amd.schedules.pretrain_schedule
+        # gives train_pretrain.py's epoch-cosine + linear warm-up
+        self.lr_schedule = lr_schedule or (lambda it: cosine_lr(it, self.total_steps, self.init_lr, self.min_lr))
         self.wd, self.betas, self.eps = weight_decay, betas, eps
         self.task = task
         self.max_text_len = max_text_len
@@ -65,8 +67,14 @@ class Trainer:
             st._grad_cur = st.grad
         dev = self.stores[0].master.device
         self.device = dev
-        self.m = [torch.zeros(st.n_train, dtype=F32, device=dev) for st in self.stores]
-        self.v = [torch.zeros(st.n_train, dtype=F32, device=dev) for st in self.stores]
+        # shard_optimizer (ZeRO-1 style, the role of accelerate's --shard_grad_op flag in train_pretrain.py:56-91,104-107): every
+        # rank keeps Adam moments for, and updates, only ITS contiguous 1/world slice of each flat buffer, then the owners
+        # broadcast their updated fp32 slices.  Optimizer state and AdamW time shrink by 1/world; off by default.
+        self.rank = torch.distributed.get_rank(process_group) if self.world > 1 else 0
+        self.shard = bool(shard_optimizer) and self.world > 1
+        own = [self._shard_bounds(i)[self.rank] for i in range(len(self.stores))] if self.shard else [(0, st.n_train) for st in self.stores]
+        self.m = [torch.zeros(max(hi - lo, 1), dtype=F32, device=dev) for lo, hi in own]
+        self.v = [torch.zeros(max(hi - lo, 1), dtype=F32, device=dev) for lo, hi in own]
         self.hyper = torch.zeros(3, dtype=F32, device=dev)
         # per-step host values travel through a ring of pinned slots: a slot is rewritten only after the async copy that read
         # it last has executed (event per slot), so a host that runs ahead of the device (no loss.item() in the loop) can
@@ -272,6 +280,28 @@ class Trainer:
         ops.join_side()
         self.sv_f = self.dh = self.dxf = None
 
+    def _shard_bounds(self, i):
+        """[(lo, hi)] per rank: contiguous, 256-element aligned slices of the trainable range of store i"""
+        n, W = self.stores[i].n_train, self.world
+        per = ((n + W - 1) // W + 255) // 256 * 256
+        return [(min(k * per, n), min((k + 1) * per, n)) for k in range(W)]
+
+    def _adamw_sharded(self, i):
+        """eager (between graph replays): AdamW on the own slice of the reduced gradients, owners broadcast their fp32 slices, bf16
+        shadows re-derived.  Collectives use torch.distributed on the current stream."""
+        st = self.stores[i]
+        bounds = self._shard_bounds(i)
+        lo, hi = bounds[self.rank]
+        if hi > lo:
+            ops.adamw(st.master[lo:hi], st.grad[lo:hi], self.m[i], self.v[i], st.shadow[lo:hi], hi - lo, self.hyper, self.betas[0],
+                      self.betas[1], self.eps, self.wd, 1.0 / self.world, zero_grad=False)
+        for k, (a, b) in enumerate(bounds):
+            if b > a:
+                src = torch.distributed.get_global_rank(self.pg, k) if self.pg is not None else k
+                torch.distributed.broadcast(st.master[a:b], src, group=self.pg)
+        ops.cast_to_bf16(st.master[:st.n_train], st.shadow[:st.n_train])
+        st.refresh_derived()
+
     def _adamw(self, i):
         st = self.stores[i]
         ops.adamw(st.master, st.grad, self.m[i], self.v[i], st.shadow, st.n_train, self.hyper, self.betas[0], self.betas[1], self.eps,
@@ -311,7 +341,18 @@ class Trainer:
         beside the encoder backward (an eager launch between graph replays, ordered by stream events like the collectives)"""
         self.opt_stream.wait_stream(self.comm_stream)
         with torch.cuda.stream(self.opt_stream):
-            self._adamw(1)
+            if self.shard:
+                self._adamw_sharded(1)
+            else:
+                self._adamw(1)
+
+    def _tail_sharded(self):
+        """sharded optimizer: the encoder's update and the seed advance run eagerly after the last bucket (collectives cannot sit
+        inside a captured segment); gradients are re-zeroed by the next step's first segment"""
+        torch.cuda.current_stream().wait_stream(self.opt_stream)
+        self._adamw_sharded(0)
+        ops.advance_seed(self.seed)
+        self._grads_clean = False
 
     def _seg_optimizer_tail_dp(self):
         torch.cuda.current_stream().wait_stream(self.opt_stream)
@@ -336,9 +377,11 @@ class Trainer:
             sched.append(((lambda k=k: self._seg_dec_backward(cuts[k], cuts[k + 1])), (lambda k=k: self._issue(f'dec{k}'))))
         seg, host = sched[-1]
         sched[-1] = (seg, lambda host=host: (host(), self._dec_adamw_after_comm()))
-        sched += [(self._seg_enc_trunk_backward_joined, lambda: self._issue('trunk')),
-                  (self._seg_enc_front_backward, lambda: (self._issue('front'), self._wait_comm())),
-                  (self._seg_optimizer_tail_dp, None)]
+        sched += [(self._seg_enc_trunk_backward_joined, lambda: self._issue('trunk'))]
+        if self.shard:
+            sched += [(self._seg_enc_front_backward, lambda: (self._issue('front'), self._wait_comm(), self._tail_sharded()))]
+        else:
+            sched += [(self._seg_enc_front_backward, lambda: (self._issue('front'), self._wait_comm())), (self._seg_optimizer_tail_dp, None)]
         return sched
 
     def _host_prologue(self):
@@ -348,7 +391,7 @@ class Trainer:
         slot = self._slots[self.it % len(self._slots)]
         if slot['ev'] is not None:
             slot['ev'].synchronize()
-        lr = cosine_lr(self.it - 1, self.total_steps, self.init_lr, self.min_lr)
+        lr = self.lr_schedule(self.it - 1)
         slot['hyper'].copy_(torch.tensor([lr, 1.0 - self.betas[0] ** self.it, 1.0 - self.betas[1] ** self.it], dtype=F32))
         self.hyper.copy_(slot['hyper'], non_blocking=True)
         if 'obj_detection' in self.enc.experts:

@@ -17,7 +17,7 @@ def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, use_graph, out, payload='bf16', n_steps=2):
+def _worker(rank, world, port, use_graph, out, payload='bf16', n_steps=2, shard=False):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
@@ -44,7 +44,8 @@ def _worker(rank, world, port, use_graph, out, payload='bf16', n_steps=2):
         pass
     m = Holder(); m.expert_encoder, m.text_decoder = enc, dec
     tab = case.instance_table(x)
-    tr = Trainer(m, lr=1e-3, total_steps=10, use_graph=use_graph, keep_grads=True, grad_payload=payload, dec_backward_stages=2)
+    tr = Trainer(m, lr=1e-3, total_steps=10, use_graph=use_graph, keep_grads=True, grad_payload=payload, dec_backward_stages=2,
+                 shard_optimizer=shard)
     assert tr.world == world and tr.dec_cuts == [2, 1, 0]
     tr.set_batch(T.to_dev(x), ids, mask, labels)
     orig = tr._host_prologue
@@ -58,6 +59,8 @@ def _worker(rank, world, port, use_graph, out, payload='bf16', n_steps=2):
     torch.cuda.synchronize()
     out[rank] = dict(loss=float(loss), grads=[st.grad[:st.n_train].float().cpu() for st in tr.stores],
                      params=[st.master[:st.n_train].float().cpu() for st in tr.stores], trace=list(tr.trace),
+                     shadow=[st.shadow[:st.n_train].float().cpu() for st in tr.stores], m=[t.float().cpu() for t in tr.m],
+                     bounds=[tr._shard_bounds(i) for i in range(2)],
                      log=list(tr.exchange.log), desc=tr.exchange.describe() if tr.exchange.log_last else None,
                      n_train=[st.n_train for st in tr.stores])
     dist.barrier()
@@ -134,3 +137,29 @@ print('NATIVE_COMM_OK')
         if 'ncclCommInitRank' in r.stderr or 'ncclGetUniqueId' in r.stderr or 'librccl not found' in r.stderr:
             pytest.skip('RCCL communicator unavailable on this box: ' + r.stderr.strip().splitlines()[-1][:200])
         raise AssertionError(r.stderr[-2000:])
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_sharded_optimizer_matches_replicated(use_graph):
+    """shard_optimizer=True (ZeRO-1 style: each rank updates its 1/world slice, owners broadcast).  Within the run both ranks end
+    with bit-identical parameters and shadows (the broadcasts delivered every slice); against a separate replicated-optimizer
+    run the parameters agree up to the fp32-atomics noise of two independent backward passes (a near-zero gradient may take
+    either sign of Adam's +-lr first step), and the owned Adam moments are the replicated run's slice."""
+    world = 2
+    res = {}
+    for shard in (False, True):
+        mgr = mp.Manager(); out = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), use_graph, out, 'bf16', 2, shard), nprocs=world, join=True)
+        res[shard] = (out[0], out[1])
+    for i in range(2):
+        assert torch.equal(res[True][0]['params'][i], res[True][1]['params'][i]) and torch.equal(res[True][0]['shadow'][i], res[True][1]['shadow'][i])
+        assert torch.equal(res[True][0]['shadow'][i], res[True][0]['params'][i].bfloat16().float())      # shadows re-derived from the gathered masters
+    for r in range(world):
+        rep, sh = res[False][r], res[True][r]
+        for i in range(2):
+            d = (rep['params'][i] - sh['params'][i]).abs()
+            assert d.max() <= 2.1e-3 * 2 and (d > 1e-5).float().mean() < 2e-2, (r, i, float(d.max()), float((d > 1e-5).float().mean()))
+            lo, hi = sh['bounds'][i][r]
+            assert sh['m'][i].numel() == max(hi - lo, 1)
+            a, b = sh['m'][i][:hi - lo], rep['m'][i][lo:hi]
+            assert ((a - b).norm() / b.norm()).item() < 1e-2

@@ -413,8 +413,9 @@ def test_implicit_gemm_conv_forward_stats_and_wgrad(ops, B, H, C, Cout, stride, 
     M = B * Ho * Ho
     geo = (B, H, H, C, ks, stride)
     y = torch.empty(M, Cout, dtype=BF, device='cuda')
-    stats = torch.zeros(2, Cout, device='cuda', dtype=torch.float64)
-    ops.conv_fwd_grouped([(x, geo, shadow, y, stats)])
+    slabs = torch.zeros(8, 2, Cout, device='cuda', dtype=torch.float64)          # PH_COLSTAT_SLABS replicated accumulators
+    ops.conv_fwd_grouped([(x, geo, shadow, y, slabs)])
+    stats = slabs.sum(0)
     xr = x.float().permute(0, 3, 1, 2).requires_grad_(False)
     wr = shadow[:, :ks * ks * C].float().view(Cout, ks, ks, C).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
     ref = F.conv2d(xr, wr, stride=stride, padding=ks // 2)

@@ -116,3 +116,44 @@ def test_store_layout_packs_qkv_and_all_cross_kv():
     # incomplete cross set (a layer without value.bias): falls back to leaving those names in place
     broken = [n for n in names if n != 'roberta.encoder.layer.1.1.self.value.bias']
     assert sorted(_reorder_qkv(list(broken))) == sorted(broken)
+
+
+def test_schedules_match_reference_loops():
+    """prismer_amd.schedules against the reference's own schedule functions driven by its two training loops (utils.py:13-31,
+    train_caption.py:127, train_pretrain.py:112-122), replayed here on a dummy optimizer."""
+    import math
+    from prismer_amd import schedules as S
+
+    class Opt:
+        def __init__(self):
+            self.param_groups = [{'lr': None}]
+
+    def ref_cosine(opt, epoch, max_epoch, init_lr, min_lr):          # utils.py:13-17
+        lr = (init_lr - min_lr) * 0.5 * (1. + math.cos(math.pi * epoch / max_epoch)) + min_lr
+        for g in opt.param_groups:
+            g['lr'] = lr
+
+    def ref_warmup(opt, step, max_step, init_lr, max_lr):            # utils.py:20-24
+        lr = min(max_lr, init_lr + (max_lr - init_lr) * step / max_step)
+        for g in opt.param_groups:
+            g['lr'] = lr
+    # fine-tune loop: cosine per iteration
+    opt, spe, epochs = Opt(), 7, 3
+    f = S.finetune_schedule(spe * epochs, 5e-5, 0.0)
+    for epoch in range(epochs):
+        for i in range(spe):
+            ref_cosine(opt, epoch * spe + i, epochs * spe, 5e-5, 0.0)
+            assert abs(opt.param_groups[0]['lr'] - f(epoch * spe + i)) < 1e-18
+    # pre-train loop: epoch cosine + step warm-up that ends in the middle of an epoch
+    opt, spe, epochs, wsteps = Opt(), 5, 4, 8
+    f = S.pretrain_schedule(spe, epochs, 3e-4, 1e-6, 1e-6, wsteps)
+    w, it = 0, 0
+    for epoch in range(epochs):
+        ref_cosine(opt, epoch, epochs, 3e-4, 1e-6)
+        for i in range(spe):
+            if w < wsteps:
+                ref_warmup(opt, w, wsteps, 1e-6, 3e-4)
+                w += 1
+            assert abs(opt.param_groups[0]['lr'] - f(it)) < 1e-18, (it, opt.param_groups[0]['lr'], f(it))
+            it += 1
+    assert S.step_lr(3, 1e-3, 1e-5, 0.5) == 1e-3 * 0.125
