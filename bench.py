@@ -32,7 +32,7 @@ PEAK_TFLOPS = 2500.0           # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 FAMILIES = ['gemm', 'layernorm', 'attention_fwd', 'attention_bwd', 'frontend', 'embed_ce', 'optimizer', 'misc']
 
 
-def make_inputs(dims, batch, T, seed, device):
+def make_inputs(dims, batch, T, seed, device, compact_labels=False):
     """SURVEY 8d synthetic inputs, generated on the device (label experts = uint8 rectangle maps gathered through a
     [256,64] table of std 0.75; dense experts U(-1,1); rgb N(0,1)); text: <s> prompt(3) body </s>, labels mask the prompt."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -50,6 +50,8 @@ def make_inputs(dims, batch, T, seed, device):
                 h, w = 1 + int(rect[b, r, 2]) % (E // 2), 1 + int(rect[b, r, 3]) % (E // 2)
                 lab[b, y0:y0 + h, x0:x0 + w] = int(rect[b, r, 4]) % 200
         table = torch.randn(256, 64, generator=g, device=device) * 0.75
+        if compact_labels:       # SURVEY 8f #2 input form: uint8 label map + CLIP-feature table, in-painted on the device by the stem
+            return lab, {'label_map': lab.to(torch.uint8), 'table': table}
         return lab, table[lab].permute(0, 3, 1, 2).contiguous()
     for n in names:
         if n in ('depth', 'edge'):
@@ -58,7 +60,10 @@ def make_inputs(dims, batch, T, seed, device):
             x[n] = torch.rand(batch, 3, E, E, generator=g, device=device) * 2 - 1
         else:
             lab, m = label_map()
-            x[n] = {'label': m, 'instance': lab.unsqueeze(1)} if n == 'obj_detection' else m
+            if compact_labels:
+                x[n] = m
+            else:
+                x[n] = {'label': m, 'instance': lab.unsqueeze(1)} if n == 'obj_detection' else m
     ids = torch.randint(3, dims.vocab_size, (batch, T), generator=g, device=device)
     ids[:, 0] = 0
     ids[:, 1:4] = torch.tensor([83, 2170, 9], device=device)
@@ -69,7 +74,7 @@ def make_inputs(dims, batch, T, seed, device):
     return x, ids, mask, labels
 
 
-def build_trainer(batch, use_graph, rank, T=30, workload='base_caption', freeze='freeze_vision'):
+def build_trainer(batch, use_graph, rank, T=30, workload='base_caption', freeze='freeze_vision', compact_labels=False):
     from prismer_amd import config as pcfg
     from prismer_amd.model.prismer_caption import PrismerCaption
     from prismer_amd.model.prismer_vqa import PrismerVQA
@@ -95,7 +100,7 @@ def build_trainer(batch, use_graph, rank, T=30, workload='base_caption', freeze=
     _ops.WQ.enabled = os.environ.get('PRISMER_WGRAD_QUEUE', '1') != '0'      # A/B switch: grouped deferred wgrads
     _ops.WQ.eager_flush = os.environ.get('PRISMER_WGRAD_EAGER_FLUSH', '0') != '0'
     _ops.WQ.bg_blocks = int(os.environ.get('PRISMER_WGRAD_BG_BLOCKS', '0'))       # with eager flush: capped background launches
-    x, ids, mask, labels = make_inputs(dims, batch, T, 1234 + rank, torch.device('cuda'))
+    x, ids, mask, labels = make_inputs(dims, batch, T, 1234 + rank, torch.device('cuda'), compact_labels)
     weights = None
     if workload == 'large_vqa':
         labels[:, :35] = -100                              # only the answer span is scored (prismer_vqa.py:32-33)
@@ -192,6 +197,9 @@ def main():
                     help='freeze_vision = the shipped fine-tune setting (headline); none = all parameters trainable (secondary)')
     ap.add_argument('--workload', default='base_caption', choices=['base_caption', 'large_vqa', 'z_base_caption'],
                     help='base_caption = the headline metric (BASELINE config 3/4); large_vqa = config 5 (secondary; use --batch 16)')
+    ap.add_argument('--compact-labels', action='store_true',
+                    help='label experts as uint8 maps + feature tables, in-painted on the device (SURVEY 8f #2; secondary: the headline '
+                         'keeps the reference loader contract of dense 64-channel fp32 maps)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -237,11 +245,12 @@ def main():
         ranks_seen = int(t.item())
         assert ranks_seen == world, (ranks_seen, world)
 
-    tr, dims, n_train = build_trainer(args.batch, not args.no_graph, rank, workload=args.workload, freeze=args.freeze)
+    tr, dims, n_train = build_trainer(args.batch, not args.no_graph, rank, workload=args.workload, freeze=args.freeze,
+                                      compact_labels=args.compact_labels)
     # algorithmic train GFLOP per image (SURVEY 8d / BASELINE.md section 2): (freeze_vision, none)
     gf_img = {'base_caption': (TRAIN_GF_PER_IMG, 307.26), 'z_base_caption': (134.30, 167.59), 'large_vqa': (2987.8, 3724.7)}[args.workload][
         0 if args.freeze == 'freeze_vision' else 1]
-    headline = args.workload == 'base_caption' and args.freeze == 'freeze_vision'
+    headline = args.workload == 'base_caption' and args.freeze == 'freeze_vision' and not args.compact_labels
 
     def barrier():
         if world > 1:
@@ -270,7 +279,7 @@ def main():
         'metric': {'base_caption': 'images/sec Prismer-BASE caption train, 224^2 + 6 experts, bs32/GPU',
                    'z_base_caption': 'images/sec PrismerZ-BASE caption train, 224^2, rgb only, bs32/GPU',
                    'large_vqa': 'images/sec Prismer-LARGE VQAv2 fine-tune, 480^2 + 6 experts, bs16/GPU'}[args.workload] +
-                  ('' if args.freeze == 'freeze_vision' else ' (freeze: none)'),
+                  ('' if args.freeze == 'freeze_vision' else ' (freeze: none)') + (' (compact label inputs)' if args.compact_labels else ''),
         'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
         'data': 'synthetic',

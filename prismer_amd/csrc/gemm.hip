@@ -1041,7 +1041,10 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
     const int big_mode = g_big_mode, big_min_tiles = g_big_min_tiles;
     const int64_t tb = (int64_t)ceil_div(a->M, big::BM) * ceil_div(a->N, big::BN);
     if (big_mode > 0 && !a->conv && !a->col_stats && !a->trans_a && !a->trans_b && (a->K % BK) == 0 && a->K >= 2 * BK && a->split_k <= 0 && a->M >= big::BM &&
-        (a->N % 8) == 0 && tb >= big_min_tiles) {
+        (a->N % 8) == 0 && tb >= big_min_tiles && (a->N <= 1024 || a->K >= 2048 || big_min_tiles <= 1)) {
+      // (measured per shape, tools/big_probe.py: the 1-block-per-CU kernel wins where a launch is one round of tiles (N = 768) or
+      //  the k loop is long (K >= 2048); wide-N, K = 768 launches keep the 2-blocks-per-CU 128x128 kernel, whose co-resident
+      //  blocks overlap one tile's epilogue with the other's main loop)
       p.tiles_m = ceil_div(a->M, big::BM); p.tiles_n = ceil_div(a->N, big::BN);
       p.k_tiles_per_split = a->K / BK;
       p.ws = nullptr; p.ldws = 0;

@@ -14,9 +14,19 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   const float lr = hyper[0], bc1 = hyper[1], bc2 = hyper[2];
   const float step = lr / bc1, rbc2 = rsqrtf(bc2), decay = 1.f - lr * wd;
   int64_t n4 = n >> 2;
+#ifndef PH_ADAMW_NT
+#define PH_ADAMW_NT 0
+#endif
+#if PH_ADAMW_NT
+#define LD4(ptr, i) __builtin_nontemporal_load(reinterpret_cast<f32x4*>(ptr) + (i))
+#define ST4(ptr, i, val) __builtin_nontemporal_store((val), reinterpret_cast<f32x4*>(ptr) + (i))
+#else
+#define LD4(ptr, i) (reinterpret_cast<f32x4*>(ptr)[i])
+#define ST4(ptr, i, val) (reinterpret_cast<f32x4*>(ptr)[i] = (val))
+#endif
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    f32x4 tp = reinterpret_cast<f32x4*>(p)[i], tg = reinterpret_cast<f32x4*>(g)[i];
-    f32x4 tm = reinterpret_cast<f32x4*>(m)[i], tv = reinterpret_cast<f32x4*>(v)[i];
+    f32x4 tp = LD4(p, i), tg = LD4(g, i);
+    f32x4 tm = LD4(m, i), tv = LD4(v, i);
     bf16x4 ob;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -28,11 +38,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
       tp[e] = pp;
       ob[e] = f2bf(pp);
     }
-    reinterpret_cast<f32x4*>(p)[i] = tp;
-    reinterpret_cast<f32x4*>(m)[i] = tm;
-    reinterpret_cast<f32x4*>(v)[i] = tv;
+    ST4(p, i, tp);
+    ST4(m, i, tm);
+    ST4(v, i, tv);
     if (pb) reinterpret_cast<bf16x4*>(pb)[i] = ob;
-    if (zero_g) reinterpret_cast<f32x4*>(g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};      // optimizer.zero_grad() of the NEXT step
+    if (zero_g) ST4(g, i, (f32x4{0.f, 0.f, 0.f, 0.f}));      // optimizer.zero_grad() of the NEXT step
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     int64_t i = (n4 << 2) + threadIdx.x;

@@ -368,6 +368,21 @@ class Trainer:
         s = self.static
         if self.world == 1:
             nl = len(self.dec_prog.layers)
+            if self.opt_stream is not None and os.environ.get('PRISMER_ADAMW_OVERLAP', '0') == '2':
+                # decoder AdamW as an EAGER launch on the optimizer stream between two graph replays (two independent
+                # branch-free streams overlap on this runtime, branches inside one graph do not)
+                def fork():
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream())
+                    self.opt_stream.wait_event(ev)
+                    with torch.cuda.stream(self.opt_stream):
+                        self._adamw(1)
+
+                def enc_bwd():
+                    self._seg_enc_trunk_backward()
+                    self._seg_enc_front_backward()
+                return [(lambda: self._seg_forward(self.static, (nl, 0)), fork),
+                        (enc_bwd, lambda: torch.cuda.current_stream().wait_stream(self.opt_stream)), (self._seg_optimizer_tail, None)]
             return [(lambda: self._seg_forward(self.static, (nl, 0)), None), (self._seg_enc_backward_with_dec_adamw, None),
                     (self._seg_optimizer_tail, None)]
         cuts = self.dec_cuts

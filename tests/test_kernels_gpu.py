@@ -154,6 +154,29 @@ def test_gemm_grouped_capped_background_launch(ops):
             assert rel_fro(gw, ref) < 3e-4, cap
 
 
+@pytest.mark.parametrize('M,N,K,act', [(1000, 776, 640, 1), (2048, 256, 128, 0), (515, 1536, 3072, 3)])
+def test_gemm_big_tile_lds_dma_kernel(ops, M, N, K, act):
+    """the 256x128 LDS-DMA kernel (global_load_lds into a 3-stage ring, counted vmcnt, raw barriers), forced for shapes it would
+    not normally take: ragged M / N tails, short and long k loops, the full fused epilogue -- against fp32 torch and against the
+    128x128 register-staged kernel on the same inputs."""
+    from prismer_amd import _lib
+    a, b = rnd(M, K, scale=0.5, seed=3), rnd(N, K, scale=0.2, seed=4)
+    bias = rnd(N, dtype=torch.float32, seed=5)
+    res = rnd(M, N, seed=6)
+    pre_big = torch.empty(M, N, dtype=BF, device='cuda'); pre_old = torch.empty_like(pre_big)
+    try:
+        _lib.lib.ph_gemm_tuning(1, 1)
+        big = ops.gemm(a, b, bias=bias, act=act, pre_out=pre_big, residual=res)
+        _lib.lib.ph_gemm_tuning(0, 160)
+        old = ops.gemm(a, b, bias=bias, act=act, pre_out=pre_old, residual=res)
+    finally:
+        _lib.lib.ph_gemm_tuning(1, 160)
+    z = a.float() @ b.float().t() + bias
+    fn = {0: lambda t: t, 1: lambda t: t * torch.sigmoid(1.702 * t), 3: lambda t: F.gelu(t)}[act]
+    assert rel_fro(pre_big, z) < 6e-3 and rel_fro(big, fn(z) + res.float()) < 6e-3
+    assert rel_fro(big, old.float()) < 2e-3 and rel_fro(pre_big, pre_old.float()) < 2e-3
+
+
 def test_gemm_f32_accumulate_splitk(ops):
     M, N, K = 768, 768, 4160           # wgrad shape: dW[N_out, K_in] = dY^T X, reduction over 4160 rows
     dy, x = rnd(K, M, scale=0.3, seed=10), rnd(K, N, scale=0.3, seed=11)

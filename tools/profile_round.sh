@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-2 profile set: kernel trace (graph replays), three PMC passes (eager), default bench line, two-rank dry run
-out=gpurun_out/r2_prof; mkdir -p $out
+out=${1:-gpurun_out/r2_prof}; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp; cd - > /dev/null
 R=$PWD
 timeout 600 python bench.py --steps 20 --warmup 5 > $out/bench_n1.json 2> $out/bench_n1.err; tail -c 400 $out/bench_n1.json; echo
