@@ -188,30 +188,40 @@ struct ConvFoldGroup {
   int blk_start[PH_CONV_GROUP_MAX + 1];
   struct Item { const float* src; void* dst; int Cout, Cin, ks, Kp; } it[PH_CONV_GROUP_MAX];
 };
-__global__ void conv_g_shadow_grouped_kernel(ConvFoldGroup g) {
+// One block per output channel: the row (ks*ks*Cin values) passes through LDS so that BOTH the global read and the global write
+// are contiguous (the direct form read or wrote with a stride of ks*ks floats: 250 / 210 us per step for 25 M stem parameters).
+__global__ __launch_bounds__(256) void conv_g_shadow_grouped_kernel(ConvFoldGroup g) {
+  extern __shared__ float row[];
   int i = 0;
   while (i + 1 < g.n && (int)blockIdx.x >= g.blk_start[i + 1]) ++i;
   const ConvFoldGroup::Item& t = g.it[i];
-  int64_t id = (int64_t)((int)blockIdx.x - g.blk_start[i]) * blockDim.x + threadIdx.x;
-  int K = t.ks * t.ks * t.Cin;
-  if (id >= (int64_t)t.Cout * K) return;
-  int k = (int)(id % K), o = (int)(id / K);
-  int tap = k / t.Cin, c = k % t.Cin;
-  reinterpret_cast<float*>(t.dst)[((int64_t)o * t.Cin + c) * t.ks * t.ks + tap] += t.src[(int64_t)o * t.Kp + k];
-}
-__global__ void conv_w_shadow_grouped_kernel(ConvFoldGroup g) {
-  int i = 0;
-  while (i + 1 < g.n && (int)blockIdx.x >= g.blk_start[i + 1]) ++i;
-  const ConvFoldGroup::Item& t = g.it[i];
-  int64_t id = (int64_t)((int)blockIdx.x - g.blk_start[i]) * blockDim.x + threadIdx.x;
-  if (id >= (int64_t)t.Cout * t.Kp) return;
-  int k = (int)(id % t.Kp), o = (int)(id / t.Kp);
-  float v = 0.f;
-  if (k < t.ks * t.ks * t.Cin) {
-    int tap = k / t.Cin, c = k % t.Cin;
-    v = t.src[((int64_t)o * t.Cin + c) * t.ks * t.ks + tap];
+  const int o = (int)blockIdx.x - g.blk_start[i];
+  const int T = t.ks * t.ks, K = T * t.Cin;
+  const float* src = t.src + (int64_t)o * t.Kp;
+  for (int k = threadIdx.x; k < K; k += 256) row[k] = src[k];
+  __syncthreads();
+  float* dst = reinterpret_cast<float*>(t.dst) + (int64_t)o * K;
+  for (int j = threadIdx.x; j < K; j += 256) {
+    const int c = j / T, tap = j - c * T;
+    dst[j] += row[tap * t.Cin + c];
   }
-  reinterpret_cast<bf16*>(t.dst)[id] = f2bf(v);
+}
+__global__ __launch_bounds__(256) void conv_w_shadow_grouped_kernel(ConvFoldGroup g) {
+  extern __shared__ float row[];
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.blk_start[i + 1]) ++i;
+  const ConvFoldGroup::Item& t = g.it[i];
+  const int o = (int)blockIdx.x - g.blk_start[i];
+  const int T = t.ks * t.ks, K = T * t.Cin;
+  const float* src = t.src + (int64_t)o * K;
+  for (int j = threadIdx.x; j < K; j += 256) row[j] = src[j];
+  __syncthreads();
+  bf16* dst = reinterpret_cast<bf16*>(t.dst) + (int64_t)o * t.Kp;
+  for (int k = threadIdx.x; k < t.Kp; k += 256) {
+    float v = 0.f;
+    if (k < K) { const int tap = k / t.Cin, c = k - tap * t.Cin; v = row[c * T + tap]; }
+    dst[k] = f2bf(v);
+  }
 }
 
 __global__ void advance_seed_kernel(uint64_t* seed) {
@@ -407,17 +417,19 @@ static int conv_group_launch(const ph_conv_layout_item* items, int n, bool to_sh
   PH_CHECK_ARG(items && n >= 1 && n <= PH_CONV_GROUP_MAX, "%s: need 1..%d items, got %d", who, PH_CONV_GROUP_MAX, n);
   ConvFoldGroup g;
   g.n = n;
-  int total = 0;
+  int total = 0, max_k = 0;
   for (int i = 0; i < n; ++i) {
     const ph_conv_layout_item& a = items[i];
     PH_CHECK_ARG(a.src && a.dst && a.Kp >= a.Cin * a.ks * a.ks, "%s: bad item %d", who, i);
     g.it[i].src = a.src; g.it[i].dst = a.dst; g.it[i].Cout = a.Cout; g.it[i].Cin = a.Cin; g.it[i].ks = a.ks; g.it[i].Kp = a.Kp;
     g.blk_start[i] = total;
-    total += (int)ceil_div64(to_shadow ? (int64_t)a.Cout * a.Kp : (int64_t)a.Cout * a.Cin * a.ks * a.ks, 256);
+    total += a.Cout;                         // one block per output channel
+    max_k = std::max(max_k, a.Cin * a.ks * a.ks);
   }
   g.blk_start[n] = total;
-  if (to_shadow) hipLaunchKernelGGL(conv_w_shadow_grouped_kernel, dim3(total), dim3(256), 0, stream, g);
-  else hipLaunchKernelGGL(conv_g_shadow_grouped_kernel, dim3(total), dim3(256), 0, stream, g);
+  PH_CHECK_ARG(max_k * 4 <= 64 * 1024, "%s: ks*ks*Cin = %d too large for the LDS row", who, max_k);
+  if (to_shadow) hipLaunchKernelGGL(conv_w_shadow_grouped_kernel, dim3(total), dim3(256), sizeof(float) * max_k, stream, g);
+  else hipLaunchKernelGGL(conv_g_shadow_grouped_kernel, dim3(total), dim3(256), sizeof(float) * max_k, stream, g);
   PH_LAUNCH_CHECK(who);
   return PH_OK;
 }

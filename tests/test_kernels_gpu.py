@@ -422,6 +422,31 @@ def test_conv_as_gemm(ops, C, stride, ks):
     assert rel_fro(dw, ds[:, :K].reshape(Co, ks, ks, C).permute(0, 3, 1, 2)) < 1e-6
 
 
+def test_conv_layout_grouped_kernels(ops):
+    """the per-step grouped layout passes of the stems (weights -> bf16 im2col-order shadows, shadow-order gradients -> parameter
+    layout), one block per output channel through LDS: against the single-layer kernels / plain permutes, for 3x3, 1x1 and the
+    16x16 patch convolution, ragged K padding included"""
+    layers = [(96, 64, 3), (192, 96, 3), (40, 3, 3), (24, 1, 3), (128, 128, 1), (64, 3, 16), (768, 384, 3)]
+    items_w, items_g, refs = [], [], []
+    for i, (Co, Ci, ks) in enumerate(layers):
+        K = ks * ks * Ci
+        Kp = (K + 7) // 8 * 8
+        w = rnd(Co, Ci, ks, ks, scale=0.3, seed=60 + i, dtype=torch.float32)
+        sh = torch.full((Co, Kp), 7.0, dtype=BF, device='cuda')
+        ds = torch.randn(Co, Kp, device='cuda')
+        dw0 = torch.randn(Co, Ci, ks, ks, device='cuda')
+        dw = dw0.clone()
+        items_w.append((w, sh, Co, Ci, ks, Kp)); items_g.append((ds, dw, Co, Ci, ks, Kp))
+        refs.append((w, ds, dw0, K, Kp))
+    ops.conv_layout_grouped(items_w, True)
+    ops.conv_layout_grouped(items_g, False)
+    for (w, sh, Co, Ci, ks, Kp), (ds, dw, _, _, _, _), (w_, ds_, dw0, K, _) in zip(items_w, items_g, refs):
+        want = w.permute(0, 2, 3, 1).reshape(Co, K).to(BF)
+        assert torch.equal(sh[:, :K], want) and float(sh[:, K:].float().abs().sum()) == 0.0, (Co, Ci, ks)
+        want_g = dw0 + ds[:, :K].reshape(Co, ks, ks, Ci).permute(0, 3, 1, 2)
+        assert torch.equal(dw, want_g), (Co, Ci, ks)
+
+
 @pytest.mark.parametrize('B,H,C,Cout,stride,ks', [(3, 28, 96, 192, 2, 3), (2, 14, 64, 96, 1, 3), (2, 15, 384, 200, 2, 3), (5, 7, 768, 768, 1, 1),
                                                   (32, 56, 96, 192, 2, 3)])
 def test_implicit_gemm_conv_forward_stats_and_wgrad(ops, B, H, C, Cout, stride, ks):
