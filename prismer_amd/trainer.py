@@ -354,10 +354,6 @@ class Trainer:
         ops.advance_seed(self.seed)
         self._grads_clean = False
 
-    def _seg_optimizer_tail_dp(self):
-        torch.cuda.current_stream().wait_stream(self.opt_stream)
-        self._seg_optimizer_tail()
-
     def _schedule(self):
         """[(compute segment, host action right after it)].
         One rank: forward + decoder backward | encoder backward (+ decoder AdamW as a parallel branch) | encoder AdamW.
@@ -396,7 +392,10 @@ class Trainer:
         if self.shard:
             sched += [(self._seg_enc_front_backward, lambda: (self._issue('front'), self._wait_comm(), self._tail_sharded()))]
         else:
-            sched += [(self._seg_enc_front_backward, lambda: (self._issue('front'), self._wait_comm())), (self._seg_optimizer_tail_dp, None)]
+            # (stream joins are host actions BETWEEN replays: a wait recorded inside a captured segment would be frozen at capture)
+            sched += [(self._seg_enc_front_backward, lambda: (self._issue('front'), self._wait_comm(),
+                                                              torch.cuda.current_stream().wait_stream(self.opt_stream))),
+                      (self._seg_optimizer_tail, None)]
         return sched
 
     def _host_prologue(self):
