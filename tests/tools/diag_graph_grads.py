@@ -1,6 +1,6 @@
 """diagnostic: Trainer eager vs hipGraph gradients per parameter (dropout 0, lr 0)"""
 import os, sys, random
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tests.golden import cases as C
 from tests.test_parity_gpu import build, set_freeze, to_dev

@@ -1,5 +1,5 @@
 import os, sys, random
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tests.golden import cases as C
 from tests.test_parity_gpu import build, set_freeze, to_dev

@@ -1,6 +1,6 @@
 """diagnostic: per-parameter gradient error of the HIP path vs the golden fixture (run on the GPU box)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from tests.test_parity_gpu import build, set_freeze, run, C, GOLD
 from tests.util import rel_fro

@@ -2,13 +2,13 @@
 fine-tune step (forward + backward + torch.optim.AdamW, freeze_vision, fp32, dropout 0.1, train-mode BatchNorm) on the synthetic
 inputs of prismer_amd/synth.py.  The number BASELINE.md quotes as "reference CPU path" (SURVEY 8d); bench.py's cpu_baseline leg
 times the oracle port on the GPU box's host instead.
-    python tools/ref_cpu_timing.py [batch] [steps]"""
+    python tests/tools/ref_cpu_timing.py [batch] [steps]"""
 import os
 import random
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import ref_harness as RH
 from prismer_amd import config, synth

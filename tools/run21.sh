@@ -1,0 +1,13 @@
+#!/bin/bash
+out=gpurun_out/r2_run21; mkdir -p $out
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -m gpu -q --timeout=900 --durations=5 > $out/pytest.log 2>&1; echo "pytest rc=$?" >> $out/pytest.log
+grep -E "^(FAILED|ERROR)|passed|failed|^E  " $out/pytest.log | tail -10
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; tail -1 $out/smoke.log
+bash tools/profile_round.sh gpurun_out/r2_prof > $out/profile.log 2>&1; grep -E "per step|total " $out/profile.log | head -3
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --compact-labels > gpurun_out/r2_prof/bench_compact_labels.json 2>/dev/null
+timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --workload z_base_caption > gpurun_out/r2_prof/bench_prismerz_base.json 2>/dev/null
+timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-roofline --workload large_vqa --batch 16 > gpurun_out/r2_prof/bench_large_vqa_bs16.json 2>/dev/null
+timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --freeze none > gpurun_out/r2_prof/bench_freeze_none.json 2>/dev/null
+for f in bench_n1 bench_compact_labels bench_prismerz_base bench_large_vqa_bs16 bench_freeze_none; do python -c "
+import json; d=json.load(open('gpurun_out/r2_prof/$f.json')); print('$f', d['value'], d['ms_per_step'], d.get('roofline',{}).get('frac'))"; done
