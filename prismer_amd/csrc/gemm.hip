@@ -234,6 +234,25 @@ __device__ __forceinline__ bf16x8 frag_ks(const char* lds, int rbase, int kk, in
   return o;
 }
 
+// K-strided operand image written by the LDS-DMA path (big kernel; B given as [K][N], A given as [K][M]): 64 k-rows of 256 B (128 n)
+// or 512 B (256 m), no padding -- the
+// DMA destination is lane-linear.  Bank spreading is done by XOR-ing the 64-B block index of a k-row with (k & 3): the four k-rows a
+// 16-lane group of ds_read_b64_tr_b16 touches then sit in four different 16-bank quarters (same effect as the 64-B row pad of the
+// register-staged image).  The DMA source addressing applies the same permutation (gemm_big_kernel).
+template <int RB>      // bytes per k-row: 256 (128-wide B tile) or 512 (256-wide A tile)
+__device__ __forceinline__ bf16x8 frag_ks_dma(const char* lds, int rbase, int kk, int lane) {
+  const int g = lane >> 4, i = lane & 15, j = i >> 2, q = i & 3;
+  const int k = kk * 16 + (g >> 1) * 8 + j;                    // k & 3 == j, for the second read (k + 4) too
+  const int byte = (rbase + (g & 1) * 16 + q * 4) * 2;         // offset inside the k-row
+  const char* p = lds + k * RB + ((((byte >> 6) ^ j) << 6) | (byte & 63));
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * RB));
+  bf16x8 o;
+  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+  o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+  return o;
+}
+
 // one lane's 4 consecutive outputs C[m][n..n+3]
 __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n, float (&v)[4], bool splitk, bool drop,
                                                const DropCtx& dc) {
@@ -317,8 +336,23 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
   }
 }
 
-// 8 consecutive outputs C[m][n..n+7] with 16-B vector loads/stores (interior tiles, 16-B aligned leading dimensions)
-__device__ __forceinline__ void epilogue_store8(const GemmParams& p, int m, int n, float (&v)[8], bool drop, const DropCtx& dc) {
+// 8 consecutive outputs C[m][n..n+7] with 16-B vector loads/stores (interior tiles, 16-B aligned leading dimensions), in two
+// halves: epi_load8 issues the global READS of the fused chain (saved activation, residual), epi_apply8 does the arithmetic and the
+// stores.  The write-out loops issue the loads of several steps before the first apply, so their latency (1-2 us under load) is
+// paid once per group instead of once per step (stores to C may alias the residual -- in-place residual adds -- so the compiler
+// cannot hoist the loads by itself; every thread reads exactly the elements it later writes, which keeps the reordering exact).
+struct EpiIn { bf16x8 a, rb; f32x4 r0, r1; };   // act_in | bf16 residual | fp32 residual (typed fields: no punning through the
+                                                 // aggregate, or it is not promoted to registers)
+__device__ __forceinline__ void epi_load8(const GemmParams& p, int m, int n, EpiIn& in) {
+  if (p.act_in) in.a = *reinterpret_cast<const bf16x8*>(p.act_in + (size_t)m * p.ld_act + n);
+  if (p.residual && p.res_f32) {
+    const float* q = reinterpret_cast<const float*>(p.residual) + (size_t)m * p.ldr + n;
+    in.r0 = *reinterpret_cast<const f32x4*>(q); in.r1 = *reinterpret_cast<const f32x4*>(q + 4);
+  } else if (p.residual) {
+    in.rb = *reinterpret_cast<const bf16x8*>(p.residual + (size_t)m * p.ldr + n);
+  }
+}
+__device__ __forceinline__ void epi_apply8(const GemmParams& p, int m, int n, float (&v)[8], bool drop, const DropCtx& dc, const EpiIn& in) {
   if (p.bias) {
     f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
 #pragma unroll
@@ -336,7 +370,7 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int m, int 
     *reinterpret_cast<bf16x8*>(p.pre_out + (size_t)m * p.ldc + n) = t;
   }
   if (p.act_in) {
-    bf16x8 t = *reinterpret_cast<const bf16x8*>(p.act_in + (size_t)m * p.ld_act + n);
+    const bf16x8 t = in.a;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= act_grad(p.act, bf2f(t[e]));
   } else if (p.act != PH_ACT_NONE && !fused_grad) {
@@ -350,12 +384,11 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int m, int 
     for (int e = 0; e < 4; ++e) { v[e] = drop_apply(dc, r0[e], v[e]); v[4 + e] = drop_apply(dc, r1[e], v[4 + e]); }
   }
   if (p.residual && p.res_f32) {
-    const float* q = reinterpret_cast<const float*>(p.residual) + (size_t)m * p.ldr + n;
-    f32x4 r0 = *reinterpret_cast<const f32x4*>(q), r1 = *reinterpret_cast<const f32x4*>(q + 4);
+    const f32x4 r0 = in.r0, r1 = in.r1;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
   } else if (p.residual) {
-    bf16x8 t = *reinterpret_cast<const bf16x8*>(p.residual + (size_t)m * p.ldr + n);
+    const bf16x8 t = in.rb;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += bf2f(t[e]);
   }
@@ -390,29 +423,43 @@ __device__ __forceinline__ void tile_writeout(const GemmParams& p, const float* 
                                               const DropCtx& dc) {
   constexpr int CH = BN / 4;                       // 16-B chunks per tile row
   // fast path: 8 outputs per thread per step (16-B loads/stores) when every leading dimension / pointer allows it
-  const bool vec8 = !(splitk) && (p.ldc % 8) == 0 && (!p.act_in || (p.ld_act % 8) == 0) && (!p.residual || (p.ldr % 8) == 0) &&
+  const bool vec8 = !(splitk) && p.N >= 8 && (p.ldc % 8) == 0 && (!p.act_in || (p.ld_act % 8) == 0) && (!p.residual || (p.ldr % 8) == 0) &&
                     ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.pre_out) | reinterpret_cast<uintptr_t>(p.act_in) |
                       reinterpret_cast<uintptr_t>(p.residual) | reinterpret_cast<uintptr_t>(p.bias)) & 15) == 0;
   if (vec8) {
-#pragma unroll 2
-    for (int it = 0; it < BM * CH / (2 * NTHR); ++it) {
-      const int id = it * NTHR + threadIdx.x;
-      const int ml = id / (CH / 2), c = (id % (CH / 2)) * 2;
-      const int m = m0 + ml, n = n0 + c * 4;
-      const int sw = ml & (CH - 1);
-      f32x4 t0 = *reinterpret_cast<const f32x4*>(cl + ml * BN + ((c ^ sw) << 2));
-      f32x4 t1 = *reinterpret_cast<const f32x4*>(cl + ml * BN + (((c + 1) ^ sw) << 2));
-      if (m < p.M && n + 8 <= p.N) {
-        float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+    // steps per thread; steps per load group (16 VGPRs of prefetched inputs per step: 4 for the 512-thread kernel, whose register budget
+    // is 256/lane at its occupancy; 2 for the 256-thread kernels, which must stay under 192 + 64 accumulators for 2 blocks per CU)
+    constexpr int IT = BM * CH / (2 * NTHR), G = (NTHR >= 512 && IT % 4 == 0) ? 4 : (IT % 2 == 0 ? 2 : 1);
+    for (int it0 = 0; it0 < IT; it0 += G) {
+      EpiIn in[G];                  // (indexed with compile-time constants only and fully initialised: stays in VGPRs)
+      static_for(std::make_integer_sequence<int, G>{}, [&](auto uu) {
+        constexpr int u = decltype(uu)::value;
+        const int id = (it0 + u) * NTHR + threadIdx.x;
+        const int ml = id / (CH / 2), c = (id % (CH / 2)) * 2;
+        const int m = min(m0 + ml, p.M - 1), n = (n0 + c * 4 + 8 <= p.N) ? n0 + c * 4 : 0;     // always a valid address: the loads are unconditional
+        in[u] = EpiIn{};
+        epi_load8(p, m, n, in[u]);
+      });
+      static_for(std::make_integer_sequence<int, G>{}, [&](auto uu) {
+        constexpr int u = decltype(uu)::value;
+        const int id = (it0 + u) * NTHR + threadIdx.x;
+        const int ml = id / (CH / 2), c = (id % (CH / 2)) * 2;
+        const int m = m0 + ml, n = n0 + c * 4;
+        const int sw = ml & (CH - 1);
+        f32x4 t0 = *reinterpret_cast<const f32x4*>(cl + ml * BN + ((c ^ sw) << 2));
+        f32x4 t1 = *reinterpret_cast<const f32x4*>(cl + ml * BN + (((c + 1) ^ sw) << 2));
+        if (m < p.M && n + 8 <= p.N) {
+          float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
 #ifdef PH_GEMM_DIAG_NOSTORE  // diagnostics build: staging + LDS reads, no HBM traffic from the epilogue
-        if (v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] != 123456.789f) continue;
+          if (v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] != 123456.789f) return;
 #endif
-        epilogue_store8(p, m, n, v, drop, dc);
-      } else if (m < p.M) {
-        float v0[4] = {t0[0], t0[1], t0[2], t0[3]}, v1[4] = {t1[0], t1[1], t1[2], t1[3]};
-        if (n < p.N) epilogue_store(p, m, n, v0, false, drop, dc);
-        if (n + 4 < p.N) epilogue_store(p, m, n + 4, v1, false, drop, dc);
-      }
+          epi_apply8(p, m, n, v, drop, dc, in[u]);
+        } else if (m < p.M) {
+          float v0[4] = {t0[0], t0[1], t0[2], t0[3]}, v1[4] = {t1[0], t1[1], t1[2], t1[3]};
+          if (n < p.N) epilogue_store(p, m, n, v0, false, drop, dc);
+          if (n + 4 < p.N) epilogue_store(p, m, n + 4, v1, false, drop, dc);
+        }
+      });
     }
   } else {
 #pragma unroll 4
@@ -452,8 +499,11 @@ __device__ __forceinline__ void tile_colstats(const GemmParams& p, const float* 
   atomicAdd(st + p.N + n0 + col, (double)ss);
 }
 
-template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0>
-__device__ __forceinline__ void gemm_body(const GemmParams& p, const int block_id, const int split_id, const int nsplits) {
+// One output tile over the k-tiles [kt_begin, kt_end).  XCD_REMAP: block_id is a hardware block index of a one-tile-per-block launch
+// (re-mapped so that each XCD owns a contiguous run of tiles); otherwise block_id already is the tile index.  splitk: the tile has
+// other contributors (raw partial sums: workspace slice blockIdx.z, or fp32 atomics into C when there is no workspace).
+template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0, bool XCD_REMAP = true>
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, const int block_id, const int kt_begin, const int kt_end, const bool splitk) {
   static_assert(CONV == 0 || (CONV == 1 && !TA && !TB) || (CONV == 2 && TA && TB), "conv gather: A of an NN problem or B of a TT problem");
   constexpr int WM = BM / 2, WN = BN / 2;   // wave tile
   constexpr int TM = WM / 32, TN = WN / 32; // 32x32 MFMA tiles per wave
@@ -465,7 +515,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int block_i
   // XCD-aware tile mapping: hardware places block b on XCD b % 8; give each XCD a contiguous run of tiles.
   int nt = p.tiles_m * p.tiles_n;
   int bid = block_id;
-  {
+  if constexpr (XCD_REMAP) {
     int q = nt / 8, r = nt % 8, xcd = bid % 8, idx = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
@@ -479,9 +529,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int block_i
   const int rin = bid % group_sz;
   int tm = first_m + rin % gm, tn = rin / gm;
   int m0 = tm * BM, n0 = tn * BN;
-  int kt_begin = split_id * p.k_tiles_per_split;
-  int kt_total = (p.K + BK - 1) / BK;
-  int kt_end = min(kt_begin + p.k_tiles_per_split, kt_total);
   if (kt_begin >= kt_end) return;
 
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -611,7 +658,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int block_i
   // to HBM from that layout costs one cache-line touch per 16 B; instead the fp32 tile is parked in LDS (re-using the
   // stage buffers, 16-B chunks XOR-swizzled by the row so both sides are conflict-free) and re-read row-wise: 32
   // consecutive lanes then own 256 contiguous bytes of one output row for every load/store of the fused epilogue.
-  const bool splitk = nsplits > 1;
   DropCtx dc;
   const bool drop = p.drop_p > 0.0f;
   if (drop) dc = make_drop(p.drop_seed, p.drop_stream, p.drop_p);
@@ -631,6 +677,13 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, const int block_i
   __syncthreads();
   tile_writeout<BM, BN, 256>(p, cl, m0, n0, splitk, drop, dc);
   if (p.col_stats) tile_colstats<BM, BN, 256>(p, cl, m0, n0);
+}
+
+template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0>
+__device__ __forceinline__ void gemm_body(const GemmParams& p, const int block_id, const int split_id, const int nsplits) {
+  const int kt_begin = split_id * p.k_tiles_per_split;
+  const int kt_end = min(kt_begin + p.k_tiles_per_split, (p.K + BK - 1) / BK);
+  gemm_tile<BM, BN, TA, TB, PF, CONV, true>(p, block_id, kt_begin, kt_end, nsplits > 1);
 }
 
 template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0>
@@ -658,13 +711,13 @@ constexpr int SMEM = STAGES * STAGE;                                            
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
-template <int VARIANT>
-__global__ __launch_bounds__(NTHR) void gemm_big_kernel(GemmParams p) {
+template <int VARIANT, bool TA, bool TB, bool XCD_REMAP>
+__device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // tile mapping: same XCD-contiguous + grouped rasterisation as gemm_body
+  // tile mapping: same XCD-contiguous + grouped rasterisation as gemm_tile
   const int nt = p.tiles_m * p.tiles_n;
-  int bid = blockIdx.x;
-  {
+  int bid = block_id;
+  if constexpr (XCD_REMAP) {
     int q = nt / 8, r = nt % 8, xcd = bid % 8, idx = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
@@ -686,15 +739,27 @@ __global__ __launch_bounds__(NTHR) void gemm_big_kernel(GemmParams p) {
   const bf16* b_src[B_INSTR];
 #pragma unroll
   for (int i = 0; i < A_INSTR; ++i) {
-    const int r = (i * 8 + wave) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
-    a_src[i] = p.A + (size_t)min(m0 + r, p.M - 1) * p.lda + c * 8;
+    if constexpr (TA) {   // A = [K][M]: one instruction = 2 k-rows x 512 B; lane -> k-row (lane >> 5), LDS slot lane & 31 holds chunk c
+      const int kr = (i * 8 + wave) * 2 + (lane >> 5), pos = lane & 31;
+      const int c = (((pos >> 2) ^ (kr & 3)) << 2) | (pos & 3);
+      a_src[i] = p.A + (size_t)kr * p.lda + min(m0 + c * 8, p.M - 8);
+    } else {
+      const int r = (i * 8 + wave) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      a_src[i] = p.A + (size_t)min(m0 + r, p.M - 1) * p.lda + c * 8;
+    }
   }
 #pragma unroll
   for (int i = 0; i < B_INSTR; ++i) {
-    const int r = (i * 8 + wave) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
-    b_src[i] = p.B + (size_t)min(n0 + r, p.N - 1) * p.ldb + c * 8;
+    if constexpr (TB) {   // B = [K][N]: one instruction = 4 k-rows x 256 B; lane -> k-row (lane >> 4), LDS slot lane & 15 holds chunk c
+      const int kr = (i * 8 + wave) * 4 + (lane >> 4), pos = lane & 15;
+      const int c = (((pos >> 2) ^ (kr & 3)) << 2) | (pos & 3);
+      b_src[i] = p.B + (size_t)kr * p.ldb + min(n0 + c * 8, p.N - 8);
+    } else {
+      const int r = (i * 8 + wave) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      b_src[i] = p.B + (size_t)min(n0 + r, p.N - 1) * p.ldb + c * 8;
+    }
   }
   auto issue = [&](int kt, int stage) {
     char* sa = smem + stage * STAGE;
@@ -702,10 +767,10 @@ __global__ __launch_bounds__(NTHR) void gemm_big_kernel(GemmParams p) {
     const int koff = kt * BK;
 #pragma unroll
     for (int i = 0; i < A_INSTR; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t*)(a_src[i] + koff), (lptr_t*)(sa + (i * 8 + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t*)(a_src[i] + (TA ? (size_t)koff * p.lda : (size_t)koff)), (lptr_t*)(sa + (i * 8 + wave) * 1024), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t*)(b_src[i] + koff), (lptr_t*)(sb + (i * 8 + wave) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t*)(b_src[i] + (TB ? (size_t)koff * p.ldb : (size_t)koff)), (lptr_t*)(sb + (i * 8 + wave) * 1024), 16, 0, 0);
   };
 
   f32x16 acc[2][2];
@@ -717,55 +782,99 @@ __global__ __launch_bounds__(NTHR) void gemm_big_kernel(GemmParams p) {
   auto compute = [&](int stage) {
     const char* la = smem + stage * STAGE;
     const char* lb = la + A_BYTES;
-    if constexpr (VARIANT & 2) {
-      // fragment double buffer: the ds_reads of k-step kk+1 are in flight while the MFMAs of k-step kk run
-      bf16x8 fx[2][2], fw[2][2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) { fx[0][i] = frag_kc(la, wm * 64 + i * 32, 0, lane); fw[0][i] = frag_kc(lb, wn * 64 + i * 32, 0, lane); }
-      static_for(std::make_integer_sequence<int, BK / 16>{}, [&](auto kq) {
-        constexpr int kk = decltype(kq)::value, cur = kk & 1, nxt = cur ^ 1;
-        if constexpr (kk + 1 < BK / 16) {
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8 fx[2], fw[2];
 #pragma unroll
-          for (int i = 0; i < 2; ++i) { fx[nxt][i] = frag_kc(la, wm * 64 + i * 32, kk + 1, lane); fw[nxt][i] = frag_kc(lb, wn * 64 + i * 32, kk + 1, lane); }
-        }
-        if (VARIANT & 1) __builtin_amdgcn_s_setprio(1);
+      for (int i = 0; i < 2; ++i) fx[i] = TA ? frag_ks_dma<512>(la, wm * 64 + i * 32, kk, lane) : frag_kc(la, wm * 64 + i * 32, kk, lane);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j) fw[j] = TB ? frag_ks_dma<256>(lb, wn * 64 + j * 32, kk, lane) : frag_kc(lb, wn * 64 + j * 32, kk, lane);
+      if (VARIANT & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[cur][j], fx[cur][i], acc[i][j], 0, 0, 0);
-        if (VARIANT & 1) __builtin_amdgcn_s_setprio(0);
-      });
-    } else {
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int kk = 0; kk < BK / 16; ++kk) {
-        bf16x8 fx[2], fw[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) fx[i] = frag_kc(la, wm * 64 + i * 32, kk, lane);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) fw[j] = frag_kc(lb, wn * 64 + j * 32, kk, lane);
-        if (VARIANT & 1) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fx[i], acc[i][j], 0, 0, 0);
-        if (VARIANT & 1) __builtin_amdgcn_s_setprio(0);
-      }
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fx[i], acc[i][j], 0, 0, 0);
+      if (VARIANT & 1) __builtin_amdgcn_s_setprio(0);
     }
   };
 
-  // ---- main loop: tile t lives in stage t % 3.  Every iteration issues exactly one tile (index clamped: the surplus loads of
-  // the last two iterations land in a stage nobody reads again), so "all but the newest tile have landed" is always vmcnt(6).
-  issue(0, 0);
-  issue(min(1, nk - 1), 1);
-  int st = 0;                                                // stage of tile t
-  for (int t = 0; t < nk; ++t) {
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");         // my DMA writes of tile t are in LDS (tile t+1 may still fly)
-    __builtin_amdgcn_s_barrier();                            // everybody's are; everybody finished reading tile t-1
-    asm volatile("" ::: "memory");
-    int st2 = st + 2; st2 = st2 >= 3 ? st2 - 3 : st2;
-    issue(min(t + 2, nk - 1), st2);                          // overwrites the stage tile t-1 was read from
-    compute(st);
-    st = st + 1 == 3 ? 0 : st + 1;
+  if constexpr ((VARIANT & 4) == 0) {
+    // ---- main loop: tile t lives in stage t % 3.  Every iteration issues exactly one tile (index clamped: the surplus loads of
+    // the last two iterations land in a stage nobody reads again), so "all but the newest tile have landed" is always vmcnt(6).
+    issue(0, 0);
+    issue(min(1, nk - 1), 1);
+    int st = 0;                                                // stage of tile t
+    for (int t = 0; t < nk; ++t) {
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");         // my DMA writes of tile t are in LDS (tile t+1 may still fly)
+      __builtin_amdgcn_s_barrier();                            // everybody's are; everybody finished reading tile t-1
+      asm volatile("" ::: "memory");
+      int st2 = st + 2; st2 = st2 >= 3 ? st2 - 3 : st2;
+      issue(min(t + 2, nk - 1), st2);                          // overwrites the stage tile t-1 was read from
+      compute(st);
+      st = st + 1 == 3 ? 0 : st + 1;
+    }
+  } else {
+    // ---- ping-pong main loop (VARIANT & 4).  The two waves of a SIMD (wave w of group 0 = waves 0..3, wave w+4 of group 1) take
+    // turns on the matrix pipe: every k-tile is two PHASES per group, R(t) = the 16 ds_read_b128 of the wave's whole k-tile (64
+    // fragment VGPRs) and M(t) = its 16 MFMAs with the LDS-DMA of a later tile issued between them; group 1 runs one phase behind
+    // group 0, every phase ends in one workgroup barrier:
+    //     phase 2t   : group 0 R(t)                 | group 1 M(t-1) + DMA(t+2)
+    //     phase 2t+1 : group 0 M(t) + DMA(t+2)      | group 1 R(t)
+    // so while one wave of a SIMD issues back-to-back MFMAs its partner collects operands, instead of both waves alternating
+    // ds_read -> s_waitcnt -> 4 MFMAs in lockstep (what the compiler makes of the plain loop).
+    // Ordering (3-stage ring, tile t in stage t % 3; group g's M(t) issues tile t+2+g, so every wave has exactly one tile newer
+    // than the one it must have landed and the wait is always vmcnt(6)):
+    //   RAW  every wave waits vmcnt(6) before the barrier that ends an ODD phase (group 0: after M(t)'s issue, group 1: in R(t)):
+    //        all shares of tile t+1 are then in LDS, the first read of tile t+1 is in phase 2t+2 (one barrier later).
+    //   WAR  R phases end with lgkmcnt(0) BEFORE their barrier; stage (t+2)%3 = stage of tile t-1 was last read in phase 2t-1 and
+    //        is overwritten from phase 2t+1 (group 0) / 2t (group 1, tile t+2 = (t-1)+3) on.
+    const int grp = wave >> 2;
+    issue(0, 0);
+    issue(min(1, nk - 1), 1);
+    if (grp) {
+      issue(min(2, nk - 1), 2);
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                              // tile 0 is in LDS for everybody
+    if (grp) __builtin_amdgcn_s_barrier();                     // group 1 idles through phase 0
+    int st = 0;
+    for (int t = 0; t < nk; ++t) {
+      // R(t)
+      const char* la = smem + st * STAGE;
+      const char* lb = la + A_BYTES;
+      bf16x8 fx[BK / 16][2], fw[BK / 16][2];
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fx[kk][i] = TA ? frag_ks_dma<512>(la, wm * 64 + i * 32, kk, lane) : frag_kc(la, wm * 64 + i * 32, kk, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fw[kk][j] = TB ? frag_ks_dma<256>(lb, wn * 64 + j * 32, kk, lane) : frag_kc(lb, wn * 64 + j * 32, kk, lane);
+      }
+      if (grp) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // M(t)
+      int sn = st + 2 + grp; sn = sn >= 3 ? sn - 3 : sn;
+      if (VARIANT & 1) __builtin_amdgcn_s_setprio(1);
+      issue(min(t + 2 + grp, nk - 1), sn);
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[kk][j], fx[kk][i], acc[i][j], 0, 0, 0);
+      if (VARIANT & 1) __builtin_amdgcn_s_setprio(0);
+      if (!grp) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      st = st + 1 == 3 ? 0 : st + 1;
+    }
+    if (!grp) __builtin_amdgcn_s_barrier();                    // group 0 idles through the last phase (group 1's M(nk-1))
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // drain the surplus DMA before the ring is reused as the C tile
   __builtin_amdgcn_s_barrier();
@@ -789,14 +898,19 @@ __global__ __launch_bounds__(NTHR) void gemm_big_kernel(GemmParams p) {
   tile_writeout<BM, BN, NTHR>(p, cl, m0, n0, false, drop, dc);
 }
 
-template <int VARIANT>
+template <int VARIANT, bool TA, bool TB>
+__global__ __launch_bounds__(NTHR) void gemm_big_kernel(GemmParams p) {
+  big_tile<VARIANT, TA, TB, true>(p, blockIdx.x);
+}
+
+template <int VARIANT, bool TA, bool TB>
 int launch(const GemmParams& p, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<VARIANT>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<VARIANT, TA, TB>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_big_kernel<VARIANT>), dim3(p.tiles_m * p.tiles_n), dim3(NTHR), SMEM, s, p);
+  hipLaunchKernelGGL((gemm_big_kernel<VARIANT, TA, TB>), dim3(p.tiles_m * p.tiles_n), dim3(NTHR), SMEM, s, p);
   PH_LAUNCH_CHECK("gemm_big_kernel");
   return PH_OK;
 }
@@ -808,6 +922,8 @@ int launch(const GemmParams& p, hipStream_t s) {
 struct GroupParams {
   int n;
   int tile_start[PH_GEMM_GROUP_MAX + 1];
+  int iter_start[PH_GEMM_GROUP_MAX + 1];   // stream-K launches: prefix sums of tiles x k-tiles per problem
+  int iters_per_worker;                    // stream-K launches: length of one worker's slice of that iteration space
   GemmParams p[PH_GEMM_GROUP_MAX];
 };
 // The grid may be SMALLER than the number of tiles (ph_gemm_grouped_bf16's max_blocks): each block then walks tiles
@@ -821,6 +937,64 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupParams g) {
     while (i + 1 < g.n && t >= g.tile_start[i + 1]) ++i;
     gemm_body<BM, BN, TA, TB, PF, CONV>(g.p[i], t - g.tile_start[i], 0, 1);
     __syncthreads();                     // the epilogue's LDS staging area is the next tile's stage buffer
+  }
+}
+
+// Grouped launch on the 256x128 ping-pong kernel (weight-gradient layout, long reductions): a persistent grid of one block per CU
+// walks the tiles round by round; within a round the XCD-contiguous numbering of gemm_tile is kept (tiles that share an operand
+// panel run on one XCD at the same time).
+namespace big {
+template <int VARIANT, bool TA, bool TB>
+__global__ __launch_bounds__(NTHR) void gemm_big_grouped_kernel(GroupParams g) {
+  const int total = g.tile_start[g.n], grid = gridDim.x;
+  int i = 0;
+  for (int base = 0; base < total; base += grid) {
+    const int cnt = min(grid, total - base);
+    if ((int)blockIdx.x >= cnt) break;
+    const int q = cnt / 8, r = cnt % 8, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+    const int t = base + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    while (i + 1 < g.n && t >= g.tile_start[i + 1]) ++i;
+    big_tile<VARIANT, TA, TB, false>(g.p[i], t - g.tile_start[i]);
+    __syncthreads();                     // the write-out's LDS staging area is the next tile's DMA ring
+  }
+}
+template <int VARIANT, bool TA, bool TB>
+int launch_grouped(const GroupParams& g, int total, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_grouped_kernel<VARIANT, TA, TB>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_big_grouped_kernel<VARIANT, TA, TB>), dim3(total < 256 ? total : 256), dim3(NTHR), SMEM, s, g);
+  PH_LAUNCH_CHECK("gemm_big_grouped_kernel");
+  return PH_OK;
+}
+}  // namespace big
+
+// Stream-K form of the grouped launch, for groups of plain fp32-accumulate problems (the deferred weight gradients: dW += dY^T X):
+// the work is the flat iteration space (problem, tile, k-tile); gridDim.x workers -- one per block slot of the chip -- each take an
+// equal contiguous slice of it, whatever the tile count.  A worker therefore runs at most one tail of a tile, some whole tiles and one
+// head of a tile; a tile whose k range is shared adds its partial sums with fp32 atomics (the gradient buffers are fp32 accumulators
+// anyway), a tile owned by one worker keeps the plain read-add-write epilogue.  Without this a group of 288 tiles x 620 k-tiles (the
+// resampler's K/V weight gradients) put two blocks on 32 CUs and one on the rest and ran at the pace of the doubled-up CUs, and
+// 1152-tile groups paid three block rounds for 2.25 rounds of work.  Workers are numbered XCD-contiguously (hardware places block b on
+// XCD b % 8) so that neighbouring tiles -- which share operand panels -- meet in one L2.
+template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0>
+__global__ __launch_bounds__(256) void gemm_streamk_kernel(GroupParams g) {
+  const int W = gridDim.x, q = W / 8, r = W % 8, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+  const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  int it = w * g.iters_per_worker;
+  const int it_end = min(it + g.iters_per_worker, g.iter_start[g.n]);
+  int i = 0;
+  while (it < it_end) {
+    while (i + 1 < g.n && it >= g.iter_start[i + 1]) ++i;
+    const int kt = g.p[i].k_tiles_per_split;
+    const int local = it - g.iter_start[i];
+    const int tile = local / kt, k0 = local - tile * kt;
+    const int k1 = min(kt, k0 + (it_end - it));
+    gemm_tile<BM, BN, TA, TB, PF, CONV, false>(g.p[i], tile, k0, k1, !(k0 == 0 && k1 == kt));
+    __syncthreads();                     // the epilogue's LDS staging area is the next unit's stage buffer
+    it += k1 - k0;
   }
 }
 
@@ -892,7 +1066,7 @@ int dispatch_layout(const GemmParams& p, int ta, int tb, int splits, hipStream_t
 }  // namespace
 
 static int g_big_mode = -1, g_big_min_tiles = -1;
-/* tuning hook (benchmarks / A-B probes): selects the big-tile kernel variant and its minimum tile count; -1 keeps a value */
+
 extern "C" int ph_gemm_tuning(int big_mode, int big_min_tiles) {
   if (big_mode >= 0) g_big_mode = big_mode;
   if (big_min_tiles >= 0) g_big_min_tiles = big_min_tiles;
@@ -940,8 +1114,18 @@ static int fill_params(const ph_gemm_args* a, GemmParams& p) {
 }
 
 template <int BM, bool TA, bool TB, int PF, int CONV = 0>
-static int launch_grouped(const GroupParams& g, int total, int max_blocks, hipStream_t s) {
+static int launch_grouped(const GroupParams& g, int total, int max_blocks, int workers, hipStream_t s) {
   constexpr int smem = 2 * ((TA ? TileBytes<BM>::ks : TileBytes<BM>::kc) + (TB ? TileBytes<BM>::ks : TileBytes<BM>::kc));
+  if (workers > 0) {                    // stream-K: `workers` blocks share the flat (tile, k-tile) iteration space equally
+    static bool attr_sk = false;
+    if (!attr_sk) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_streamk_kernel<BM, BM, TA, TB, PF, CONV>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      attr_sk = true;
+    }
+    hipLaunchKernelGGL((gemm_streamk_kernel<BM, BM, TA, TB, PF, CONV>), dim3(workers), dim3(256), smem, s, g);
+    PH_LAUNCH_CHECK("gemm_streamk_kernel");
+    return PH_OK;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<BM, BM, TA, TB, PF, CONV>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -953,11 +1137,11 @@ static int launch_grouped(const GroupParams& g, int total, int max_blocks, hipSt
   return PH_OK;
 }
 template <int BM, int PF>
-static int launch_grouped_layout(const GroupParams& g, int total, int max_blocks, int ta, int tb, hipStream_t s) {
-  if (!ta && !tb) return launch_grouped<BM, false, false, PF>(g, total, max_blocks, s);
-  if (!ta && tb) return launch_grouped<BM, false, true, PF>(g, total, max_blocks, s);
-  if (ta && tb) return launch_grouped<BM, true, true, PF>(g, total, max_blocks, s);
-  return launch_grouped<BM, true, false, PF>(g, total, max_blocks, s);
+static int launch_grouped_layout(const GroupParams& g, int total, int max_blocks, int workers, int ta, int tb, hipStream_t s) {
+  if (!ta && !tb) return launch_grouped<BM, false, false, PF>(g, total, max_blocks, workers, s);
+  if (!ta && tb) return launch_grouped<BM, false, true, PF>(g, total, max_blocks, workers, s);
+  if (ta && tb) return launch_grouped<BM, true, true, PF>(g, total, max_blocks, workers, s);
+  return launch_grouped<BM, true, false, PF>(g, total, max_blocks, workers, s);
 }
 
 extern "C" int ph_gemm_grouped_bf16(const ph_gemm_args* args, int n, hipStream_t stream) {
@@ -1003,20 +1187,80 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
     total += g.p[i].tiles_m * g.p[i].tiles_n;
   }
   g.tile_start[n] = total;
+  // ---- weight-gradient groups with long reductions: the 256x128 ping-pong kernel, one persistent block per CU ----
+  {
+    if (g_big_mode < 0) { const char* e = getenv("PH_GEMM_BIG"); g_big_mode = e ? atoi(e) : 5; }
+    static int big_grp = -1;            // PH_GEMM_BIG_GROUPED=0: keep every group on the 128x128 / 64x64 grouped kernel
+    if (big_grp < 0) { const char* e = getenv("PH_GEMM_BIG_GROUPED"); big_grp = e ? atoi(e) : 1; }
+    bool ok = g_big_mode > 0 && big_grp && !conv && max_blocks == 0 && args[0].trans_a && args[0].trans_b;
+    int tbig = 0, kt_min = 1 << 30, kt_big = 0;
+    for (int i = 0; i < n && ok; ++i) {
+      const ph_gemm_args& a = args[i];
+      ok = (a.K % BK) == 0 && (a.M % 8) == 0 && (a.N % 8) == 0 && a.M >= 8 && a.N >= 8 && !a.col_stats;
+      tbig += ceil_div(a.M, big::BM) * ceil_div(a.N, big::BN);
+      kt_min = min(kt_min, a.K / BK); kt_big = max(kt_big, a.K / BK);
+    }
+    if (ok && kt_min >= 32) {
+      // rounds x (k loop + fixed part) of either kernel, constants from the per-shape fits: 0.67 us per k-tile for the
+      // one-per-CU 256x128 block, 0.84 us per k-tile and pair of co-resident 128x128 blocks (0.5 us for a lone one)
+      const double cost_big = ceil(tbig / 256.0) * (kt_big * 0.67 + 14.0);
+      const int t128 = total;           // (tiles of the BMsel grid computed above; BMsel is 128 for these groups)
+      const double cost_128 = BMsel == 128 ? (t128 <= 256 ? kt_big * 0.5 + 10.0 : ceil(t128 / 512.0) * (kt_big * 0.84 + 10.0)) : 1e30;
+      if (cost_big < cost_128) {
+        int tot = 0;
+        for (int i = 0; i < n; ++i) {
+          g.p[i].tiles_m = ceil_div(args[i].M, big::BM); g.p[i].tiles_n = ceil_div(args[i].N, big::BN);
+          g.p[i].k_tiles_per_split = args[i].K / BK;
+          g.tile_start[i] = tot;
+          tot += g.p[i].tiles_m * g.p[i].tiles_n;
+        }
+        g.tile_start[n] = tot;
+        g.iters_per_worker = 0;
+        return big::launch_grouped<4, true, true>(g, tot, stream);
+      }
+    }
+  }
+  // ---- stream-K for plain fp32-accumulate groups whose tile count does not fill whole block rounds (see gemm_streamk_kernel) ----
+  int workers = 0;
+  g.iters_per_worker = 0;
+  {
+    static int sk = -1;                 // PH_GEMM_STREAMK=1 enables it.  OFF by default: measured in the step (profiles/r2_ab_step_switches.txt) the
+                                        // fp32 atomics of the shared tiles cost more than the balance gains (+0.3 .. +1.6 ms per step)
+    if (sk < 0) { const char* e = getenv("PH_GEMM_STREAMK"); sk = e ? atoi(e) : 0; }
+    static int sk_min_kt = -1;          // PH_GEMM_STREAMK_MIN_KT: only groups whose reductions are at least this many k-tiles long
+    if (sk_min_kt < 0) { const char* e = getenv("PH_GEMM_STREAMK_MIN_KT"); sk_min_kt = e ? atoi(e) : 64; }
+    bool plain = sk != 0 && max_blocks == 0;
+    int64_t iters = 0;
+    for (int i = 0; i < n; ++i) {
+      const ph_gemm_args& a = args[i];
+      plain = plain && g.p[i].k_tiles_per_split >= sk_min_kt && !a.bias && !a.pre_out && !a.act_in && a.act == PH_ACT_NONE && !a.residual && !(a.drop_p > 0.0f) && a.out_f32 &&
+              a.accumulate && !a.col_stats && a.alpha == 1.0f;
+      g.iter_start[i] = (int)iters;
+      iters += (int64_t)g.p[i].tiles_m * g.p[i].tiles_n * g.p[i].k_tiles_per_split;
+    }
+    g.iter_start[n] = (int)iters;
+    const int slots = BMsel == 128 ? 512 : 1024;          // co-resident blocks of the chip: 2 (128x128) / 4 (64x64) per CU
+    const double rounds = (double)total / slots;
+    const double waste = ceil(rounds) / rounds - 1.0;      // idle share of the last block round (incl. a first round that is not full)
+    if (plain && iters < (1ll << 30) && waste > 0.08 && iters >= 8ll * slots) {
+      workers = slots;
+      g.iters_per_worker = (int)ceil_div64(iters, (int64_t)workers);
+    }
+  }
   const int ta = args[0].trans_a, tb = args[0].trans_b;
   if (conv) {               // gathered operand: forward (NN, A = im2col view) or weight gradient (TT, B = im2col view); no prefetch ring
     PH_CHECK_ARG(ta == tb, "ph_gemm_grouped_bf16: conv gather needs the NN or the TT layout");
-    if (!ta) return BMsel == 128 ? launch_grouped<128, false, false, 1, 1>(g, total, max_blocks, stream)
-                                 : launch_grouped<64, false, false, 1, 1>(g, total, max_blocks, stream);
-    return BMsel == 128 ? launch_grouped<128, true, true, 1, 2>(g, total, max_blocks, stream)
-                        : launch_grouped<64, true, true, 1, 2>(g, total, max_blocks, stream);
+    if (!ta) return BMsel == 128 ? launch_grouped<128, false, false, 1, 1>(g, total, max_blocks, workers, stream)
+                                 : launch_grouped<64, false, false, 1, 1>(g, total, max_blocks, workers, stream);
+    return BMsel == 128 ? launch_grouped<128, true, true, 1, 2>(g, total, max_blocks, workers, stream)
+                        : launch_grouped<64, true, true, 1, 2>(g, total, max_blocks, workers, stream);
   }
   if (BMsel == 128) {
-    if (kfull && PH_RING128 > 1 && !ta) return launch_grouped_layout<128, PH_RING128>(g, total, max_blocks, ta, tb, stream);
-    return launch_grouped_layout<128, 1>(g, total, max_blocks, ta, tb, stream);
+    if (kfull && PH_RING128 > 1 && !ta) return launch_grouped_layout<128, PH_RING128>(g, total, max_blocks, workers, ta, tb, stream);
+    return launch_grouped_layout<128, 1>(g, total, max_blocks, workers, ta, tb, stream);
   }
-  if (kfull && PH_RING64 > 1) return launch_grouped_layout<64, PH_RING64>(g, total, max_blocks, ta, tb, stream);
-  return launch_grouped_layout<64, 1>(g, total, max_blocks, ta, tb, stream);
+  if (kfull && PH_RING64 > 1) return launch_grouped_layout<64, PH_RING64>(g, total, max_blocks, workers, ta, tb, stream);
+  return launch_grouped_layout<64, 1>(g, total, max_blocks, workers, ta, tb, stream);
 }
 
 extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
@@ -1034,26 +1278,46 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
 
   // ---- big-tile LDS-DMA kernel: forward-shaped (both operands K-contiguous) GEMMs with enough 256x128 tiles for the chip ----
   {
-    // g_big_mode (PH_GEMM_BIG / ph_gemm_tuning): 0 = off, 1 = on, 2 = + s_setprio around the MFMA clusters, 3 = fragment
-    // double buffer, 4 = both
-    if (g_big_mode < 0) { const char* e = getenv("PH_GEMM_BIG"); g_big_mode = e ? atoi(e) : 1; }
+    // g_big_mode (PH_GEMM_BIG / ph_gemm_tuning): 0 = off, 1 = plain main loop (round-2 first version), 5 = ping-pong main loop (the
+    // two waves of a SIMD alternate read and MFMA phases; default), 6 = ping-pong + s_setprio around the MFMA phase
+    if (g_big_mode < 0) { const char* e = getenv("PH_GEMM_BIG"); g_big_mode = e ? atoi(e) : 5; }
     if (g_big_min_tiles < 0) { const char* e = getenv("PH_GEMM_BIG_MIN_TILES"); g_big_min_tiles = e ? atoi(e) : 160; }
     const int big_mode = g_big_mode, big_min_tiles = g_big_min_tiles;
     const int64_t tb = (int64_t)ceil_div(a->M, big::BM) * ceil_div(a->N, big::BN);
-    if (big_mode > 0 && !a->conv && !a->col_stats && !a->trans_a && !a->trans_b && (a->K % BK) == 0 && a->K >= 2 * BK && a->split_k <= 0 && a->M >= big::BM &&
-        (a->N % 8) == 0 && tb >= big_min_tiles && (a->N <= 1024 || a->K >= 2048 || big_min_tiles <= 1)) {
-      // (measured per shape, tools/big_probe.py: the 1-block-per-CU kernel wins where a launch is one round of tiles (N = 768) or
-      //  the k loop is long (K >= 2048); wide-N, K = 768 launches keep the 2-blocks-per-CU 128x128 kernel, whose co-resident
-      //  blocks overlap one tile's epilogue with the other's main loop)
+    static int wide = -1;             // PH_GEMM_BIG_WIDE=1: also the wide-N, short-K launches (in the step they do not gain, see below)
+    if (wide < 0) { const char* e = getenv("PH_GEMM_BIG_WIDE"); wide = e ? atoi(e) : 0; }
+    static int tb_ok = -1;            // PH_GEMM_BIG_TB=0: keep the [K][N]-B (dgrad-shaped) problems on the 128x128 kernel
+    if (tb_ok < 0) { const char* e = getenv("PH_GEMM_BIG_TB"); tb_ok = e ? atoi(e) : 1; }
+    if (big_mode > 0 && !a->conv && !a->col_stats && !a->trans_a && (!a->trans_b || tb_ok) && (a->K % BK) == 0 && a->K >= 2 * BK && a->split_k <= 0 && a->M >= big::BM &&
+        (a->N % 8) == 0 && a->N >= 8 && tb >= big_min_tiles && (wide || a->N <= 1024 || a->K >= 2048 || big_min_tiles <= 1)) {
+      // Forward-shaped (B = [N][K]) and dgrad-shaped (B = [K][N], trans_b) problems alike.  Isolated (tools/big_probe.py,
+      // profiles/r2_ab_big_tile_gemm.txt) the ping-pong kernel beats the 128x128 register-staged kernel on every shape of the
+      // step; inside the step (rocprofv3 per-grid durations, profiles/r2_gemm_by_grid.txt) only the launches with N <= 1024 or a
+      // long k loop keep the gain -- the wide-N, K = 768 launches are write-out bound there and the 2-blocks-per-CU kernel overlaps
+      // one tile's write-out with the other's main loop -- so those stay on the 128x128 kernel.
       p.tiles_m = ceil_div(a->M, big::BM); p.tiles_n = ceil_div(a->N, big::BN);
       p.k_tiles_per_split = a->K / BK;
       p.ws = nullptr; p.ldws = 0;
-      switch (big_mode) {
-        case 2: return big::launch<1>(p, stream);
-        case 3: return big::launch<2>(p, stream);
-        case 4: return big::launch<3>(p, stream);
-        default: return big::launch<0>(p, stream);
+      if (a->trans_b) {
+        switch (big_mode) {
+          case 1: return big::launch<0, false, true>(p, stream);
+          case 6: return big::launch<5, false, true>(p, stream);
+          default: return big::launch<4, false, true>(p, stream);
+        }
       }
+      switch (big_mode) {
+        case 1: return big::launch<0, false, false>(p, stream);
+        case 6: return big::launch<5, false, false>(p, stream);
+        default: return big::launch<4, false, false>(p, stream);
+      }
+    }
+    // weight-gradient layout (A = [K][M], B = [K][N]) with a long reduction: same kernel, both operands through the transposing reads
+    if (big_mode > 0 && !a->conv && !a->col_stats && a->trans_a && a->trans_b && tb_ok && (a->K % BK) == 0 && a->K >= 32 * BK && a->split_k <= 0 &&
+        a->M >= big::BM && (a->M % 8) == 0 && (a->N % 8) == 0 && a->N >= 8 && tb >= 64) {
+      p.tiles_m = ceil_div(a->M, big::BM); p.tiles_n = ceil_div(a->N, big::BN);
+      p.k_tiles_per_split = a->K / BK;
+      p.ws = nullptr; p.ldws = 0;
+      return big::launch<4, true, true>(p, stream);
     }
   }
 

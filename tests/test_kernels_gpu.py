@@ -4,6 +4,7 @@ Tolerances: bf16 outputs carry one rounding (2^-9 relative) on top of fp32-accum
 import math
 
 import numpy as np
+import os
 import pytest
 import torch
 import torch.nn.functional as F
@@ -154,27 +155,117 @@ def test_gemm_grouped_capped_background_launch(ops):
             assert rel_fro(gw, ref) < 3e-4, cap
 
 
+@pytest.mark.parametrize('trans_b', [False, True])
+@pytest.mark.parametrize('mode', [1, 5, 6])
 @pytest.mark.parametrize('M,N,K,act', [(1000, 776, 640, 1), (2048, 256, 128, 0), (515, 1536, 3072, 3)])
-def test_gemm_big_tile_lds_dma_kernel(ops, M, N, K, act):
-    """the 256x128 LDS-DMA kernel (global_load_lds into a 3-stage ring, counted vmcnt, raw barriers), forced for shapes it would
-    not normally take: ragged M / N tails, short and long k loops, the full fused epilogue -- against fp32 torch and against the
-    128x128 register-staged kernel on the same inputs."""
+def test_gemm_big_tile_lds_dma_kernel(ops, M, N, K, act, mode, trans_b):
+    """the 256x128 LDS-DMA kernel (global_load_lds into a 3-stage ring, counted vmcnt, raw barriers; mode 1 = plain main loop, 5 =
+    ping-pong phases of the two waves of a SIMD, 6 = + s_setprio), forced for shapes it would not normally take: ragged M / N
+    tails, short and long k loops, the full fused epilogue, B given as [N,K] and as [K,N] -- against fp32 torch and against the
+    128x128 register-staged kernel on the same inputs; repeated, because a mis-ordered DMA ring shows up as a rare wrong tile."""
     from prismer_amd import _lib
     a, b = rnd(M, K, scale=0.5, seed=3), rnd(N, K, scale=0.2, seed=4)
+    bb = b.t().contiguous() if trans_b else b
     bias = rnd(N, dtype=torch.float32, seed=5)
     res = rnd(M, N, seed=6)
     pre_big = torch.empty(M, N, dtype=BF, device='cuda'); pre_old = torch.empty_like(pre_big)
     try:
-        _lib.lib.ph_gemm_tuning(1, 1)
-        big = ops.gemm(a, b, bias=bias, act=act, pre_out=pre_big, residual=res)
         _lib.lib.ph_gemm_tuning(0, 160)
-        old = ops.gemm(a, b, bias=bias, act=act, pre_out=pre_old, residual=res)
+        old = ops.gemm(a, bb, trans_b=trans_b, bias=bias, act=act, pre_out=pre_old, residual=res)
+        _lib.lib.ph_gemm_tuning(mode, 1)
+        z = a.float() @ b.float().t() + bias
+        fn = {0: lambda t: t, 1: lambda t: t * torch.sigmoid(1.702 * t), 3: lambda t: F.gelu(t)}[act]
+        for rep in range(6):
+            pre_big.zero_()
+            big = ops.gemm(a, bb, trans_b=trans_b, bias=bias, act=act, pre_out=pre_big, residual=res)
+            assert rel_fro(pre_big, z) < 6e-3 and rel_fro(big, fn(z) + res.float()) < 6e-3, rep
+            assert rel_fro(big, old.float()) < 2e-3 and rel_fro(pre_big, pre_old.float()) < 2e-3, rep
     finally:
-        _lib.lib.ph_gemm_tuning(1, 160)
-    z = a.float() @ b.float().t() + bias
-    fn = {0: lambda t: t, 1: lambda t: t * torch.sigmoid(1.702 * t), 3: lambda t: F.gelu(t)}[act]
-    assert rel_fro(pre_big, z) < 6e-3 and rel_fro(big, fn(z) + res.float()) < 6e-3
-    assert rel_fro(big, old.float()) < 2e-3 and rel_fro(pre_big, pre_old.float()) < 2e-3
+        _lib.lib.ph_gemm_tuning(5, 160)
+
+
+@pytest.mark.parametrize('shapes', [
+    [(1536, 768, 4096)] * 4,                         # 144 tiles of 256x128, 64 k-tiles: the resampler K/V weight-gradient pattern
+    [(1544, 776, 2048)] * 4,                         # ragged M / N edges
+    [(768, 384, 8320)] * 16,                         # 16 adaptor weight gradients
+])
+def test_gemm_grouped_big_tile_wgrad(shapes, ops):
+    """weight-gradient groups with long reductions run on the 256x128 ping-pong kernel (A = [K,M] and B = [K,N] both through the
+    LDS-DMA ring and the transposing fragment reads; persistent one-block-per-CU grid): dW += dY^T X against fp32 torch and against
+    the 128x128 grouped kernel (capped entry point with a huge cap), on a non-zero accumulator, repeated."""
+    from prismer_amd import _lib
+    ops_, refs = [], []
+    for i, (M, N, K) in enumerate(shapes):
+        dy, x = rnd(K, M, scale=0.3, seed=20 + i), rnd(K, N, scale=0.3, seed=40 + i)
+        ops_.append((dy, x, torch.empty(M, N, device='cuda')))
+        refs.append(dy.float().t() @ x.float())
+    c0 = [torch.randn_like(o[2]) for o in ops_]
+    arr = (_lib.GemmArgs * len(shapes))()
+    for g, (dy, x, gw) in zip(arr, ops_):
+        g.A, g.B, g.C = dy.data_ptr(), x.data_ptr(), gw.data_ptr()
+        g.M, g.N, g.K = gw.shape[0], gw.shape[1], dy.shape[0]
+        g.lda, g.ldb, g.ldc = dy.stride(0), x.stride(0), gw.stride(0)
+        g.trans_a, g.trans_b, g.out_f32, g.accumulate, g.alpha = 1, 1, 1, 1, 1.0
+    results = []
+    for cap, reps in ((0, 4), (1 << 30, 1)):
+        for rep in range(reps):
+            for (dy, x, gw), c in zip(ops_, c0):
+                gw.copy_(c)
+            _lib.check(_lib.lib.ph_gemm_grouped_capped_bf16(arr, len(shapes), cap, torch.cuda.current_stream().cuda_stream), 'grouped')
+            for (dy, x, gw), ref, c in zip(ops_, refs, c0):
+                assert rel_fro(gw - c, ref) < 3e-4, (cap, rep, rel_fro(gw - c, ref))
+        results.append([o[2].clone() for o in ops_])
+    for x, y in zip(*results):
+        assert rel_fro(x, y) < 1e-5
+    # single-problem entry point, same layout
+    dy, x, gw = ops_[0]
+    gw.copy_(c0[0])
+    ops.gemm(dy, x, out=gw, trans_a=True, trans_b=True, out_f32=True, accumulate=True)
+    assert rel_fro(gw - c0[0], refs[0]) < 3e-4
+
+
+@pytest.mark.parametrize('shapes,ta', [
+    ([(1536, 768, 9920)] * 2, True),                 # 144 tiles x 155 k-tiles: under-filled first round (the resampler K/V weight gradients)
+    ([(768, 768, 4160)] * 16 + [], True),            # 576 tiles: 1.125 rounds
+    ([(384, 768, 2048), (768, 384, 2048), (104, 200, 2048)] * 2, True),     # 64x64 tiles, ragged
+    ([(1536, 768, 1024)] * 8, False),                # NN layout (A = [M,K], B = [K,N])
+])
+def test_gemm_grouped_streamk(shapes, ta, ops):
+    """stream-K form of the grouped launch (plain fp32-accumulate groups that do not fill whole block rounds): workers take equal
+    slices of the (tile, k-tile) iteration space, shared tiles are combined with fp32 atomics -- same sums as the tile-per-block
+    launch (PH tile path forced through the capped entry point with a huge cap) and as fp32 torch, on top of a non-zero accumulator."""
+    from prismer_amd import _lib
+    if os.environ.get('PH_GEMM_STREAMK', '0') == '0':
+        pytest.skip('stream-K grouped launches are off by default (PH_GEMM_STREAMK=1 PH_GEMM_BIG_GROUPED=0 enables the path)')
+    shapes = shapes[:_lib.GEMM_GROUP_MAX]
+    ops_, refs = [], []
+    for i, (M, N, K) in enumerate(shapes):
+        if ta:
+            a_, b_ = rnd(K, M, scale=0.3, seed=20 + i), rnd(K, N, scale=0.3, seed=40 + i)
+            refs.append(a_.float().t() @ b_.float())
+        else:
+            a_, b_ = rnd(M, K, scale=0.3, seed=20 + i), rnd(K, N, scale=0.3, seed=40 + i)
+            refs.append(a_.float() @ b_.float())
+        ops_.append((a_, b_, torch.empty(M, N, device='cuda')))
+    c0 = [torch.randn_like(o[2]) for o in ops_]
+    results = []
+    for cap in (0, 1 << 30):                         # 0: default policy (stream-K for these groups); huge cap: one block per tile
+        arr = (_lib.GemmArgs * len(shapes))()
+        for g, (a_, b_, gw), c in zip(arr, ops_, c0):
+            gw.copy_(c)
+            g.A, g.B, g.C = a_.data_ptr(), b_.data_ptr(), gw.data_ptr()
+            g.M, g.N, g.K = gw.shape[0], gw.shape[1], a_.shape[0] if ta else a_.shape[1]
+            g.lda, g.ldb, g.ldc = a_.stride(0), b_.stride(0), gw.stride(0)
+            g.trans_a, g.trans_b, g.out_f32, g.accumulate, g.alpha = int(ta), 1, 1, 1, 1.0
+        for rep in range(3 if cap == 0 else 1):
+            for (a_, b_, gw), c in zip(ops_, c0):
+                gw.copy_(c)
+            _lib.check(_lib.lib.ph_gemm_grouped_capped_bf16(arr, len(shapes), cap, torch.cuda.current_stream().cuda_stream), 'grouped')
+            for (a_, b_, gw), ref, c in zip(ops_, refs, c0):
+                assert rel_fro(gw - c, ref) < 3e-4, (cap, rep, rel_fro(gw - c, ref))
+        results.append([o[2].clone() for o in ops_])
+    for x, y in zip(*results):
+        assert rel_fro(x, y) < 1e-5
 
 
 def test_gemm_f32_accumulate_splitk(ops):

@@ -10,7 +10,8 @@ from prismer_amd import _lib, ops
 from prismer_amd._lib import ACT_QUICKGELU, ACT_RELU2
 
 BF = torch.bfloat16
-MODES = [int(m) for m in os.environ.get('BIG_MODES', '0,1,2,3,4').split(',')]
+MODES = [int(m) for m in os.environ.get('BIG_MODES', '0,1,5').split(',')]
+REPLAYS = int(os.environ.get('BIG_REPLAYS', '3'))      # graph replays per timing sample (10 launches each): raise for sustained-load numbers
 
 
 def graph_of(fn, n):
@@ -28,10 +29,18 @@ def graph_of(fn, n):
     return g
 
 
-def case(name, M, N, K, bias=True, act=0, pre=False, residual=False, f32res=False, out_f32=False, n=10, rounds=4):
+def case(name, M, N, K, bias=True, act=0, pre=False, residual=False, f32res=False, out_f32=False, n=10, rounds=4, tb=False, act_in=False):
     a = (torch.randn(M, K, device='cuda') * 0.5).to(BF)
     b = (torch.randn(N, K, device='cuda') * 0.05).to(BF)
     kw = {}
+    bt = b.t().contiguous() if tb else None          # [K, N]: the dgrad layout (dy . W with W = [N_out, K_in])
+    if tb:
+        kw['trans_b'] = True
+    g_in = None
+    if act_in:
+        g_in = torch.randn(M, N, device='cuda').to(BF)
+        kw['act_in'] = g_in
+        kw['act'] = _lib.ACT_SAVED_GRAD
     if bias:
         kw['bias'] = torch.randn(N, device='cuda') * 0.1
     if act:
@@ -51,28 +60,32 @@ def case(name, M, N, K, bias=True, act=0, pre=False, residual=False, f32res=Fals
         z = z * torch.sigmoid(1.702 * z)
     elif act == ACT_RELU2:
         z = torch.relu(z) ** 2
+    if act_in:
+        z = z * g_in.float()
     if residual:
         z = z + kw['residual'].float()
     graphs, errs = [], []
+    bb = bt if tb else b
     for m in MODES:
         _lib.lib.ph_gemm_tuning(m, 1)
         out.zero_()
-        ops.gemm(a, b, out=out, out_f32=out_f32, **kw)
+        ops.gemm(a, bb, out=out, out_f32=out_f32, **kw)
         torch.cuda.synchronize()
         e = ((out.float() - z).norm() / z.norm()).item()
         if pre:
             e = max(e, ((pre_t.float() - zp).norm() / zp.norm()).item())
         errs.append(e)
-        graphs.append(graph_of(lambda: ops.gemm(a, b, out=out, out_f32=out_f32, **kw), n))
+        graphs.append(graph_of(lambda: ops.gemm(a, bb, out=out, out_f32=out_f32, **kw), n))
     best = [1e30] * len(MODES)
     for _ in range(rounds):
         for i, g in enumerate(graphs):
             t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0.record()
-            for _ in range(3):
+            for _ in range(REPLAYS):
                 g.replay()
             t1.record(); torch.cuda.synchronize()
-            best[i] = min(best[i], t0.elapsed_time(t1) / (3 * n) * 1e3)
+            best[i] = min(best[i], t0.elapsed_time(t1) / (REPLAYS * n) * 1e3)
+            errs[i] = max(errs[i], ((out.float() - z).norm() / z.norm()).item())      # race screen: every replay batch is re-checked
     fl = 2.0 * M * N * K
     print(f'{name:30s} ' + ' | '.join(f'm{m}: {best[i]:6.1f}us {fl / best[i] / 1e6:5.0f}TF e={errs[i]:.1e}' for i, m in enumerate(MODES)), flush=True)
     assert all(e < 8e-3 for e in errs), errs
@@ -89,6 +102,12 @@ if __name__ == '__main__':
     case('cross kv all 8320x18432x768', 8320, 18432, 768)
     case('stem 25088x384x1728', 25088, 384, 1728, bias=False)
     case('stem 6272x768x3456', 6272, 768, 3456, bias=False)
+    case('dgrad proj 8320x3072x768 *g', 8320, 3072, 768, bias=False, tb=True, act_in=True)
+    case('dgrad 8320x768x768 tb', 8320, 768, 768, bias=False, tb=True)
+    case('dgrad fc 8320x768x3072 tb +res', 8320, 768, 3072, bias=False, tb=True, residual=True)
+    case('dgrad qkv 8320x768x2304 tb', 8320, 768, 2304, bias=False, tb=True)
+    case('dgrad kv 39680x768x1536 tb', 39680, 768, 1536, bias=False, tb=True)
     case('ragged 8300x2312x704', 8300, 2312, 704, act=ACT_RELU2, pre=True, residual=True)
+    case('ragged tb 8300x2312x704', 8300, 2312, 704, act=ACT_RELU2, pre=True, residual=True, tb=True)
     case('f32 out/res 4160x1536x768', 4160, 1536, 768, residual=True, f32res=True, out_f32=True)
     _lib.lib.ph_gemm_tuning(1, 160)

@@ -22,11 +22,22 @@ def short(n):
     return n[:90]
 
 
-def durations(db, steps, window_ms):
+def step_window(cur, steps, marker='ce_fwd_kernel'):
+    """[t0, t1) covering exactly `steps` whole steps at the END of the trace: the marker kernel (one launch per step) delimits
+    steps, so launches/step are integers for graph replays whatever the step time was on that box."""
+    starts = [r[0] for r in cur.execute(f"select start from kernels where name like '%{marker}%' order by start")]
+    if len(starts) < steps + 1:
+        raise SystemExit(f'{marker}: only {len(starts)} launches in the trace, need {steps + 1}')
+    return starts[-1 - steps], starts[-1]
+
+
+def durations(db, steps, window_ms=None):
     cur = sqlite3.connect(db).cursor()
-    tmax = list(cur.execute('select max(end) from kernels'))[0][0]
-    rows = cur.execute(f'select name, count(*), sum(end-start) from kernels where start >= {tmax - int(window_ms * 1e6)} group by name')
-    return {short(n): (c / steps, t / steps / 1e3) for n, c, t in rows}          # launches/step, us/step
+    t0, t1 = step_window(cur, int(steps))
+    rows = cur.execute(f'select name, count(*), sum(end-start) from kernels where start >= {t0} and start < {t1} group by name')
+    out = {short(n): (c / steps, t / steps / 1e3) for n, c, t in rows}          # launches/step, us/step
+    out['__wall_ms_per_step__'] = (0, (t1 - t0) / steps / 1e6)
+    return out
 
 
 def counter(db, name, steps):
@@ -54,6 +65,7 @@ def main():
     kt, steps, window = sys.argv[1], float(sys.argv[2]), float(sys.argv[3])
     fdb, wdb, mdb, psteps, out = sys.argv[4], sys.argv[5], sys.argv[6], float(sys.argv[7]), sys.argv[8]
     dur = durations(kt, steps, window)
+    wall_ms = dur.pop('__wall_ms_per_step__')[1]
     fetch, write = counter(fdb, 'FETCH_SIZE', psteps), counter(wdb, 'WRITE_SIZE', psteps)
     busy, gui = counter(mdb, 'SQ_VALU_MFMA_BUSY_CYCLES', psteps), counter(mdb, 'GRBM_GUI_ACTIVE', psteps)
     rows = []
@@ -68,7 +80,7 @@ def main():
                          mfma_busy_over_gui_active=round(busy.get(k, (0, 0))[0] / max(gui.get(k, (1, 0))[0], 1), 3)))
     rows.sort(key=lambda r: -r['us_per_step'])
     tot_us = sum(r['us_per_step'] for r in rows)
-    tot = dict(kernel_us_per_step=round(tot_us, 1), launches_per_step=round(sum(r['launches_per_step'] for r in rows), 1),
+    tot = dict(wall_ms_per_step=round(wall_ms, 3), kernel_us_per_step=round(tot_us, 1), launches_per_step=round(sum(r['launches_per_step'] for r in rows), 1),
                hbm_gb_per_step=round(sum(r['hbm_gb_per_step'] for r in rows), 2),
                mfma_tflop_per_step=round(sum(r['mfma_tflop_per_step'] for r in rows), 3))
     gemm = [r for r in rows if re.search(r'gemm_(grouped_|big_)?kernel', r['kernel'])]
@@ -78,7 +90,7 @@ def main():
                        mfma_tflop_per_step=round(sum(r['mfma_tflop_per_step'] for r in gemm), 3))
     json.dump(dict(totals=tot, kernels=rows), open(out + '_kernel_table.json', 'w'), indent=1)
     with open(out + '_kernel_table.txt', 'w') as f:
-        f.write(f'per step: {tot_us / 1e3:.2f} ms of kernel time, {tot["launches_per_step"]:.0f} launches, HBM-side traffic {tot["hbm_gb_per_step"]:.1f} GB '
+        f.write(f'per step ({int(steps)} whole steps, {wall_ms:.2f} ms wall each): {tot_us / 1e3:.2f} ms of kernel time, {tot["launches_per_step"]:.0f} launches, HBM-side traffic {tot["hbm_gb_per_step"]:.1f} GB '
                 f'(2 x FETCH_SIZE + WRITE_SIZE), {tot["mfma_tflop_per_step"]:.2f} TFLOP on the matrix cores (SQ_VALU_MFMA_BUSY_CYCLES x 1024)\n')
         f.write(f'{"kernel":70s} {"n/step":>7s} {"avg us":>8s} {"ms/step":>8s} {"TB/s":>6s} {"TF/s":>7s} {"MFMA util":>9s}\n')
         for r in rows[:40]:
