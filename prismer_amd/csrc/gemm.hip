@@ -1200,13 +1200,13 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
       tbig += ceil_div(a.M, big::BM) * ceil_div(a.N, big::BN);
       kt_min = min(kt_min, a.K / BK); kt_big = max(kt_big, a.K / BK);
     }
-    if (ok && kt_min >= 32) {
+    if (ok && kt_min >= (big_grp == 2 ? 8 : 32)) {        // (PH_GEMM_BIG_GROUPED=2: experiments -- every eligible group with K >= 512, no cost comparison)
       // rounds x (k loop + fixed part) of either kernel, constants from the per-shape fits: 0.67 us per k-tile for the
       // one-per-CU 256x128 block, 0.84 us per k-tile and pair of co-resident 128x128 blocks (0.5 us for a lone one)
       const double cost_big = ceil(tbig / 256.0) * (kt_big * 0.67 + 14.0);
       const int t128 = total;           // (tiles of the BMsel grid computed above; BMsel is 128 for these groups)
       const double cost_128 = BMsel == 128 ? (t128 <= 256 ? kt_big * 0.5 + 10.0 : ceil(t128 / 512.0) * (kt_big * 0.84 + 10.0)) : 1e30;
-      if (cost_big < cost_128) {
+      if (cost_big < cost_128 || big_grp == 2) {
         int tot = 0;
         for (int i = 0; i < n; ++i) {
           g.p[i].tiles_m = ceil_div(args[i].M, big::BM); g.p[i].tiles_n = ceil_div(args[i].N, big::BN);

@@ -48,7 +48,8 @@ def case(name, M, N, K, bias=True, act=0, pre=False, residual=False, f32res=Fals
     if residual:
         kw['residual'] = torch.randn(M, N, device='cuda').to(torch.float32 if f32res else BF)
     out = torch.empty(M, N, dtype=torch.float32 if out_f32 else BF, device='cuda')
-    pre_t = torch.empty(M, N, dtype=BF, device='cuda') if pre else None
+    off = int(os.environ.get('BIG_PRE_OFFSET', '0'))      # elements: shifts the second output's base relative to the first (channel-aliasing test)
+    pre_t = torch.empty(M * N + off, dtype=BF, device='cuda')[off:].view(M, N) if pre else None
     if pre:
         kw['pre_out'] = pre_t
     # reference on a row sample (full fp32 matmul of 8320x3072x768 is fine on the GPU)
@@ -93,6 +94,10 @@ def case(name, M, N, K, bias=True, act=0, pre=False, residual=False, f32res=Fals
 
 if __name__ == '__main__':
     torch.manual_seed(0)
+    if os.environ.get('BIG_ONLY_FC'):
+        case('vit fc 8320x3072x768 qgelu+pre', 8320, 3072, 768, act=ACT_QUICKGELU, pre=True)
+        case('vit fc 8320x3072x768 qgelu (one output)', 8320, 3072, 768, act=ACT_QUICKGELU)
+        sys.exit(0)
     case('plain 8192x4096x4096', 8192, 4096, 4096, bias=False)
     case('vit qkv 8320x2304x768', 8320, 2304, 768)
     case('vit out 8320x768x768 +res', 8320, 768, 768, residual=True)

@@ -45,7 +45,7 @@ def per_kernel(rows, pat):
 
 def main():
     fdb, wdb, steps = sys.argv[1], sys.argv[2], float(sys.argv[3])
-    pat = r'gemm_(grouped_|big_)?kernel'
+    pat = r'gemm_(grouped_|big_|big_grouped_|streamk_)?kernel'
     fv, frows = find_rows(fdb, 'FETCH_SIZE')
     wv, wrows = find_rows(wdb, 'WRITE_SIZE')
     f_kb, f_n, f_all = per_kernel(frows, pat)

@@ -83,7 +83,7 @@ def main():
     tot = dict(wall_ms_per_step=round(wall_ms, 3), kernel_us_per_step=round(tot_us, 1), launches_per_step=round(sum(r['launches_per_step'] for r in rows), 1),
                hbm_gb_per_step=round(sum(r['hbm_gb_per_step'] for r in rows), 2),
                mfma_tflop_per_step=round(sum(r['mfma_tflop_per_step'] for r in rows), 3))
-    gemm = [r for r in rows if re.search(r'gemm_(grouped_|big_)?kernel', r['kernel'])]
+    gemm = [r for r in rows if re.search(r'gemm_(grouped_|big_|big_grouped_|streamk_)?kernel', r['kernel'])]
     gl = sum(r['launches_per_step'] for r in gemm)
     tot['gemm'] = dict(us_per_step=round(sum(r['us_per_step'] for r in gemm), 1), launches_per_step=round(gl, 1),
                        hbm_bytes_per_launch=round(sum(r['hbm_gb_per_step'] for r in gemm) * 1e9 / max(gl, 1)),

@@ -1,5 +1,6 @@
 #!/bin/bash
-out=gpurun_out/r2_run21; mkdir -p $out
+# end-of-round verification on the GPU box: full -m gpu suite, smoke, the profile set (tools/profile_round.sh) and the secondary bench lines
+out=gpurun_out/r2_check; mkdir -p $out
 export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -q --timeout=900 --durations=5 > $out/pytest.log 2>&1; echo "pytest rc=$?" >> $out/pytest.log
 grep -E "^(FAILED|ERROR)|passed|failed|^E  " $out/pytest.log | tail -10
