@@ -83,10 +83,10 @@ struct GemmParams {
 // which the deep prefetch ring depends on).
 template <int R, bool KFULL = false>
 __device__ __forceinline__ void load_kc(const bf16* __restrict__ base, int ld, int row0, int rows, int k0, int K,
-                                        u32x4 (&regs)[R * 8 / 256]) {
+                                        u32x4 (&regs)[R * 8 / 256], const int tid) {
 #pragma unroll
   for (int i = 0; i < R * 8 / 256; ++i) {
-    int id = threadIdx.x + 256 * i;
+    int id = tid + 256 * i;
     int r = id >> 3, c = id & 7;
     int row = row0 + r;
     row = row < rows ? row : rows - 1;          // clamp: out-of-range rows only feed out-of-range outputs
@@ -101,10 +101,10 @@ __device__ __forceinline__ void load_kc(const bf16* __restrict__ base, int ld, i
   }
 }
 template <int R>
-__device__ __forceinline__ void store_kc(char* lds, const u32x4 (&regs)[R * 8 / 256]) {
+__device__ __forceinline__ void store_kc(char* lds, const u32x4 (&regs)[R * 8 / 256], const int tid) {
 #pragma unroll
   for (int i = 0; i < R * 8 / 256; ++i) {
-    int id = threadIdx.x + 256 * i;
+    int id = tid + 256 * i;
     int r = id >> 3, c = id & 7;
     int cs = c ^ ((r >> 1) & 7);
     *reinterpret_cast<u32x4*>(lds + r * KC_ROW_BYTES + cs * 16) = regs[i];
@@ -113,11 +113,11 @@ __device__ __forceinline__ void store_kc(char* lds, const u32x4 (&regs)[R * 8 / 
 // K-strided operand: memory [K][rows] (rows contiguous). tile = 64 k-rows x R. chunk id -> (kr = id/(R/8), c = id%(R/8)).
 template <int R, bool KFULL = false>
 __device__ __forceinline__ void load_ks(const bf16* __restrict__ base, int ld, int row0, int rows, int k0, int K,
-                                        u32x4 (&regs)[R * 8 / 256]) {
+                                        u32x4 (&regs)[R * 8 / 256], const int tid) {
   constexpr int CPR = R / 8;
 #pragma unroll
   for (int i = 0; i < R * 8 / 256; ++i) {
-    int id = threadIdx.x + 256 * i;
+    int id = tid + 256 * i;
     int kr = id / CPR, c = id % CPR;
     int k = k0 + kr;
     int r = row0 + c * 8;
@@ -132,11 +132,11 @@ __device__ __forceinline__ void load_ks(const bf16* __restrict__ base, int ld, i
   }
 }
 template <int R>
-__device__ __forceinline__ void store_ks(char* lds, const u32x4 (&regs)[R * 8 / 256]) {
+__device__ __forceinline__ void store_ks(char* lds, const u32x4 (&regs)[R * 8 / 256], const int tid) {
   constexpr int CPR = R / 8;
 #pragma unroll
   for (int i = 0; i < R * 8 / 256; ++i) {
-    int id = threadIdx.x + 256 * i;
+    int id = tid + 256 * i;
     int kr = id / CPR, c = id % CPR;
     *reinterpret_cast<u32x4*>(lds + kr * TileBytes<R>::ks_stride + c * 16) = regs[i];
   }
@@ -420,7 +420,7 @@ __device__ __forceinline__ void epi_apply8(const GemmParams& p, int m, int n, fl
 // consecutive 16/32-B pieces of one output row for every load / store of the fused epilogue chain.
 template <int BM, int BN, int NTHR>
 __device__ __forceinline__ void tile_writeout(const GemmParams& p, const float* cl, int m0, int n0, bool splitk, bool drop,
-                                              const DropCtx& dc) {
+                                              const DropCtx& dc, const float* cl2 = nullptr) {   // cl2: second partial tile to add (KS = 2)
   constexpr int CH = BN / 4;                       // 16-B chunks per tile row
   // fast path: 8 outputs per thread per step (16-B loads/stores) when every leading dimension / pointer allows it
   const bool vec8 = !(splitk) && p.N >= 8 && (p.ldc % 8) == 0 && (!p.act_in || (p.ld_act % 8) == 0) && (!p.residual || (p.ldr % 8) == 0) &&
@@ -448,6 +448,10 @@ __device__ __forceinline__ void tile_writeout(const GemmParams& p, const float* 
         const int sw = ml & (CH - 1);
         f32x4 t0 = *reinterpret_cast<const f32x4*>(cl + ml * BN + ((c ^ sw) << 2));
         f32x4 t1 = *reinterpret_cast<const f32x4*>(cl + ml * BN + (((c + 1) ^ sw) << 2));
+        if (cl2) {
+          t0 += *reinterpret_cast<const f32x4*>(cl2 + ml * BN + ((c ^ sw) << 2));
+          t1 += *reinterpret_cast<const f32x4*>(cl2 + ml * BN + (((c + 1) ^ sw) << 2));
+        }
         if (m < p.M && n + 8 <= p.N) {
           float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
 #ifdef PH_GEMM_DIAG_NOSTORE  // diagnostics build: staging + LDS reads, no HBM traffic from the epilogue
@@ -468,6 +472,7 @@ __device__ __forceinline__ void tile_writeout(const GemmParams& p, const float* 
       const int ml = id / CH, c = id % CH;
       const int m = m0 + ml, n = n0 + c * 4;
       f32x4 t = *reinterpret_cast<const f32x4*>(cl + ml * BN + ((c ^ (ml & (CH - 1))) << 2));
+      if (cl2) t += *reinterpret_cast<const f32x4*>(cl2 + ml * BN + ((c ^ (ml & (CH - 1))) << 2));
       float v[4] = {t[0], t[1], t[2], t[3]};
       if (m < p.M && n < p.N) epilogue_store(p, m, n, v, splitk, drop, dc);
     }
@@ -502,8 +507,13 @@ __device__ __forceinline__ void tile_colstats(const GemmParams& p, const float* 
 // One output tile over the k-tiles [kt_begin, kt_end).  XCD_REMAP: block_id is a hardware block index of a one-tile-per-block launch
 // (re-mapped so that each XCD owns a contiguous run of tiles); otherwise block_id already is the tile index.  splitk: the tile has
 // other contributors (raw partial sums: workspace slice blockIdx.z, or fp32 atomics into C when there is no workspace).
-template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0, bool XCD_REMAP = true>
+// KS = 2: intra-block split of the k loop (512 threads): thread group g = threadIdx.x >> 8 multiplies the k-tiles kt_begin + 2i + g
+// in its own pair of LDS stage buffers, the write-out sums the two partial tiles.  For the decoder's launches (M = B*T = 960 rows:
+// fewer tiles than CUs, so one block per CU and one wave per SIMD) the k loop is a latency chain -- LDS write, barrier, LDS read,
+// 4 MFMAs per wave -- and a second wave per SIMD working on the other half of K hides half of it.
+template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0, bool XCD_REMAP = true, int KS = 1>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int block_id, const int kt_begin, const int kt_end, const bool splitk) {
+  static_assert(KS == 1 || (KS == 2 && CONV == 0 && PF > 1), "intra-block k split: plain ring kernels only");
   static_assert(CONV == 0 || (CONV == 1 && !TA && !TB) || (CONV == 2 && TA && TB), "conv gather: A of an NN problem or B of a TT problem");
   constexpr int WM = BM / 2, WN = BN / 2;   // wave tile
   constexpr int TM = WM / 32, TN = WN / 32; // 32x32 MFMA tiles per wave
@@ -531,8 +541,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int block_i
   int m0 = tm * BM, n0 = tn * BN;
   if (kt_begin >= kt_end) return;
 
-  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tid = KS == 2 ? (int)(threadIdx.x & 255) : (int)threadIdx.x;
+  const int grp = KS == 2 ? (int)(threadIdx.x >> 8) : 0;
+  int lane = tid & 63, wave = tid >> 6;
   int wm = wave >> 1, wn = wave & 1;
+  char* const smem_g = smem + grp * 2 * STAGE;          // this thread group's two stage buffers
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -557,19 +570,19 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int block_i
     int k0 = kt * BK;
     constexpr bool KF = PF > 1;                 // ring kernels are only launched when K % BK == 0
     if constexpr (CONV == 1) load_kc_conv<BM>(p.cv, p.A, px, k0, xa);
-    else if (TA) load_ks<BM, KF>(p.A, p.lda, m0, p.M, k0, p.K, xa); else load_kc<BM, KF>(p.A, p.lda, m0, p.M, k0, p.K, xa);
+    else if (TA) load_ks<BM, KF>(p.A, p.lda, m0, p.M, k0, p.K, xa, tid); else load_kc<BM, KF>(p.A, p.lda, m0, p.M, k0, p.K, xa, tid);
     if constexpr (CONV == 2) load_ks_conv<BN>(p.cv, p.B, ct, k0, p.K, xb);
-    else if (TB) load_ks<BN, KF>(p.B, p.ldb, n0, p.N, k0, p.K, xb); else load_kc<BN, KF>(p.B, p.ldb, n0, p.N, k0, p.K, xb);
+    else if (TB) load_ks<BN, KF>(p.B, p.ldb, n0, p.N, k0, p.K, xb, tid); else load_kc<BN, KF>(p.B, p.ldb, n0, p.N, k0, p.K, xb, tid);
   };
   auto lstore = [&](int buf, const u32x4 (&xa)[BM * 8 / 256], const u32x4 (&xb)[BN * 8 / 256]) {
-    char* sa = smem + buf * STAGE;
+    char* sa = smem_g + buf * STAGE;
     char* sb = sa + A_BYTES;
-    if (TA) store_ks<BM>(sa, xa); else store_kc<BM>(sa, xa);
+    if (TA) store_ks<BM>(sa, xa, tid); else store_kc<BM>(sa, xa, tid);
     if constexpr (CONV == 2) store_ks_conv<BN>(sb, xb);
-    else if (TB) store_ks<BN>(sb, xb); else store_kc<BN>(sb, xb);
+    else if (TB) store_ks<BN>(sb, xb, tid); else store_kc<BN>(sb, xb, tid);
   };
   auto compute = [&](int buf) {
-    const char* la = smem + buf * STAGE;
+    const char* la = smem_g + buf * STAGE;
     const char* lb = la + A_BYTES;
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
@@ -612,8 +625,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int block_i
     // Ring of D register sets: the loads of tile i+1+D are issued in iteration i and written to LDS in iteration i+D, so a
     // load has D iterations to land (one is not enough when a CU holds a single block, i.e. every GEMM with few tiles).
     // Loads are unconditional (tile index clamped to the last one) and slots are compile-time constants.
-    const int nk = kt_end - kt_begin;
-    auto gl = [&](int i, u32x4 (&xa)[BM * 8 / 256], u32x4 (&xb)[BN * 8 / 256]) { gload(kt_begin + min(i, nk - 1), xa, xb); };
+    // (KS = 2: group g owns tiles kt_begin + 2i + g; nk = iterations of the block, nkg = tiles of this group -- one less for group 1
+    //  when the count is odd: it then runs its last iteration on a clamped reload without multiplying)
+    const int nkt = kt_end - kt_begin;
+    const int nk = (nkt + KS - 1) / KS, nkg = (nkt - grp + KS - 1) / KS;
+    auto gl = [&](int i, u32x4 (&xa)[BM * 8 / 256], u32x4 (&xb)[BN * 8 / 256]) { gload(kt_begin + KS * min(i, nkg - 1) + grp, xa, xb); };
     static_for(std::make_integer_sequence<int, D>{}, [&](auto dd) { gl(decltype(dd)::value, ra[decltype(dd)::value], rb[decltype(dd)::value]); });
     lstore(0, ra[0], rb[0]);
     gl(D, ra[0], rb[0]);
@@ -625,7 +641,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int block_i
         constexpr int d = decltype(dd)::value, slot = (d + 1) % D;
         lstore(cur ^ 1, ra[slot], rb[slot]);
         gl(i0 + d + 1 + D, ra[slot], rb[slot]);
-        compute(cur);
+        if (KS == 1 || i0 + d < nkg) compute(cur);
         __syncthreads();
         cur ^= 1;
       });
@@ -634,7 +650,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int block_i
       constexpr int d = decltype(dd)::value, slot = (d + 1) % D;
       if (i0 + d < nk) {
         lstore(cur ^ 1, ra[slot], rb[slot]);
-        compute(cur);
+        if (KS == 1 || i0 + d < nkg) compute(cur);
         __syncthreads();
         cur ^= 1;
       }
@@ -662,7 +678,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int block_i
   const bool drop = p.drop_p > 0.0f;
   if (drop) dc = make_drop(p.drop_seed, p.drop_stream, p.drop_p);
   constexpr int CH = BN / 4;                       // 16-B chunks per tile row
-  float* cl = reinterpret_cast<float*>(smem);
+  float* cl = reinterpret_cast<float*>(smem) + grp * (BM * BN);     // (KS = 2: one parking area per thread group, summed by the write-out)
   // (the main loop ended with a barrier: nobody reads the stage buffers any more)
   // acc[][] must only ever be indexed with compile-time constants (a runtime index demotes the accumulators to
   // scratch memory and the main loop then spills them every k-tile), so the tile loop is a static_for.
@@ -675,8 +691,13 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int block_i
     *reinterpret_cast<f32x4*>(cl + ml * BN + ((c ^ (ml & (CH - 1))) << 2)) = v;
   });
   __syncthreads();
-  tile_writeout<BM, BN, 256>(p, cl, m0, n0, splitk, drop, dc);
-  if (p.col_stats) tile_colstats<BM, BN, 256>(p, cl, m0, n0);
+  if constexpr (KS == 2) {
+    static_assert(2 * BM * BN * 4 <= 4 * STAGE, "two parked fp32 tiles must fit the four stage buffers");
+    tile_writeout<BM, BN, 512>(p, reinterpret_cast<float*>(smem), m0, n0, splitk, drop, dc, reinterpret_cast<float*>(smem) + BM * BN);
+  } else {
+    tile_writeout<BM, BN, 256>(p, cl, m0, n0, splitk, drop, dc);
+    if (p.col_stats) tile_colstats<BM, BN, 256>(p, cl, m0, n0);
+  }
 }
 
 template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0>
@@ -1025,6 +1046,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
 #endif
 #define PF_DEPTH(bm) ((bm) == 128 ? PH_RING128 : PH_RING64)
 
+// 512-thread form with the k loop split between two thread groups (gemm_tile KS = 2); 64x64 tiles, K % 64 == 0, no split-K
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512) void gemm_ks2_kernel(GemmParams p) {
+  gemm_tile<64, 64, TA, TB, PH_RING64, 0, true, 2>(p, blockIdx.x, 0, p.K / BK, false);
+}
+
+template <bool TA, bool TB>
+int launch_ks2(const GemmParams& p, hipStream_t s) {
+  constexpr int smem = 4 * ((TA ? TileBytes<64>::ks : TileBytes<64>::kc) + (TB ? TileBytes<64>::ks : TileBytes<64>::kc));
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ks2_kernel<TA, TB>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_ks2_kernel<TA, TB>), dim3(p.tiles_m * p.tiles_n), dim3(512), smem, s, p);
+  PH_LAUNCH_CHECK("gemm_ks2_kernel");
+  return PH_OK;
+}
+
 template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0>
 int launch_pf(const GemmParams& p, int splits, hipStream_t s) {
   constexpr int smem_min = 2 * ((TA ? TileBytes<BM>::ks : TileBytes<BM>::kc) + (TB ? TileBytes<BN>::ks : TileBytes<BN>::kc));
@@ -1281,15 +1321,28 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
     // g_big_mode (PH_GEMM_BIG / ph_gemm_tuning): 0 = off, 1 = plain main loop (round-2 first version), 5 = ping-pong main loop (the
     // two waves of a SIMD alternate read and MFMA phases; default), 6 = ping-pong + s_setprio around the MFMA phase
     if (g_big_mode < 0) { const char* e = getenv("PH_GEMM_BIG"); g_big_mode = e ? atoi(e) : 5; }
-    if (g_big_min_tiles < 0) { const char* e = getenv("PH_GEMM_BIG_MIN_TILES"); g_big_min_tiles = e ? atoi(e) : 160; }
+    if (g_big_min_tiles < 0) { const char* e = getenv("PH_GEMM_BIG_MIN_TILES"); g_big_min_tiles = e ? atoi(e) : 128; }
     const int big_mode = g_big_mode, big_min_tiles = g_big_min_tiles;
     const int64_t tb = (int64_t)ceil_div(a->M, big::BM) * ceil_div(a->N, big::BN);
     static int wide = -1;             // PH_GEMM_BIG_WIDE=1: also the wide-N, short-K launches (in the step they do not gain, see below)
     if (wide < 0) { const char* e = getenv("PH_GEMM_BIG_WIDE"); wide = e ? atoi(e) : 0; }
     static int tb_ok = -1;            // PH_GEMM_BIG_TB=0: keep the [K][N]-B (dgrad-shaped) problems on the 128x128 kernel
     if (tb_ok < 0) { const char* e = getenv("PH_GEMM_BIG_TB"); tb_ok = e ? atoi(e) : 1; }
+    // block rounds of either kernel (constants from the per-shape fits, us): a 256x128 block alone on its CU, a pair of co-resident
+    // 128x128 blocks, a lone 128x128 block (what the last, half-empty round of that kernel is made of -- the reason a tile count just
+    // above a multiple of 256 favours it: 41 x 8 tiles of 256x128 are two full rounds, 81 x 8 of 128x128 one pair round + one lone round)
+    bool big_cheaper = true;
+    if (big_min_tiles > 1) {
+      const double ktd = (double)(a->K / BK);
+      const int64_t t128b = (int64_t)ceil_div(a->M, 128) * ceil_div(a->N, 128), rem = t128b % 512;
+      const double cost_big = (double)ceil_div64(tb, 256) * (ktd * 0.67 + 12.0);
+      const double cost_128 = (double)(t128b / 512) * (ktd * 0.84 + 12.0) + (rem > 256 ? ktd * 0.84 + 12.0 : (rem > 0 ? ktd * 0.5 + 12.0 : 0.0));
+      big_cheaper = cost_big < cost_128 * (a->trans_b ? 1.0 : 1.02);      // ties (two full rounds vs pair + lone round): measured in favour of
+                                                                           // the big kernel for [N,K] B (stem 25088x384x1728), against it for [K,N] B (LARGE dgrads)
+    }
     if (big_mode > 0 && !a->conv && !a->col_stats && !a->trans_a && (!a->trans_b || tb_ok) && (a->K % BK) == 0 && a->K >= 2 * BK && a->split_k <= 0 && a->M >= big::BM &&
-        (a->N % 8) == 0 && a->N >= 8 && tb >= big_min_tiles && (wide || a->N <= 1024 || a->K >= 2048 || big_min_tiles <= 1)) {
+        (a->N % 8) == 0 && a->N >= 8 && tb >= big_min_tiles && (tb >= 192 || a->K >= 32 * BK || big_min_tiles <= 1) && big_cheaper &&
+        (wide || a->N <= 1024 || a->K >= 2048 || big_min_tiles <= 1)) {      // (short-K launches that fill < 3/4 of the CUs with one round: 128x128)
       // Forward-shaped (B = [N][K]) and dgrad-shaped (B = [K][N], trans_b) problems alike.  Isolated (tools/big_probe.py,
       // profiles/r2_ab_big_tile_gemm.txt) the ping-pong kernel beats the 128x128 register-staged kernel on every shape of the
       // step; inside the step (rocprofv3 per-grid durations, profiles/r2_gemm_by_grid.txt) only the launches with N <= 1024 or a
@@ -1313,7 +1366,7 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
     }
     // weight-gradient layout (A = [K][M], B = [K][N]) with a long reduction: same kernel, both operands through the transposing reads
     if (big_mode > 0 && !a->conv && !a->col_stats && a->trans_a && a->trans_b && tb_ok && (a->K % BK) == 0 && a->K >= 32 * BK && a->split_k <= 0 &&
-        a->M >= big::BM && (a->M % 8) == 0 && (a->N % 8) == 0 && a->N >= 8 && tb >= 64) {
+        a->M >= big::BM && (a->M % 8) == 0 && (a->N % 8) == 0 && a->N >= 8 && tb >= 64 && big_cheaper) {
       p.tiles_m = ceil_div(a->M, big::BM); p.tiles_n = ceil_div(a->N, big::BN);
       p.k_tiles_per_split = a->K / BK;
       p.ws = nullptr; p.ldws = 0;
@@ -1372,6 +1425,19 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
   if (splits > 1) {
     if (ws_fits(splits)) p.ws = (float*)a->workspace;
     else PH_CHECK_ARG(plain_acc, "ph_gemm_bf16: split_k > 1 without workspace needs out_f32 + accumulate and no fused epilogue");
+  }
+  {
+    // 64x64-tile launches that leave CUs with a single block (the decoder's M = 960 rows): split the k loop inside the block instead
+    // of over gridDim.z + a reduce launch.  PH_GEMM_KS2: 0 = off, 1 = when the tile/split choice above was 64x64 unsplit,
+    // 2 = also instead of a workspace split-K of a 64x64 launch
+    static int ks2 = -1;
+    if (ks2 < 0) { const char* e = getenv("PH_GEMM_KS2"); ks2 = e ? atoi(e) : 2; }
+    const bool plain64 = BM == 64 && BN == 64 && !a->conv && !a->col_stats && !a->trans_a && (a->K % BK) == 0 && kt >= 8 && a->split_k <= 0;
+    if (ks2 > 0 && plain64 && t64 <= 512 && (splits == 1 || ks2 >= 2)) {
+      p.tiles_m = ceil_div(a->M, 64); p.tiles_n = ceil_div(a->N, 64);
+      p.k_tiles_per_split = kt; p.ws = nullptr;
+      return a->trans_b ? launch_ks2<false, true>(p, stream) : launch_ks2<false, false>(p, stream);
+    }
   }
   int rc = BM == 64 ? dispatch_layout<64, 64>(p, a->trans_a, a->trans_b, splits, stream)
            : BN == 64 ? dispatch_layout<128, 64>(p, a->trans_a, a->trans_b, splits, stream)

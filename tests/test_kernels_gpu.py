@@ -170,7 +170,7 @@ def test_gemm_big_tile_lds_dma_kernel(ops, M, N, K, act, mode, trans_b):
     res = rnd(M, N, seed=6)
     pre_big = torch.empty(M, N, dtype=BF, device='cuda'); pre_old = torch.empty_like(pre_big)
     try:
-        _lib.lib.ph_gemm_tuning(0, 160)
+        _lib.lib.ph_gemm_tuning(0, 128)
         old = ops.gemm(a, bb, trans_b=trans_b, bias=bias, act=act, pre_out=pre_old, residual=res)
         _lib.lib.ph_gemm_tuning(mode, 1)
         z = a.float() @ b.float().t() + bias
@@ -181,7 +181,7 @@ def test_gemm_big_tile_lds_dma_kernel(ops, M, N, K, act, mode, trans_b):
             assert rel_fro(pre_big, z) < 6e-3 and rel_fro(big, fn(z) + res.float()) < 6e-3, rep
             assert rel_fro(big, old.float()) < 2e-3 and rel_fro(pre_big, pre_old.float()) < 2e-3, rep
     finally:
-        _lib.lib.ph_gemm_tuning(5, 160)
+        _lib.lib.ph_gemm_tuning(5, 128)
 
 
 @pytest.mark.parametrize('shapes', [

@@ -115,4 +115,4 @@ if __name__ == '__main__':
     case('ragged 8300x2312x704', 8300, 2312, 704, act=ACT_RELU2, pre=True, residual=True)
     case('ragged tb 8300x2312x704', 8300, 2312, 704, act=ACT_RELU2, pre=True, residual=True, tb=True)
     case('f32 out/res 4160x1536x768', 4160, 1536, 768, residual=True, f32res=True, out_f32=True)
-    _lib.lib.ph_gemm_tuning(1, 160)
+    _lib.lib.ph_gemm_tuning(5, 128)

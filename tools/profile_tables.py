@@ -35,7 +35,9 @@ def durations(db, steps, window_ms=None):
     cur = sqlite3.connect(db).cursor()
     t0, t1 = step_window(cur, int(steps))
     rows = cur.execute(f'select name, count(*), sum(end-start) from kernels where start >= {t0} and start < {t1} group by name')
-    out = {short(n): (c / steps, t / steps / 1e3) for n, c, t in rows}          # launches/step, us/step
+    out = {}
+    for n, c, t in rows:                                                          # launches/step, us/step (names that collide after shortening are summed)
+        a = out.get(short(n), (0.0, 0.0)); out[short(n)] = (a[0] + c / steps, a[1] + t / steps / 1e3)
     out['__wall_ms_per_step__'] = (0, (t1 - t0) / steps / 1e6)
     return out
 
@@ -57,7 +59,10 @@ def counter(db, name, steps):
             except sqlite3.Error:
                 continue
             if rows:
-                return {short(k): (v / steps, c / steps) for k, v, c in rows}
+                out = {}
+                for k, v, c in rows:
+                    a = out.get(short(k), (0.0, 0.0)); out[short(k)] = (a[0] + v / steps, a[1] + c / steps)
+                return out
     raise SystemExit(f'{db}: counter {name} not found')
 
 
