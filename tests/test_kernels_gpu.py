@@ -268,6 +268,20 @@ def test_gemm_grouped_streamk(shapes, ta, ops):
         assert rel_fro(x, y) < 1e-5
 
 
+@pytest.mark.parametrize('M,N,K,tb', [(960, 768, 768, False), (960, 768, 3072, True), (960, 2304, 832, False), (200, 136, 512, True)])
+def test_gemm_intra_block_k_split(ops, M, N, K, tb):
+    """gemm_ks2_kernel (64x64 tiles, 512 threads, two thread groups on alternate k-tiles, partial tiles summed by the write-out): the
+    decoder-sized launches take it by default.  Against fp32 torch with the full fused epilogue, odd and even k-tile counts, and
+    bit-for-bit repeatable (fixed summation order: no atomics)."""
+    a, b = rnd(M, K, scale=0.5, seed=3), rnd(N, K, scale=0.2, seed=4)
+    bb = b.t().contiguous() if tb else b
+    bias, res = rnd(N, dtype=torch.float32, seed=5), rnd(M, N, dtype=torch.float32, seed=6)
+    z = F.gelu(a.float() @ b.float().t() + bias) + res
+    outs = [ops.gemm(a, bb, trans_b=tb, bias=bias, act=3, residual=res) for _ in range(3)]
+    assert rel_fro(outs[0], z) < 6e-3
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_gemm_f32_accumulate_splitk(ops):
     M, N, K = 768, 768, 4160           # wgrad shape: dW[N_out, K_in] = dY^T X, reduction over 4160 rows
     dy, x = rnd(K, M, scale=0.3, seed=10), rnd(K, N, scale=0.3, seed=11)

@@ -55,7 +55,12 @@ def counter(db, name, steps):
         kn = next((c for c in cols if c.lower() in ('kernel_name', 'name', 'kernel')), None)
         if cn and val and kn and cn != kn:
             try:
-                rows = list(cur.execute(f'select "{kn}", sum("{val}"), count(*) from "{n}" where "{cn}" = ? group by "{kn}"', (name,)))
+                where = ''
+                if 'start' in cols:         # whole steps of the eager counter run only: between the first and the last once-per-step marker
+                    marks = [r[0] for r in cur.execute(f'select "start" from "{n}" where "{cn}" = ? and "{kn}" like \'%ce_fwd_kernel%\' order by "start"', (name,))]
+                    if len(marks) >= 2:
+                        where, steps = f' and "start" >= {marks[0]} and "start" < {marks[-1]}', float(len(marks) - 1)
+                rows = list(cur.execute(f'select "{kn}", sum("{val}"), count(*) from "{n}" where "{cn}" = ?' + where + f' group by "{kn}"', (name,)))
             except sqlite3.Error:
                 continue
             if rows:
@@ -88,7 +93,7 @@ def main():
     tot = dict(wall_ms_per_step=round(wall_ms, 3), kernel_us_per_step=round(tot_us, 1), launches_per_step=round(sum(r['launches_per_step'] for r in rows), 1),
                hbm_gb_per_step=round(sum(r['hbm_gb_per_step'] for r in rows), 2),
                mfma_tflop_per_step=round(sum(r['mfma_tflop_per_step'] for r in rows), 3))
-    gemm = [r for r in rows if re.search(r'gemm_(grouped_|big_|big_grouped_|streamk_)?kernel', r['kernel'])]
+    gemm = [r for r in rows if re.search(r'gemm_\w*kernel', r['kernel'])]
     gl = sum(r['launches_per_step'] for r in gemm)
     tot['gemm'] = dict(us_per_step=round(sum(r['us_per_step'] for r in gemm), 1), launches_per_step=round(gl, 1),
                        hbm_bytes_per_launch=round(sum(r['hbm_gb_per_step'] for r in gemm) * 1e9 / max(gl, 1)),
