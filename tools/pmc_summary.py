@@ -30,7 +30,7 @@ def find_rows(db, counter, marker='ce_fwd_kernel'):
             try:
                 where, steps = '', None
                 if 'start' in cols:
-                    marks = [r[0] for r in cur.execute(f'select "start" from "{n}" where "{cn}" = ? and "{kn}" like ? order by "start"',
+                    marks = [r[0] for r in cur.execute(f'select distinct "start" from "{n}" where "{cn}" = ? and "{kn}" like ? order by "start"',
                                                        (counter, f'%{marker}%'))]
                     if len(marks) >= 2:
                         where, steps = f' and "start" >= {marks[0]} and "start" < {marks[-1]}', len(marks) - 1

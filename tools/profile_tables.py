@@ -57,7 +57,7 @@ def counter(db, name, steps):
             try:
                 where = ''
                 if 'start' in cols:         # whole steps of the eager counter run only: between the first and the last once-per-step marker
-                    marks = [r[0] for r in cur.execute(f'select "start" from "{n}" where "{cn}" = ? and "{kn}" like \'%ce_fwd_kernel%\' order by "start"', (name,))]
+                    marks = [r[0] for r in cur.execute(f'select distinct "start" from "{n}" where "{cn}" = ? and "{kn}" like \'%ce_fwd_kernel%\' order by "start"', (name,))]
                     if len(marks) >= 2:
                         where, steps = f' and "start" >= {marks[0]} and "start" < {marks[-1]}', float(len(marks) - 1)
                 rows = list(cur.execute(f'select "{kn}", sum("{val}"), count(*) from "{n}" where "{cn}" = ?' + where + f' group by "{kn}"', (name,)))
