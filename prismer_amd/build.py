@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libprismer_hip.so')
 COMM_LIB = os.path.join(LIBDIR, 'libprismer_comm.so')     # RCCL gradient-exchange transport (include/prismer_comm.h), host code only
-SOURCES = ['core.hip', 'gemm.hip', 'norm.hip', 'attention.hip', 'frontend.hip', 'embed_loss.hip', 'optim.hip']
+SOURCES = ['core.hip', 'gemm.hip', 'gemm_big.hip', 'norm.hip', 'attention.hip', 'frontend.hip', 'embed_loss.hip', 'optim.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-pass-failed']
 
 

@@ -20,489 +20,12 @@
 //   * epilogue through LDS (row-contiguous 16-B vectors), fused bias / activation / act' / dropout / residual / accumulate.
 //   * split-K (grid.z): partial tiles to an fp32 workspace + splitk_reduce_kernel (which runs the same epilogue).
 //   * XCD-aware, grouped tile rasterisation (each XCD walks 8-row-panel groups, rows fastest).
-#include <stdarg.h>
-#include <stdio.h>
-#include <stdlib.h>
+#include "gemm_common.h"
 
-#include <math.h>
-#include <utility>
-
-#include "common.h"
+using namespace phg;
 
 namespace {
 
-template <int... Is, class F>
-__device__ __forceinline__ void static_for(std::integer_sequence<int, Is...>, F&& f) {
-  (f(std::integral_constant<int, Is>{}), ...);
-}
-
-constexpr int BK = 64;
-constexpr int KC_ROW_BYTES = BK * 2;   // K-contiguous image: 128 B per row
-
-template <int R>
-struct TileBytes {
-  static constexpr int kc = R * KC_ROW_BYTES;          // K-contiguous image
-  static constexpr int ks_stride = R * 2 + 64;         // K-strided image: bytes per k-row (64-B pad)
-  static constexpr int ks = BK * ks_stride;
-  static constexpr int max = ks > kc ? ks : kc;
-};
-
-// Implicit-GEMM convolution: one operand is the im2col VIEW of an NHWC activation x[B][H][W][C] (C % 8 == 0), never materialised.
-// Logical matrix col[m][k], m = (b, oy, ox), k = (ky*ks + kx)*C + c (zero for out-of-image taps and for k >= ks*ks*C).
-struct ConvGather {
-  int H, W, C, ks, stride, Ho, Wo, Kreal;
-  float inv_howo, inv_wo, inv_c;      // reciprocals for the index decompositions (operands < 2^24: one float multiply + fix-up)
-};
-__device__ __forceinline__ int fdiv(int a, int d, float inv) {          // a / d for 0 <= a < 2^24, d > 0
-  int q = (int)((float)a * inv);
-  q += ((q + 1) * d <= a) ? 1 : 0;
-  q -= (q * d > a) ? 1 : 0;
-  return q;
-}
-
-struct GemmParams {
-  const bf16* A; const bf16* B; void* C;
-  int M, N, K, lda, ldb, ldc;
-  const float* bias;
-  bf16* pre_out;
-  const bf16* act_in; int ld_act;
-  const bf16* residual; int ldr; int res_f32;
-  float drop_p; const uint64_t* drop_seed; uint32_t drop_stream;
-  int act, out_f32, accumulate, pre_grad;
-  float alpha;
-  int k_tiles_per_split;   // in units of BK
-  int tiles_m, tiles_n;
-  float* ws; int ldws;     // split-K partial tiles: ws[split][M][ldws] fp32 (plain stores), folded by splitk_reduce_kernel
-  double* col_stats;       // optional fp64 [2][N]: += column sums / sums of squares of the (bf16-rounded) outputs (BatchNorm statistics)
-  ConvGather cv;           // CONV kernels only: geometry of the gathered operand (A for CONV=1, B for CONV=2)
-};
-
-// ---- global -> register staging ------------------------------------------------------------------------
-// K-contiguous operand: tile = R rows x 64 k. chunk id -> (row = id/8, c = id%8), 16 B each.
-// KFULL: K is a multiple of BK, so no k predicate -> straight-line loads (the compiler's vmcnt bookkeeping stays exact,
-// which the deep prefetch ring depends on).
-template <int R, bool KFULL = false>
-__device__ __forceinline__ void load_kc(const bf16* __restrict__ base, int ld, int row0, int rows, int k0, int K,
-                                        u32x4 (&regs)[R * 8 / 256], const int tid) {
-#pragma unroll
-  for (int i = 0; i < R * 8 / 256; ++i) {
-    int id = tid + 256 * i;
-    int r = id >> 3, c = id & 7;
-    int row = row0 + r;
-    row = row < rows ? row : rows - 1;          // clamp: out-of-range rows only feed out-of-range outputs
-    int k = k0 + c * 8;
-    if (KFULL) {
-      regs[i] = *reinterpret_cast<const u32x4*>(base + (size_t)row * ld + k);
-    } else {
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (k < K) v = *reinterpret_cast<const u32x4*>(base + (size_t)row * ld + k);
-      regs[i] = v;
-    }
-  }
-}
-template <int R>
-__device__ __forceinline__ void store_kc(char* lds, const u32x4 (&regs)[R * 8 / 256], const int tid) {
-#pragma unroll
-  for (int i = 0; i < R * 8 / 256; ++i) {
-    int id = tid + 256 * i;
-    int r = id >> 3, c = id & 7;
-    int cs = c ^ ((r >> 1) & 7);
-    *reinterpret_cast<u32x4*>(lds + r * KC_ROW_BYTES + cs * 16) = regs[i];
-  }
-}
-// K-strided operand: memory [K][rows] (rows contiguous). tile = 64 k-rows x R. chunk id -> (kr = id/(R/8), c = id%(R/8)).
-template <int R, bool KFULL = false>
-__device__ __forceinline__ void load_ks(const bf16* __restrict__ base, int ld, int row0, int rows, int k0, int K,
-                                        u32x4 (&regs)[R * 8 / 256], const int tid) {
-  constexpr int CPR = R / 8;
-#pragma unroll
-  for (int i = 0; i < R * 8 / 256; ++i) {
-    int id = tid + 256 * i;
-    int kr = id / CPR, c = id % CPR;
-    int k = k0 + kr;
-    int r = row0 + c * 8;
-    if (KFULL) {                                 // chunks beyond `rows` re-read the last chunk (they only feed out-of-range outputs)
-      r = r < rows ? r : ((rows - 1) & ~7);
-      regs[i] = *reinterpret_cast<const u32x4*>(base + (size_t)k * ld + r);
-    } else {
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (k < K && r < rows) v = *reinterpret_cast<const u32x4*>(base + (size_t)k * ld + r);
-      regs[i] = v;
-    }
-  }
-}
-template <int R>
-__device__ __forceinline__ void store_ks(char* lds, const u32x4 (&regs)[R * 8 / 256], const int tid) {
-  constexpr int CPR = R / 8;
-#pragma unroll
-  for (int i = 0; i < R * 8 / 256; ++i) {
-    int id = tid + 256 * i;
-    int kr = id / CPR, c = id % CPR;
-    *reinterpret_cast<u32x4*>(lds + kr * TileBytes<R>::ks_stride + c * 16) = regs[i];
-  }
-}
-
-// CONV = 1: K-contiguous A operand gathered from the activation.  Per thread the tile rows are fixed over the k loop, so the
-// pixel decomposition (PixRow) is done once; per k-tile one (tap, channel) decomposition of this thread's 8-wide k chunk.
-struct PixRow { int base, iy0, ix0; };     // base = b*H*W (pixels), (iy0, ix0) = input coordinates of tap (0,0)
-__device__ __forceinline__ PixRow pix_of(const ConvGather& cv, int m) {
-  int b = fdiv(m, cv.Ho * cv.Wo, cv.inv_howo);
-  int rem = m - b * cv.Ho * cv.Wo;
-  int oy = fdiv(rem, cv.Wo, cv.inv_wo), ox = rem - oy * cv.Wo;
-  const int pad = cv.ks >> 1;
-  return PixRow{b * cv.H * cv.W, oy * cv.stride - pad, ox * cv.stride - pad};
-}
-template <int R>
-__device__ __forceinline__ void load_kc_conv(const ConvGather& cv, const bf16* __restrict__ x, const PixRow (&px)[R * 8 / 256], int k0,
-                                             u32x4 (&regs)[R * 8 / 256]) {
-  const int k = k0 + (threadIdx.x & 7) * 8;
-  const bool kin = k < cv.Kreal;
-  const int kk = kin ? k : 0;
-  const int tap = fdiv(kk, cv.C, cv.inv_c), c0 = kk - tap * cv.C;
-  const int ky = cv.ks == 3 ? (tap >= 6 ? 2 : (tap >= 3 ? 1 : 0)) : 0, kx = tap - ky * cv.ks;
-#pragma unroll
-  for (int i = 0; i < R * 8 / 256; ++i) {
-    const int iy = px[i].iy0 + ky, ix = px[i].ix0 + kx;
-    const bool ok = kin && (unsigned)iy < (unsigned)cv.H && (unsigned)ix < (unsigned)cv.W;
-    const int iyc = min(max(iy, 0), cv.H - 1), ixc = min(max(ix, 0), cv.W - 1);          // always a valid address: the load is unconditional
-    u32x4 v = *reinterpret_cast<const u32x4*>(x + ((size_t)(px[i].base + iyc * cv.W + ixc)) * cv.C + c0);
-    const u32x4 z = {0u, 0u, 0u, 0u};
-    regs[i] = ok ? v : z;
-  }
-}
-// CONV = 2: K-strided B operand (wgrad: reduction index = output pixel m, column = (tap, channel)).  Thread -> ONE k row
-// (pixel) per k-tile and R/32 column chunks 4j + (tid & 3): the pixel decomposition (two divisions) is paid once per thread and
-// k-tile, the column decompositions are loop invariants (ColTap, computed before the k loop).
-struct ColTap { int dy, dx, c0, ok; };
-template <int R>
-__device__ __forceinline__ void coltaps_of(const ConvGather& cv, int col0, int ncols, ColTap (&ct)[R * 8 / 256]) {
-#pragma unroll
-  for (int j = 0; j < R * 8 / 256; ++j) {
-    const int col = col0 + (4 * j + (threadIdx.x & 3)) * 8;
-    const bool cin = col < cv.Kreal && col < ncols;
-    const int cc = cin ? col : 0;
-    const int tap = fdiv(cc, cv.C, cv.inv_c);
-    const int ky = cv.ks == 3 ? (tap >= 6 ? 2 : (tap >= 3 ? 1 : 0)) : 0;
-    ct[j] = ColTap{ky, tap - ky * cv.ks, cc - tap * cv.C, cin ? 1 : 0};
-  }
-}
-template <int R>
-__device__ __forceinline__ void load_ks_conv(const ConvGather& cv, const bf16* __restrict__ x, const ColTap (&ct)[R * 8 / 256], int k0, int K,
-                                             u32x4 (&regs)[R * 8 / 256]) {
-  const int m = k0 + ((int)threadIdx.x >> 2);
-  const bool min_ = m < K;
-  const PixRow p = pix_of(cv, min_ ? m : 0);
-#pragma unroll
-  for (int j = 0; j < R * 8 / 256; ++j) {
-    const int iy = p.iy0 + ct[j].dy, ix = p.ix0 + ct[j].dx;
-    const bool ok = ct[j].ok && min_ && (unsigned)iy < (unsigned)cv.H && (unsigned)ix < (unsigned)cv.W;
-    const int iyc = min(max(iy, 0), cv.H - 1), ixc = min(max(ix, 0), cv.W - 1);
-    u32x4 v = *reinterpret_cast<const u32x4*>(x + ((size_t)(p.base + iyc * cv.W + ixc)) * cv.C + ct[j].c0);
-    const u32x4 z = {0u, 0u, 0u, 0u};
-    regs[j] = ok ? v : z;
-  }
-}
-template <int R>
-__device__ __forceinline__ void store_ks_conv(char* lds, const u32x4 (&regs)[R * 8 / 256]) {
-#pragma unroll
-  for (int j = 0; j < R * 8 / 256; ++j)
-    *reinterpret_cast<u32x4*>(lds + ((int)threadIdx.x >> 2) * TileBytes<R>::ks_stride + (4 * j + (threadIdx.x & 3)) * 16) = regs[j];
-}
-
-// ---- LDS -> MFMA fragment ------------------------------------------------------------------------------
-// 32x32x16 operand fragment: lane l holds 8 consecutive k for row (l & 31), k-half (l >> 5).
-__device__ __forceinline__ bf16x8 frag_kc(const char* lds, int rbase, int kk, int lane) {
-  int r = rbase + (lane & 31);
-  int c = kk * 2 + (lane >> 5);
-  int cs = c ^ ((r >> 1) & 7);
-  return *reinterpret_cast<const bf16x8*>(lds + r * KC_ROW_BYTES + cs * 16);
-}
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-template <int R>
-__device__ __forceinline__ bf16x8 frag_ks(const char* lds, int rbase, int kk, int lane) {
-  // ds_read_b64_tr_b16: within a 16-lane group, source lane (4j+q) supplies 4 consecutive row-elements of
-  // k-row j; result lane c receives element j = T[k_j][rows 4*(c/4).. + c%4] i.e. column c of the 4x16 block.
-  int g = lane >> 4, i = lane & 15, j = i >> 2, q = i & 3;
-  int k = kk * 16 + (g >> 1) * 8 + j;
-  int r = rbase + (g & 1) * 16 + q * 4;
-  const char* p = lds + k * TileBytes<R>::ks_stride + r * 2;
-  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
-  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * TileBytes<R>::ks_stride));
-  bf16x8 o;
-  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
-  o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
-  return o;
-}
-
-// K-strided operand image written by the LDS-DMA path (big kernel; B given as [K][N], A given as [K][M]): 64 k-rows of 256 B (128 n)
-// or 512 B (256 m), no padding -- the
-// DMA destination is lane-linear.  Bank spreading is done by XOR-ing the 64-B block index of a k-row with (k & 3): the four k-rows a
-// 16-lane group of ds_read_b64_tr_b16 touches then sit in four different 16-bank quarters (same effect as the 64-B row pad of the
-// register-staged image).  The DMA source addressing applies the same permutation (gemm_big_kernel).
-template <int RB>      // bytes per k-row: 256 (128-wide B tile) or 512 (256-wide A tile)
-__device__ __forceinline__ bf16x8 frag_ks_dma(const char* lds, int rbase, int kk, int lane) {
-  const int g = lane >> 4, i = lane & 15, j = i >> 2, q = i & 3;
-  const int k = kk * 16 + (g >> 1) * 8 + j;                    // k & 3 == j, for the second read (k + 4) too
-  const int byte = (rbase + (g & 1) * 16 + q * 4) * 2;         // offset inside the k-row
-  const char* p = lds + k * RB + ((((byte >> 6) ^ j) << 6) | (byte & 63));
-  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
-  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * RB));
-  bf16x8 o;
-  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
-  o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
-  return o;
-}
-
-// one lane's 4 consecutive outputs C[m][n..n+3]
-__device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n, float (&v)[4], bool splitk, bool drop,
-                                               const DropCtx& dc) {
-  const bool full = (n + 4 <= p.N);
-  if (splitk && p.ws) {   // split-K with workspace: raw partial sums, the full epilogue runs in splitk_reduce_kernel
-    float* c = p.ws + ((size_t)blockIdx.z * p.M + m) * p.ldws + n;
-    f32x4 t = {v[0], v[1], v[2], v[3]};
-    *reinterpret_cast<f32x4*>(c) = t;      // ldws % 4 == 0 and n % 4 == 0: always a full, aligned vector (pad columns are scratch)
-    return;
-  }
-  if (splitk) {   // no workspace: raw fp32 atomics into C (host guarantees a plain fp32 accumulate epilogue)
-    float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (n + e < p.N) atomicAdd(c + e, v[e]);
-    return;
-  }
-  if (p.bias) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] += p.bias[min(n + e, p.N - 1)];
-  }
-  const bool fused_grad = p.pre_out && p.pre_grad && !p.act_in;
-  if (p.pre_out) {
-    bf16* q = p.pre_out + (size_t)m * p.ldc + n;
-    float w[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (fused_grad) act_fwd_grad(p.act, v[e], v[e], w[e]);       // v becomes act(x), w = act'(x)
-      else w[e] = v[e];
-    }
-    if (full) { bf16x4 t = {f2bf(w[0]), f2bf(w[1]), f2bf(w[2]), f2bf(w[3])}; *reinterpret_cast<bf16x4*>(q) = t; }
-    else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) if (n + e < p.N) q[e] = f2bf(w[e]);
-    }
-  }
-  if (p.act_in) {       // backward through an activation: multiply by act'(saved pre-activation)
-    const bf16* q = p.act_in + (size_t)m * p.ld_act + n;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] *= act_grad(p.act, bf2f(q[min(e, p.N - 1 - n)]));
-  } else if (p.act != PH_ACT_NONE && !fused_grad) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = act_fwd(p.act, v[e]);
-  }
-  if (drop) {           // element index m*N+n ; N % 4 == 0 is required with dropout (checked on host)
-    u32x4 r = drop_rand4(dc, ((uint64_t)m * (uint64_t)p.N + (uint64_t)n) >> 2);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = drop_apply(dc, r[e], v[e]);
-  }
-  if (p.residual && p.res_f32) {    // fp32 residual stream (decoder: LayerNorm outputs stay fp32 like under autocast)
-    const float* q = reinterpret_cast<const float*>(p.residual) + (size_t)m * p.ldr + n;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] += q[min(e, p.N - 1 - n)];
-  } else if (p.residual) {
-    const bf16* q = p.residual + (size_t)m * p.ldr + n;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] += bf2f(q[min(e, p.N - 1 - n)]);
-  }
-  if (p.out_f32) {
-    float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
-    if (p.accumulate) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += c[e];
-    }
-    if (full && ((p.ldc & 3) == 0)) { f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(c) = t; }
-    else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) if (n + e < p.N) c[e] = v[e];
-    }
-  } else {
-    bf16* c = reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n;
-    if (p.accumulate) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += bf2f(c[e]);
-    }
-    if (full && ((p.ldc & 3) == 0)) { bf16x4 t = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])}; *reinterpret_cast<bf16x4*>(c) = t; }
-    else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) if (n + e < p.N) c[e] = f2bf(v[e]);
-    }
-  }
-}
-
-// 8 consecutive outputs C[m][n..n+7] with 16-B vector loads/stores (interior tiles, 16-B aligned leading dimensions), in two
-// halves: epi_load8 issues the global READS of the fused chain (saved activation, residual), epi_apply8 does the arithmetic and the
-// stores.  The write-out loops issue the loads of several steps before the first apply, so their latency (1-2 us under load) is
-// paid once per group instead of once per step (stores to C may alias the residual -- in-place residual adds -- so the compiler
-// cannot hoist the loads by itself; every thread reads exactly the elements it later writes, which keeps the reordering exact).
-struct EpiIn { bf16x8 a, rb; f32x4 r0, r1; };   // act_in | bf16 residual | fp32 residual (typed fields: no punning through the
-                                                 // aggregate, or it is not promoted to registers)
-__device__ __forceinline__ void epi_load8(const GemmParams& p, int m, int n, EpiIn& in) {
-  if (p.act_in) in.a = *reinterpret_cast<const bf16x8*>(p.act_in + (size_t)m * p.ld_act + n);
-  if (p.residual && p.res_f32) {
-    const float* q = reinterpret_cast<const float*>(p.residual) + (size_t)m * p.ldr + n;
-    in.r0 = *reinterpret_cast<const f32x4*>(q); in.r1 = *reinterpret_cast<const f32x4*>(q + 4);
-  } else if (p.residual) {
-    in.rb = *reinterpret_cast<const bf16x8*>(p.residual + (size_t)m * p.ldr + n);
-  }
-}
-__device__ __forceinline__ void epi_apply8(const GemmParams& p, int m, int n, float (&v)[8], bool drop, const DropCtx& dc, const EpiIn& in) {
-  if (p.bias) {
-    f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-  }
-  const bool fused_grad = p.pre_out && p.pre_grad && !p.act_in;
-  if (p.pre_out) {
-    bf16x8 t;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float w = v[e];
-      if (fused_grad) act_fwd_grad(p.act, v[e], v[e], w);
-      t[e] = f2bf(w);
-    }
-    *reinterpret_cast<bf16x8*>(p.pre_out + (size_t)m * p.ldc + n) = t;
-  }
-  if (p.act_in) {
-    const bf16x8 t = in.a;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] *= act_grad(p.act, bf2f(t[e]));
-  } else if (p.act != PH_ACT_NONE && !fused_grad) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = act_fwd(p.act, v[e]);
-  }
-  if (drop) {
-    uint64_t i4 = ((uint64_t)m * (uint64_t)p.N + (uint64_t)n) >> 2;
-    u32x4 r0 = drop_rand4(dc, i4), r1 = drop_rand4(dc, i4 + 1);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { v[e] = drop_apply(dc, r0[e], v[e]); v[4 + e] = drop_apply(dc, r1[e], v[4 + e]); }
-  }
-  if (p.residual && p.res_f32) {
-    const f32x4 r0 = in.r0, r1 = in.r1;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
-  } else if (p.residual) {
-    const bf16x8 t = in.rb;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] += bf2f(t[e]);
-  }
-  if (p.out_f32) {
-    float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
-    if (p.accumulate) {
-      f32x4 c0 = *reinterpret_cast<const f32x4*>(c), c1 = *reinterpret_cast<const f32x4*>(c + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] += c0[e]; v[4 + e] += c1[e]; }
-    }
-    f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-    *reinterpret_cast<f32x4*>(c) = o0;
-    *reinterpret_cast<f32x4*>(c + 4) = o1;
-  } else {
-    bf16* c = reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n;
-    if (p.accumulate) {
-      bf16x8 t = *reinterpret_cast<const bf16x8*>(c);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += bf2f(t[e]);
-    }
-    bf16x8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
-    *reinterpret_cast<bf16x8*>(c) = o;
-  }
-}
-
-// Row-wise write-out of a BM x BN fp32 tile parked in LDS (16-B chunks XOR-swizzled by the row): consecutive lanes own
-// consecutive 16/32-B pieces of one output row for every load / store of the fused epilogue chain.
-template <int BM, int BN, int NTHR>
-__device__ __forceinline__ void tile_writeout(const GemmParams& p, const float* cl, int m0, int n0, bool splitk, bool drop,
-                                              const DropCtx& dc, const float* cl2 = nullptr) {   // cl2: second partial tile to add (KS = 2)
-  constexpr int CH = BN / 4;                       // 16-B chunks per tile row
-  // fast path: 8 outputs per thread per step (16-B loads/stores) when every leading dimension / pointer allows it
-  const bool vec8 = !(splitk) && p.N >= 8 && (p.ldc % 8) == 0 && (!p.act_in || (p.ld_act % 8) == 0) && (!p.residual || (p.ldr % 8) == 0) &&
-                    ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.pre_out) | reinterpret_cast<uintptr_t>(p.act_in) |
-                      reinterpret_cast<uintptr_t>(p.residual) | reinterpret_cast<uintptr_t>(p.bias)) & 15) == 0;
-  if (vec8) {
-    // steps per thread; steps per load group (16 VGPRs of prefetched inputs per step: 4 for the 512-thread kernel, whose register budget
-    // is 256/lane at its occupancy; 2 for the 256-thread kernels, which must stay under 192 + 64 accumulators for 2 blocks per CU)
-    constexpr int IT = BM * CH / (2 * NTHR), G = (NTHR >= 512 && IT % 4 == 0) ? 4 : (IT % 2 == 0 ? 2 : 1);
-    for (int it0 = 0; it0 < IT; it0 += G) {
-      EpiIn in[G];                  // (indexed with compile-time constants only and fully initialised: stays in VGPRs)
-      static_for(std::make_integer_sequence<int, G>{}, [&](auto uu) {
-        constexpr int u = decltype(uu)::value;
-        const int id = (it0 + u) * NTHR + threadIdx.x;
-        const int ml = id / (CH / 2), c = (id % (CH / 2)) * 2;
-        const int m = min(m0 + ml, p.M - 1), n = (n0 + c * 4 + 8 <= p.N) ? n0 + c * 4 : 0;     // always a valid address: the loads are unconditional
-        in[u] = EpiIn{};
-        epi_load8(p, m, n, in[u]);
-      });
-      static_for(std::make_integer_sequence<int, G>{}, [&](auto uu) {
-        constexpr int u = decltype(uu)::value;
-        const int id = (it0 + u) * NTHR + threadIdx.x;
-        const int ml = id / (CH / 2), c = (id % (CH / 2)) * 2;
-        const int m = m0 + ml, n = n0 + c * 4;
-        const int sw = ml & (CH - 1);
-        f32x4 t0 = *reinterpret_cast<const f32x4*>(cl + ml * BN + ((c ^ sw) << 2));
-        f32x4 t1 = *reinterpret_cast<const f32x4*>(cl + ml * BN + (((c + 1) ^ sw) << 2));
-        if (cl2) {
-          t0 += *reinterpret_cast<const f32x4*>(cl2 + ml * BN + ((c ^ sw) << 2));
-          t1 += *reinterpret_cast<const f32x4*>(cl2 + ml * BN + (((c + 1) ^ sw) << 2));
-        }
-        if (m < p.M && n + 8 <= p.N) {
-          float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-#ifdef PH_GEMM_DIAG_NOSTORE  // diagnostics build: staging + LDS reads, no HBM traffic from the epilogue
-          if (v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] != 123456.789f) return;
-#endif
-          epi_apply8(p, m, n, v, drop, dc, in[u]);
-        } else if (m < p.M) {
-          float v0[4] = {t0[0], t0[1], t0[2], t0[3]}, v1[4] = {t1[0], t1[1], t1[2], t1[3]};
-          if (n < p.N) epilogue_store(p, m, n, v0, false, drop, dc);
-          if (n + 4 < p.N) epilogue_store(p, m, n + 4, v1, false, drop, dc);
-        }
-      });
-    }
-  } else {
-#pragma unroll 4
-    for (int it = 0; it < BM * CH / NTHR; ++it) {
-      const int id = it * NTHR + threadIdx.x;
-      const int ml = id / CH, c = id % CH;
-      const int m = m0 + ml, n = n0 + c * 4;
-      f32x4 t = *reinterpret_cast<const f32x4*>(cl + ml * BN + ((c ^ (ml & (CH - 1))) << 2));
-      if (cl2) t += *reinterpret_cast<const f32x4*>(cl2 + ml * BN + ((c ^ (ml & (CH - 1))) << 2));
-      float v[4] = {t[0], t[1], t[2], t[3]};
-      if (m < p.M && n < p.N) epilogue_store(p, m, n, v, splitk, drop, dc);
-    }
-  }
-}
-
-// BatchNorm statistics of a conv-as-GEMM output, taken from the tile while it is parked in LDS: per column the sum and the sum of
-// squares of the bf16-ROUNDED values (what the next layer reads) over the tile's valid rows, added to col_stats[2][N] with one
-// atomic pair per column and row half.  Plain epilogues only (the parked tile is alpha * acc: no bias / activation in a conv).
-// The global accumulators are fp64: the variance is later formed as E[x^2] - E[x]^2, and in fp32 that difference (and the order
-// of the atomics) is worth 1e-7 * x^2 -- visible against BatchNorm's eps = 1e-5 in channels that are constant over the batch
-// (piecewise-constant label maps), where it made the step's loss wander by 2e-4 from run to run.
-template <int BM, int BN, int NTHR>
-__device__ __forceinline__ void tile_colstats(const GemmParams& p, const float* cl, int m0, int n0) {
-  constexpr int CH = BN / 4, PARTS = NTHR / BN, RP = BM / PARTS;
-  const int col = threadIdx.x % BN, part = threadIdx.x / BN;
-  if (part >= PARTS || n0 + col >= p.N) return;
-  const int rows = min(BM, p.M - m0);
-  float s = 0.f, ss = 0.f;
-  const int c4 = col >> 2, e = col & 3;
-  for (int r = part * RP; r < min((part + 1) * RP, rows); ++r) {
-    float v = bf2f(f2bf(cl[r * BN + ((c4 ^ (r & (CH - 1))) << 2) + e]));
-    s += v; ss += v * v;
-  }
-  // PH_COLSTAT_SLABS interleaved copies of the accumulators (slab = block id mod 8): a tall conv output (401408 x 96: 3136 tiles)
-  // otherwise queues thousands of atomics on each of its 192 addresses (measured: 49 -> 158 us for that GEMM)
-  double* st = p.col_stats + (size_t)(blockIdx.x % PH_COLSTAT_SLABS) * 2 * p.N;
-  atomicAdd(st + n0 + col, (double)s);
-  atomicAdd(st + p.N + n0 + col, (double)ss);
-}
 
 // One output tile over the k-tiles [kt_begin, kt_end).  XCD_REMAP: block_id is a hardware block index of a one-tile-per-block launch
 // (re-mapped so that each XCD owns a contiguous run of tiles); otherwise block_id already is the tile index.  splitk: the tile has
@@ -712,241 +235,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   gemm_body<BM, BN, TA, TB, PF, CONV>(p, blockIdx.x, blockIdx.z, gridDim.z);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// "Big" kernel for the forward-shaped GEMMs with many rows (both operands K-contiguous, K % 64 == 0):
-//   block = 512 threads = 8 waves as 4 (M) x 2 (N), wave tile 64 x 64, block tile 256 x 128, BK = 64;
-//   operands go global -> LDS by the LDS-DMA path (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass) into a ring of
-//   THREE 48-KB stages: the loads of k-tile t+2 are issued right after the barrier that publishes tile t and stay in flight across
-//   the next barrier (counted s_waitcnt vmcnt(6): each thread owns 6 DMA instructions per tile), one raw s_barrier per k-tile.
-//   The LDS image is lane-linear per DMA instruction (8 rows x 128 B per wave instruction); the 16-B chunk XOR swizzle the
-//   ds_read_b128 fragment reads need is applied on the SOURCE address (lane l fetches chunk (l&7) ^ swz(row) of its row) and
-//   again on the read -- the destination stays linear (hardware writes base + lane*16).
-//   1 block per CU (144 KB of LDS), 2 waves per SIMD.  Epilogue: the 256x128 fp32 tile is parked in the (drained) ring and
-//   written out row-wise by the same fused chain as the 128x128 kernel.
-namespace big {
-constexpr int BM = 256, BN = 128, NTHR = 512, STAGES = 3;
-constexpr int A_BYTES = BM * KC_ROW_BYTES, B_BYTES = BN * KC_ROW_BYTES, STAGE = A_BYTES + B_BYTES;   // 32 KB + 16 KB
-constexpr int A_INSTR = BM * 8 / NTHR, B_INSTR = BN * 8 / NTHR;                                     // 4 + 2 DMA instructions / thread / tile
-constexpr int SMEM = STAGES * STAGE;                                                                // 147456 B (>= 256*128*4 for the epilogue)
 
-typedef __attribute__((address_space(1))) const void gptr_t;
-typedef __attribute__((address_space(3))) void lptr_t;
-
-template <int VARIANT, bool TA, bool TB, bool XCD_REMAP>
-__device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // tile mapping: same XCD-contiguous + grouped rasterisation as gemm_tile
-  const int nt = p.tiles_m * p.tiles_n;
-  int bid = block_id;
-  if constexpr (XCD_REMAP) {
-    int q = nt / 8, r = nt % 8, xcd = bid % 8, idx = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  constexpr int GM = 4;
-  const int group_sz = GM * p.tiles_n;
-  const int first_m = (bid / group_sz) * GM;
-  const int gm = min(GM, p.tiles_m - first_m);
-  const int rin = bid % group_sz;
-  const int tm = first_m + rin % gm, tn = rin / gm;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int nk = p.K / BK;
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 1, wn = wave & 1;                   // wave tile: rows wm*64, cols wn*64
-
-  // ---- DMA addressing: instruction i of this wave covers tile rows (i*8 + wave)*8 .. +8, lane l -> row +(l>>3), LDS slot l&7
-  const bf16* a_src[A_INSTR];
-  const bf16* b_src[B_INSTR];
-#pragma unroll
-  for (int i = 0; i < A_INSTR; ++i) {
-    if constexpr (TA) {   // A = [K][M]: one instruction = 2 k-rows x 512 B; lane -> k-row (lane >> 5), LDS slot lane & 31 holds chunk c
-      const int kr = (i * 8 + wave) * 2 + (lane >> 5), pos = lane & 31;
-      const int c = (((pos >> 2) ^ (kr & 3)) << 2) | (pos & 3);
-      a_src[i] = p.A + (size_t)kr * p.lda + min(m0 + c * 8, p.M - 8);
-    } else {
-      const int r = (i * 8 + wave) * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ ((r >> 1) & 7);
-      a_src[i] = p.A + (size_t)min(m0 + r, p.M - 1) * p.lda + c * 8;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < B_INSTR; ++i) {
-    if constexpr (TB) {   // B = [K][N]: one instruction = 4 k-rows x 256 B; lane -> k-row (lane >> 4), LDS slot lane & 15 holds chunk c
-      const int kr = (i * 8 + wave) * 4 + (lane >> 4), pos = lane & 15;
-      const int c = (((pos >> 2) ^ (kr & 3)) << 2) | (pos & 3);
-      b_src[i] = p.B + (size_t)kr * p.ldb + min(n0 + c * 8, p.N - 8);
-    } else {
-      const int r = (i * 8 + wave) * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ ((r >> 1) & 7);
-      b_src[i] = p.B + (size_t)min(n0 + r, p.N - 1) * p.ldb + c * 8;
-    }
-  }
-  auto issue = [&](int kt, int stage) {
-    char* sa = smem + stage * STAGE;
-    char* sb = sa + A_BYTES;
-    const int koff = kt * BK;
-#pragma unroll
-    for (int i = 0; i < A_INSTR; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t*)(a_src[i] + (TA ? (size_t)koff * p.lda : (size_t)koff)), (lptr_t*)(sa + (i * 8 + wave) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < B_INSTR; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t*)(b_src[i] + (TB ? (size_t)koff * p.ldb : (size_t)koff)), (lptr_t*)(sb + (i * 8 + wave) * 1024), 16, 0, 0);
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-  auto compute = [&](int stage) {
-    const char* la = smem + stage * STAGE;
-    const char* lb = la + A_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      bf16x8 fx[2], fw[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) fx[i] = TA ? frag_ks_dma<512>(la, wm * 64 + i * 32, kk, lane) : frag_kc(la, wm * 64 + i * 32, kk, lane);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) fw[j] = TB ? frag_ks_dma<256>(lb, wn * 64 + j * 32, kk, lane) : frag_kc(lb, wn * 64 + j * 32, kk, lane);
-      if (VARIANT & 1) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fx[i], acc[i][j], 0, 0, 0);
-      if (VARIANT & 1) __builtin_amdgcn_s_setprio(0);
-    }
-  };
-
-  if constexpr ((VARIANT & 4) == 0) {
-    // ---- main loop: tile t lives in stage t % 3.  Every iteration issues exactly one tile (index clamped: the surplus loads of
-    // the last two iterations land in a stage nobody reads again), so "all but the newest tile have landed" is always vmcnt(6).
-    issue(0, 0);
-    issue(min(1, nk - 1), 1);
-    int st = 0;                                                // stage of tile t
-    for (int t = 0; t < nk; ++t) {
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");         // my DMA writes of tile t are in LDS (tile t+1 may still fly)
-      __builtin_amdgcn_s_barrier();                            // everybody's are; everybody finished reading tile t-1
-      asm volatile("" ::: "memory");
-      int st2 = st + 2; st2 = st2 >= 3 ? st2 - 3 : st2;
-      issue(min(t + 2, nk - 1), st2);                          // overwrites the stage tile t-1 was read from
-      compute(st);
-      st = st + 1 == 3 ? 0 : st + 1;
-    }
-  } else {
-    // ---- ping-pong main loop (VARIANT & 4).  The two waves of a SIMD (wave w of group 0 = waves 0..3, wave w+4 of group 1) take
-    // turns on the matrix pipe: every k-tile is two PHASES per group, R(t) = the 16 ds_read_b128 of the wave's whole k-tile (64
-    // fragment VGPRs) and M(t) = its 16 MFMAs with the LDS-DMA of a later tile issued between them; group 1 runs one phase behind
-    // group 0, every phase ends in one workgroup barrier:
-    //     phase 2t   : group 0 R(t)                 | group 1 M(t-1) + DMA(t+2)
-    //     phase 2t+1 : group 0 M(t) + DMA(t+2)      | group 1 R(t)
-    // so while one wave of a SIMD issues back-to-back MFMAs its partner collects operands, instead of both waves alternating
-    // ds_read -> s_waitcnt -> 4 MFMAs in lockstep (what the compiler makes of the plain loop).
-    // Ordering (3-stage ring, tile t in stage t % 3; group g's M(t) issues tile t+2+g, so every wave has exactly one tile newer
-    // than the one it must have landed and the wait is always vmcnt(6)):
-    //   RAW  every wave waits vmcnt(6) before the barrier that ends an ODD phase (group 0: after M(t)'s issue, group 1: in R(t)):
-    //        all shares of tile t+1 are then in LDS, the first read of tile t+1 is in phase 2t+2 (one barrier later).
-    //   WAR  R phases end with lgkmcnt(0) BEFORE their barrier; stage (t+2)%3 = stage of tile t-1 was last read in phase 2t-1 and
-    //        is overwritten from phase 2t+1 (group 0) / 2t (group 1, tile t+2 = (t-1)+3) on.
-    const int grp = wave >> 2;
-    issue(0, 0);
-    issue(min(1, nk - 1), 1);
-    if (grp) {
-      issue(min(2, nk - 1), 2);
-      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();                              // tile 0 is in LDS for everybody
-    if (grp) __builtin_amdgcn_s_barrier();                     // group 1 idles through phase 0
-    int st = 0;
-    for (int t = 0; t < nk; ++t) {
-      // R(t)
-      const char* la = smem + st * STAGE;
-      const char* lb = la + A_BYTES;
-      bf16x8 fx[BK / 16][2], fw[BK / 16][2];
-#pragma unroll
-      for (int kk = 0; kk < BK / 16; ++kk) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) fx[kk][i] = TA ? frag_ks_dma<512>(la, wm * 64 + i * 32, kk, lane) : frag_kc(la, wm * 64 + i * 32, kk, lane);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) fw[kk][j] = TB ? frag_ks_dma<256>(lb, wn * 64 + j * 32, kk, lane) : frag_kc(lb, wn * 64 + j * 32, kk, lane);
-      }
-      if (grp) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // M(t)
-      int sn = st + 2 + grp; sn = sn >= 3 ? sn - 3 : sn;
-      if (VARIANT & 1) __builtin_amdgcn_s_setprio(1);
-      issue(min(t + 2 + grp, nk - 1), sn);
-#pragma unroll
-      for (int kk = 0; kk < BK / 16; ++kk)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[kk][j], fx[kk][i], acc[i][j], 0, 0, 0);
-      if (VARIANT & 1) __builtin_amdgcn_s_setprio(0);
-      if (!grp) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      st = st + 1 == 3 ? 0 : st + 1;
-    }
-    if (!grp) __builtin_amdgcn_s_barrier();                    // group 0 idles through the last phase (group 1's M(nk-1))
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // drain the surplus DMA before the ring is reused as the C tile
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-
-  // ---- epilogue (same chain as gemm_body, 512 threads, 256 x 128 tile)
-  DropCtx dc;
-  const bool drop = p.drop_p > 0.0f;
-  if (drop) dc = make_drop(p.drop_seed, p.drop_stream, p.drop_p);
-  constexpr int CH = BN / 4;
-  float* cl = reinterpret_cast<float*>(smem);
-  static_for(std::make_integer_sequence<int, 2 * 2 * 4>{}, [&](auto idx) {
-    constexpr int i = decltype(idx)::value / 8, j = (decltype(idx)::value / 4) % 2, g = decltype(idx)::value % 4;
-    const int ml = wm * 64 + i * 32 + (lane & 31);
-    const int c = (wn * 64 + j * 32 + g * 8 + (lane >> 5) * 4) >> 2;
-    f32x4 v = {acc[i][j][g * 4 + 0] * p.alpha, acc[i][j][g * 4 + 1] * p.alpha, acc[i][j][g * 4 + 2] * p.alpha,
-               acc[i][j][g * 4 + 3] * p.alpha};
-    *reinterpret_cast<f32x4*>(cl + ml * BN + ((c ^ (ml & (CH - 1))) << 2)) = v;
-  });
-  __syncthreads();
-  tile_writeout<BM, BN, NTHR>(p, cl, m0, n0, false, drop, dc);
-}
-
-template <int VARIANT, bool TA, bool TB>
-__global__ __launch_bounds__(NTHR) void gemm_big_kernel(GemmParams p) {
-  big_tile<VARIANT, TA, TB, true>(p, blockIdx.x);
-}
-
-template <int VARIANT, bool TA, bool TB>
-int launch(const GemmParams& p, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<VARIANT, TA, TB>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((gemm_big_kernel<VARIANT, TA, TB>), dim3(p.tiles_m * p.tiles_n), dim3(NTHR), SMEM, s, p);
-  PH_LAUNCH_CHECK("gemm_big_kernel");
-  return PH_OK;
-}
-}  // namespace big
-
-// Grouped launch: up to PH_GEMM_GROUP_MAX independent problems of one layout in ONE grid (block -> (problem, tile) through a
-// prefix table in the kernel arguments).  The deferred weight-gradient GEMMs of a layer (outputs of 18..144 tiles each, far
-// below the 512 block slots of the chip) are issued this way instead of one under-filled launch + split-K reduce apiece.
-struct GroupParams {
-  int n;
-  int tile_start[PH_GEMM_GROUP_MAX + 1];
-  int iter_start[PH_GEMM_GROUP_MAX + 1];   // stream-K launches: prefix sums of tiles x k-tiles per problem
-  int iters_per_worker;                    // stream-K launches: length of one worker's slice of that iteration space
-  GemmParams p[PH_GEMM_GROUP_MAX];
-};
 // The grid may be SMALLER than the number of tiles (ph_gemm_grouped_bf16's max_blocks): each block then walks tiles
 // blockIdx.x, blockIdx.x + gridDim.x, ... -- a background launch that occupies at most max_blocks block slots and leaves the rest
 // of the chip to the latency-bound chain on the main stream (deferred weight gradients beside the decoder's backward).
@@ -961,36 +250,7 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupParams g) {
   }
 }
 
-// Grouped launch on the 256x128 ping-pong kernel (weight-gradient layout, long reductions): a persistent grid of one block per CU
-// walks the tiles round by round; within a round the XCD-contiguous numbering of gemm_tile is kept (tiles that share an operand
-// panel run on one XCD at the same time).
-namespace big {
-template <int VARIANT, bool TA, bool TB>
-__global__ __launch_bounds__(NTHR) void gemm_big_grouped_kernel(GroupParams g) {
-  const int total = g.tile_start[g.n], grid = gridDim.x;
-  int i = 0;
-  for (int base = 0; base < total; base += grid) {
-    const int cnt = min(grid, total - base);
-    if ((int)blockIdx.x >= cnt) break;
-    const int q = cnt / 8, r = cnt % 8, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
-    const int t = base + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    while (i + 1 < g.n && t >= g.tile_start[i + 1]) ++i;
-    big_tile<VARIANT, TA, TB, false>(g.p[i], t - g.tile_start[i]);
-    __syncthreads();                     // the write-out's LDS staging area is the next tile's DMA ring
-  }
-}
-template <int VARIANT, bool TA, bool TB>
-int launch_grouped(const GroupParams& g, int total, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_grouped_kernel<VARIANT, TA, TB>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((gemm_big_grouped_kernel<VARIANT, TA, TB>), dim3(total < 256 ? total : 256), dim3(NTHR), SMEM, s, g);
-  PH_LAUNCH_CHECK("gemm_big_grouped_kernel");
-  return PH_OK;
-}
-}  // namespace big
+
 
 // Stream-K form of the grouped launch, for groups of plain fp32-accumulate problems (the deferred weight gradients: dW += dY^T X):
 // the work is the flat iteration space (problem, tile, k-tile); gridDim.x workers -- one per block slot of the chip -- each take an
@@ -1104,6 +364,7 @@ int dispatch_layout(const GemmParams& p, int ta, int tb, int splits, hipStream_t
 }
 
 }  // namespace
+
 
 static int g_big_mode = -1, g_big_min_tiles = -1;
 
@@ -1256,7 +517,7 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
         }
         g.tile_start[n] = tot;
         g.iters_per_worker = 0;
-        return big::launch_grouped<4, true, true>(g, tot, stream);
+        return big::launch_grouped_wgrad(g, tot, stream);
       }
     }
   }
@@ -1351,18 +612,7 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
       p.tiles_m = ceil_div(a->M, big::BM); p.tiles_n = ceil_div(a->N, big::BN);
       p.k_tiles_per_split = a->K / BK;
       p.ws = nullptr; p.ldws = 0;
-      if (a->trans_b) {
-        switch (big_mode) {
-          case 1: return big::launch<0, false, true>(p, stream);
-          case 6: return big::launch<5, false, true>(p, stream);
-          default: return big::launch<4, false, true>(p, stream);
-        }
-      }
-      switch (big_mode) {
-        case 1: return big::launch<0, false, false>(p, stream);
-        case 6: return big::launch<5, false, false>(p, stream);
-        default: return big::launch<4, false, false>(p, stream);
-      }
+      return big::launch_single(p, big_mode == 1 ? 0 : (big_mode == 6 ? 5 : 4), false, a->trans_b != 0, stream);
     }
     // weight-gradient layout (A = [K][M], B = [K][N]) with a long reduction: same kernel, both operands through the transposing reads
     if (big_mode > 0 && !a->conv && !a->col_stats && a->trans_a && a->trans_b && tb_ok && (a->K % BK) == 0 && a->K >= 32 * BK && a->split_k <= 0 &&
@@ -1370,7 +620,7 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
       p.tiles_m = ceil_div(a->M, big::BM); p.tiles_n = ceil_div(a->N, big::BN);
       p.k_tiles_per_split = a->K / BK;
       p.ws = nullptr; p.ldws = 0;
-      return big::launch<4, true, true>(p, stream);
+      return big::launch_single(p, 4, true, true, stream);
     }
   }
 

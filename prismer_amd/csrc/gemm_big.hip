@@ -1,0 +1,272 @@
+// 256x128 LDS-DMA GEMM kernels for gfx950 (ping-pong main loop, [N,K] / [K,N] / [K,M] operands, single and grouped persistent launch).
+// Split from gemm.hip so that the two halves of the GEMM family compile in parallel; the dispatch rules live in gemm.hip.
+#include "gemm_common.h"
+
+namespace phg {
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// "Big" kernel for the forward-shaped GEMMs with many rows (both operands K-contiguous, K % 64 == 0):
+//   block = 512 threads = 8 waves as 4 (M) x 2 (N), wave tile 64 x 64, block tile 256 x 128, BK = 64;
+//   operands go global -> LDS by the LDS-DMA path (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass) into a ring of
+//   THREE 48-KB stages: the loads of k-tile t+2 are issued right after the barrier that publishes tile t and stay in flight across
+//   the next barrier (counted s_waitcnt vmcnt(6): each thread owns 6 DMA instructions per tile), one raw s_barrier per k-tile.
+//   The LDS image is lane-linear per DMA instruction (8 rows x 128 B per wave instruction); the 16-B chunk XOR swizzle the
+//   ds_read_b128 fragment reads need is applied on the SOURCE address (lane l fetches chunk (l&7) ^ swz(row) of its row) and
+//   again on the read -- the destination stays linear (hardware writes base + lane*16).
+//   1 block per CU (144 KB of LDS), 2 waves per SIMD.  Epilogue: the 256x128 fp32 tile is parked in the (drained) ring and
+//   written out row-wise by the same fused chain as the 128x128 kernel.
+namespace big {
+constexpr int NTHR = 512, STAGES = 3;
+constexpr int A_BYTES = BM * KC_ROW_BYTES, B_BYTES = BN * KC_ROW_BYTES, STAGE = A_BYTES + B_BYTES;   // 32 KB + 16 KB
+constexpr int A_INSTR = BM * 8 / NTHR, B_INSTR = BN * 8 / NTHR;                                     // 4 + 2 DMA instructions / thread / tile
+constexpr int SMEM = STAGES * STAGE;                                                                // 147456 B (>= 256*128*4 for the epilogue)
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+template <int VARIANT, bool TA, bool TB, bool XCD_REMAP>
+__device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // tile mapping: same XCD-contiguous + grouped rasterisation as gemm_tile
+  const int nt = p.tiles_m * p.tiles_n;
+  int bid = block_id;
+  if constexpr (XCD_REMAP) {
+    int q = nt / 8, r = nt % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  constexpr int GM = 4;
+  const int group_sz = GM * p.tiles_n;
+  const int first_m = (bid / group_sz) * GM;
+  const int gm = min(GM, p.tiles_m - first_m);
+  const int rin = bid % group_sz;
+  const int tm = first_m + rin % gm, tn = rin / gm;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nk = p.K / BK;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;                   // wave tile: rows wm*64, cols wn*64
+
+  // ---- DMA addressing: instruction i of this wave covers tile rows (i*8 + wave)*8 .. +8, lane l -> row +(l>>3), LDS slot l&7
+  const bf16* a_src[A_INSTR];
+  const bf16* b_src[B_INSTR];
+#pragma unroll
+  for (int i = 0; i < A_INSTR; ++i) {
+    if constexpr (TA) {   // A = [K][M]: one instruction = 2 k-rows x 512 B; lane -> k-row (lane >> 5), LDS slot lane & 31 holds chunk c
+      const int kr = (i * 8 + wave) * 2 + (lane >> 5), pos = lane & 31;
+      const int c = (((pos >> 2) ^ (kr & 3)) << 2) | (pos & 3);
+      a_src[i] = p.A + (size_t)kr * p.lda + min(m0 + c * 8, p.M - 8);
+    } else {
+      const int r = (i * 8 + wave) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      a_src[i] = p.A + (size_t)min(m0 + r, p.M - 1) * p.lda + c * 8;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < B_INSTR; ++i) {
+    if constexpr (TB) {   // B = [K][N]: one instruction = 4 k-rows x 256 B; lane -> k-row (lane >> 4), LDS slot lane & 15 holds chunk c
+      const int kr = (i * 8 + wave) * 4 + (lane >> 4), pos = lane & 15;
+      const int c = (((pos >> 2) ^ (kr & 3)) << 2) | (pos & 3);
+      b_src[i] = p.B + (size_t)kr * p.ldb + min(n0 + c * 8, p.N - 8);
+    } else {
+      const int r = (i * 8 + wave) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      b_src[i] = p.B + (size_t)min(n0 + r, p.N - 1) * p.ldb + c * 8;
+    }
+  }
+  auto issue = [&](int kt, int stage) {
+    char* sa = smem + stage * STAGE;
+    char* sb = sa + A_BYTES;
+    const int koff = kt * BK;
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t*)(a_src[i] + (TA ? (size_t)koff * p.lda : (size_t)koff)), (lptr_t*)(sa + (i * 8 + wave) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t*)(b_src[i] + (TB ? (size_t)koff * p.ldb : (size_t)koff)), (lptr_t*)(sb + (i * 8 + wave) * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int stage) {
+    const char* la = smem + stage * STAGE;
+    const char* lb = la + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8 fx[2], fw[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fx[i] = TA ? frag_ks_dma<512>(la, wm * 64 + i * 32, kk, lane) : frag_kc(la, wm * 64 + i * 32, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fw[j] = TB ? frag_ks_dma<256>(lb, wn * 64 + j * 32, kk, lane) : frag_kc(lb, wn * 64 + j * 32, kk, lane);
+      if (VARIANT & 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fx[i], acc[i][j], 0, 0, 0);
+      if (VARIANT & 1) __builtin_amdgcn_s_setprio(0);
+    }
+  };
+
+  if constexpr ((VARIANT & 4) == 0) {
+    // ---- main loop: tile t lives in stage t % 3.  Every iteration issues exactly one tile (index clamped: the surplus loads of
+    // the last two iterations land in a stage nobody reads again), so "all but the newest tile have landed" is always vmcnt(6).
+    issue(0, 0);
+    issue(min(1, nk - 1), 1);
+    int st = 0;                                                // stage of tile t
+    for (int t = 0; t < nk; ++t) {
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");         // my DMA writes of tile t are in LDS (tile t+1 may still fly)
+      __builtin_amdgcn_s_barrier();                            // everybody's are; everybody finished reading tile t-1
+      asm volatile("" ::: "memory");
+      int st2 = st + 2; st2 = st2 >= 3 ? st2 - 3 : st2;
+      issue(min(t + 2, nk - 1), st2);                          // overwrites the stage tile t-1 was read from
+      compute(st);
+      st = st + 1 == 3 ? 0 : st + 1;
+    }
+  } else {
+    // ---- ping-pong main loop (VARIANT & 4).  The two waves of a SIMD (wave w of group 0 = waves 0..3, wave w+4 of group 1) take
+    // turns on the matrix pipe: every k-tile is two PHASES per group, R(t) = the 16 ds_read_b128 of the wave's whole k-tile (64
+    // fragment VGPRs) and M(t) = its 16 MFMAs with the LDS-DMA of a later tile issued between them; group 1 runs one phase behind
+    // group 0, every phase ends in one workgroup barrier:
+    //     phase 2t   : group 0 R(t)                 | group 1 M(t-1) + DMA(t+2)
+    //     phase 2t+1 : group 0 M(t) + DMA(t+2)      | group 1 R(t)
+    // so while one wave of a SIMD issues back-to-back MFMAs its partner collects operands, instead of both waves alternating
+    // ds_read -> s_waitcnt -> 4 MFMAs in lockstep (what the compiler makes of the plain loop).
+    // Ordering (3-stage ring, tile t in stage t % 3; group g's M(t) issues tile t+2+g, so every wave has exactly one tile newer
+    // than the one it must have landed and the wait is always vmcnt(6)):
+    //   RAW  every wave waits vmcnt(6) before the barrier that ends an ODD phase (group 0: after M(t)'s issue, group 1: in R(t)):
+    //        all shares of tile t+1 are then in LDS, the first read of tile t+1 is in phase 2t+2 (one barrier later).
+    //   WAR  R phases end with lgkmcnt(0) BEFORE their barrier; stage (t+2)%3 = stage of tile t-1 was last read in phase 2t-1 and
+    //        is overwritten from phase 2t+1 (group 0) / 2t (group 1, tile t+2 = (t-1)+3) on.
+    const int grp = wave >> 2;
+    issue(0, 0);
+    issue(min(1, nk - 1), 1);
+    if (grp) {
+      issue(min(2, nk - 1), 2);
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                              // tile 0 is in LDS for everybody
+    if (grp) __builtin_amdgcn_s_barrier();                     // group 1 idles through phase 0
+    int st = 0;
+    for (int t = 0; t < nk; ++t) {
+      // R(t)
+      const char* la = smem + st * STAGE;
+      const char* lb = la + A_BYTES;
+      bf16x8 fx[BK / 16][2], fw[BK / 16][2];
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fx[kk][i] = TA ? frag_ks_dma<512>(la, wm * 64 + i * 32, kk, lane) : frag_kc(la, wm * 64 + i * 32, kk, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fw[kk][j] = TB ? frag_ks_dma<256>(lb, wn * 64 + j * 32, kk, lane) : frag_kc(lb, wn * 64 + j * 32, kk, lane);
+      }
+      if (grp) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // M(t)
+      int sn = st + 2 + grp; sn = sn >= 3 ? sn - 3 : sn;
+      if (VARIANT & 1) __builtin_amdgcn_s_setprio(1);
+      issue(min(t + 2 + grp, nk - 1), sn);
+#pragma unroll
+      for (int kk = 0; kk < BK / 16; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[kk][j], fx[kk][i], acc[i][j], 0, 0, 0);
+      if (VARIANT & 1) __builtin_amdgcn_s_setprio(0);
+      if (!grp) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      st = st + 1 == 3 ? 0 : st + 1;
+    }
+    if (!grp) __builtin_amdgcn_s_barrier();                    // group 0 idles through the last phase (group 1's M(nk-1))
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // drain the surplus DMA before the ring is reused as the C tile
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // ---- epilogue (same chain as gemm_body, 512 threads, 256 x 128 tile)
+  DropCtx dc;
+  const bool drop = p.drop_p > 0.0f;
+  if (drop) dc = make_drop(p.drop_seed, p.drop_stream, p.drop_p);
+  constexpr int CH = BN / 4;
+  float* cl = reinterpret_cast<float*>(smem);
+  static_for(std::make_integer_sequence<int, 2 * 2 * 4>{}, [&](auto idx) {
+    constexpr int i = decltype(idx)::value / 8, j = (decltype(idx)::value / 4) % 2, g = decltype(idx)::value % 4;
+    const int ml = wm * 64 + i * 32 + (lane & 31);
+    const int c = (wn * 64 + j * 32 + g * 8 + (lane >> 5) * 4) >> 2;
+    f32x4 v = {acc[i][j][g * 4 + 0] * p.alpha, acc[i][j][g * 4 + 1] * p.alpha, acc[i][j][g * 4 + 2] * p.alpha,
+               acc[i][j][g * 4 + 3] * p.alpha};
+    *reinterpret_cast<f32x4*>(cl + ml * BN + ((c ^ (ml & (CH - 1))) << 2)) = v;
+  });
+  __syncthreads();
+  tile_writeout<BM, BN, NTHR>(p, cl, m0, n0, false, drop, dc);
+}
+
+template <int VARIANT, bool TA, bool TB>
+__global__ __launch_bounds__(NTHR) void gemm_big_kernel(GemmParams p) {
+  big_tile<VARIANT, TA, TB, true>(p, blockIdx.x);
+}
+
+template <int VARIANT, bool TA, bool TB>
+int launch(const GemmParams& p, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<VARIANT, TA, TB>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_big_kernel<VARIANT, TA, TB>), dim3(p.tiles_m * p.tiles_n), dim3(NTHR), SMEM, s, p);
+  PH_LAUNCH_CHECK("gemm_big_kernel");
+  return PH_OK;
+}
+}  // namespace big
+
+// Grouped launch on the 256x128 ping-pong kernel (weight-gradient layout, long reductions): a persistent grid of one block per CU
+// walks the tiles round by round; within a round the XCD-contiguous numbering of gemm_tile is kept (tiles that share an operand
+// panel run on one XCD at the same time).
+namespace big {
+template <int VARIANT, bool TA, bool TB>
+__global__ __launch_bounds__(NTHR) void gemm_big_grouped_kernel(GroupParams g) {
+  const int total = g.tile_start[g.n], grid = gridDim.x;
+  int i = 0;
+  for (int base = 0; base < total; base += grid) {
+    const int cnt = min(grid, total - base);
+    if ((int)blockIdx.x >= cnt) break;
+    const int q = cnt / 8, r = cnt % 8, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+    const int t = base + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    while (i + 1 < g.n && t >= g.tile_start[i + 1]) ++i;
+    big_tile<VARIANT, TA, TB, false>(g.p[i], t - g.tile_start[i]);
+    __syncthreads();                     // the write-out's LDS staging area is the next tile's DMA ring
+  }
+}
+template <int VARIANT, bool TA, bool TB>
+int launch_grouped(const GroupParams& g, int total, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_grouped_kernel<VARIANT, TA, TB>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_big_grouped_kernel<VARIANT, TA, TB>), dim3(total < 256 ? total : 256), dim3(NTHR), SMEM, s, g);
+  PH_LAUNCH_CHECK("gemm_big_grouped_kernel");
+  return PH_OK;
+}
+}  // namespace big
+
+namespace big {
+int launch_single(const GemmParams& p, int variant, bool ta, bool tb, hipStream_t s) {
+  if (ta) return launch<4, true, true>(p, s);                      // weight-gradient layout: ping-pong only
+  if (tb) return variant == 0 ? launch<0, false, true>(p, s) : variant == 5 ? launch<5, false, true>(p, s) : launch<4, false, true>(p, s);
+  return variant == 0 ? launch<0, false, false>(p, s) : variant == 5 ? launch<5, false, false>(p, s) : launch<4, false, false>(p, s);
+}
+int launch_grouped_wgrad(const GroupParams& g, int total, hipStream_t s) { return launch_grouped<4, true, true>(g, total, s); }
+}  // namespace big
+
+}  // namespace phg
