@@ -559,4 +559,29 @@ class Trainer:
         return self.loss_buf
 
     def state_dict(self):
-        return dict(it=self.it, m=[t.clone() for t in self.m], v=[t.clone() for t in self.v], model=self.model.state_dict())
+        """model + optimizer + RNG: what `accelerator.save_state` writes (train_caption.py:174; the reference itself only ever reloads
+        the model weights, train_caption.py:103-108).  With shard_optimizer the Adam moments are this rank's slice."""
+        return dict(it=self.it, m=[t.clone() for t in self.m], v=[t.clone() for t in self.v],
+                    model={k: t.detach().clone() for k, t in self.model.state_dict().items()},      # (state_dict() aliases the live buffers)
+                    seed=self.seed.clone(), rng=random.getstate(), world=self.world, shard_optimizer=self.shard)
+
+    def load_state_dict(self, sd, strict=True):
+        """resume: masters (the module parameters are views of the flat buffers), bf16 shadows and derived conv shadows re-derived from
+        them, Adam moments, iteration counter (LR schedule position), dropout seed and Python RNG (instance-embedding draws).  Captured
+        graphs stay valid: they reference the buffers, not their contents."""
+        if bool(sd.get("shard_optimizer", False)) != self.shard or (self.shard and sd.get("world", 1) != self.world):
+            raise ValueError('Trainer.load_state_dict: optimizer sharding of the checkpoint '
+                             f"(shard_optimizer={sd.get('shard_optimizer')}, world={sd.get('world')}) differs from this Trainer's")
+        if len(sd['m']) != len(self.m) or any(a.shape != b.shape for a, b in zip(sd['m'] + sd['v'], self.m + self.v)):
+            raise ValueError('Trainer.load_state_dict: Adam moment buffers do not match this model / freeze configuration')
+        self.model.load_state_dict(sd['model'], strict=strict)
+        for st in self.stores:
+            st.refresh()
+        for dst, src in zip(self.m + self.v, list(sd['m']) + list(sd['v'])):
+            dst.copy_(src)
+        self.it = int(sd['it'])
+        if 'seed' in sd:
+            self.seed.copy_(sd['seed'])
+        if 'rng' in sd:
+            random.setstate(sd['rng'])
+        torch.cuda.synchronize(self.device)

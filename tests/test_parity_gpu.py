@@ -476,6 +476,47 @@ def test_trainer_graph_equals_eager_first_step():
         assert rel_fro(tb, ta) < 5e-3                           # same kernels; fp32 atomics order differs between runs
 
 
+def test_trainer_resume_from_state_dict():
+    """Trainer.state_dict / load_state_dict (the content of accelerate's save_state, train_caption.py:174: model + optimizer + RNG):
+    a second Trainer that has already diverged (one step on its own), loaded with the state after two steps of the first, takes the
+    same third step -- loss, parameters, Adam moments, BatchNorm buffers, iteration counter, dropout seed."""
+    from prismer_amd.trainer import Trainer
+    case = C.Case('tiny_caption')
+    x, ids, mask, labels, _ = case.inputs()
+
+    def make():
+        enc, dec, _, _ = build(case)
+        set_freeze(enc, dec)
+        dec._seed = torch.tensor([1234567], dtype=torch.int64, device='cuda')
+        m = _Holder(); m.expert_encoder, m.text_decoder = enc, dec
+        tr = Trainer(m, lr=1e-3, total_steps=10, use_graph=True)
+        tr.set_batch(to_dev(x), ids, mask, labels)
+        return tr, enc
+
+    tr_a, enc_a = make()
+    random.seed(99)
+    for _ in range(2):
+        tr_a.step()
+    torch.cuda.synchronize()
+    sd = tr_a.state_dict()
+    loss_a = tr_a.step().item()
+    tr_b, enc_b = make()
+    random.seed(5)
+    tr_b.step()                                                  # its own first step: every piece of state now differs from sd
+    tr_b.load_state_dict(sd)
+    assert tr_b.it == 2 and int(tr_b.seed.item()) == int(sd['seed'].item())
+    loss_b = tr_b.step().item()
+    torch.cuda.synchronize()
+    assert tr_a.it == tr_b.it == 3 and int(tr_a.seed.item()) == int(tr_b.seed.item())
+    assert math_close(loss_a, loss_b, 1e-3), (loss_a, loss_b)
+    for ta, tb in zip([st.master for st in tr_a.stores] + tr_a.m + tr_a.v + [b.float() for b in enc_a.buffers()],
+                      [st.master for st in tr_b.stores] + tr_b.m + tr_b.v + [b.float() for b in enc_b.buffers()]):
+        assert rel_fro(tb, ta) < 5e-3
+    with pytest.raises(ValueError):
+        bad = dict(sd); bad['m'] = sd['m'][:-1] if len(sd['m']) > 1 else [sd['m'][0][:-1]]
+        tr_b.load_state_dict(bad)
+
+
 def test_set_batch_pads_text_and_rejects_other_shapes():
     case = C.Case('tiny_caption')
     tr, _ = _pinned_trainer(case, use_graph=False, max_text_len=16)
