@@ -224,6 +224,20 @@ def test_gemm_grouped_big_tile_wgrad(shapes, ops):
     assert rel_fro(gw - c0[0], refs[0]) < 3e-4
 
 
+def test_gemm_grouped_streamk_in_subprocess():
+    """the stream-K path is selected by environment variables the library reads once, and it is off by default -- so the default
+    suite runs its tests (below) in a child process with the switches set; the child's failures are this test's failure."""
+    import subprocess
+    import sys
+    if os.environ.get('PH_GEMM_STREAMK', '0') != '0':
+        pytest.skip('already running with stream-K enabled')
+    env = dict(os.environ, PH_GEMM_STREAMK='1', PH_GEMM_STREAMK_MIN_KT='16', PH_GEMM_BIG_GROUPED='0')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-m', 'gpu', '-k', 'test_gemm_grouped_streamk and not subprocess',
+                        '-p', 'no:cacheprovider'], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and ' passed' in r.stdout and 'skipped' not in r.stdout.splitlines()[-1], r.stdout[-2000:] + r.stderr[-1000:]
+
+
 @pytest.mark.parametrize('shapes,ta', [
     ([(1536, 768, 9920)] * 2, True),                 # 144 tiles x 155 k-tiles: under-filled first round (the resampler K/V weight gradients)
     ([(768, 768, 4160)] * 16 + [], True),            # 576 tiles: 1.125 rounds
