@@ -401,7 +401,7 @@ __device__ __forceinline__ void epi_apply8(const GemmParams& p, int m, int n, fl
 
 // Row-wise write-out of a BM x BN fp32 tile parked in LDS (16-B chunks XOR-swizzled by the row): consecutive lanes own
 // consecutive 16/32-B pieces of one output row for every load / store of the fused epilogue chain.
-template <int BM, int BN, int NTHR>
+template <int BM, int BN, int NTHR, int GCAP = 4>      // GCAP: cap on the prefetch group (register budget of the caller)
 __device__ __forceinline__ void tile_writeout(const GemmParams& p, const float* cl, int m0, int n0, bool splitk, bool drop,
                                               const DropCtx& dc, const float* cl2 = nullptr) {   // cl2: second partial tile to add (KS = 2)
   constexpr int CH = BN / 4;                       // 16-B chunks per tile row
@@ -412,7 +412,7 @@ __device__ __forceinline__ void tile_writeout(const GemmParams& p, const float* 
   if (vec8) {
     // steps per thread; steps per load group (16 VGPRs of prefetched inputs per step: 4 for the 512-thread kernel, whose register budget
     // is 256/lane at its occupancy; 2 for the 256-thread kernels, which must stay under 192 + 64 accumulators for 2 blocks per CU)
-    constexpr int IT = BM * CH / (2 * NTHR), G = (NTHR >= 512 && IT % 4 == 0) ? 4 : (IT % 2 == 0 ? 2 : 1);
+    constexpr int IT = BM * CH / (2 * NTHR), G = (NTHR >= 512 && IT % 4 == 0 && GCAP >= 4) ? 4 : ((IT % 2 == 0 && GCAP >= 2) ? 2 : 1);
     for (int it0 = 0; it0 < IT; it0 += G) {
       EpiIn in[G];                  // (indexed with compile-time constants only and fully initialised: stays in VGPRs)
       static_for(std::make_integer_sequence<int, G>{}, [&](auto uu) {

@@ -94,6 +94,15 @@ def case(name, M, N, K, bias=True, act=0, pre=False, residual=False, f32res=Fals
 
 if __name__ == '__main__':
     torch.manual_seed(0)
+    if os.environ.get('BIG_WIDE_ONLY'):          # the wide-N, short-K launches of the step
+        case('vit fc 8320x3072x768 qgelu+pre', 8320, 3072, 768, act=ACT_QUICKGELU, pre=True)
+        case('vit qkv 8320x2304x768', 8320, 2304, 768)
+        case('dgrad proj 8320x3072x768 *g', 8320, 3072, 768, bias=False, tb=True, act_in=True)
+        case('resampler kv 39680x1536x768', 39680, 1536, 768)
+        case('cross kv all 8320x18432x768', 8320, 18432, 768)
+        case('vit out 8320x768x768 +res', 8320, 768, 768, residual=True)
+        _lib.lib.ph_gemm_tuning(5, 128)
+        sys.exit(0)
     if os.environ.get('BIG_ONLY_FC'):
         case('vit fc 8320x3072x768 qgelu+pre', 8320, 3072, 768, act=ACT_QUICKGELU, pre=True)
         case('vit fc 8320x3072x768 qgelu (one output)', 8320, 3072, 768, act=ACT_QUICKGELU)
