@@ -252,33 +252,6 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupParams g) {
 
 
 
-// Stream-K form of the grouped launch, for groups of plain fp32-accumulate problems (the deferred weight gradients: dW += dY^T X):
-// the work is the flat iteration space (problem, tile, k-tile); gridDim.x workers -- one per block slot of the chip -- each take an
-// equal contiguous slice of it, whatever the tile count.  A worker therefore runs at most one tail of a tile, some whole tiles and one
-// head of a tile; a tile whose k range is shared adds its partial sums with fp32 atomics (the gradient buffers are fp32 accumulators
-// anyway), a tile owned by one worker keeps the plain read-add-write epilogue.  Without this a group of 288 tiles x 620 k-tiles (the
-// resampler's K/V weight gradients) put two blocks on 32 CUs and one on the rest and ran at the pace of the doubled-up CUs, and
-// 1152-tile groups paid three block rounds for 2.25 rounds of work.  Workers are numbered XCD-contiguously (hardware places block b on
-// XCD b % 8) so that neighbouring tiles -- which share operand panels -- meet in one L2.
-template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0>
-__global__ __launch_bounds__(256) void gemm_streamk_kernel(GroupParams g) {
-  const int W = gridDim.x, q = W / 8, r = W % 8, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
-  const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  int it = w * g.iters_per_worker;
-  const int it_end = min(it + g.iters_per_worker, g.iter_start[g.n]);
-  int i = 0;
-  while (it < it_end) {
-    while (i + 1 < g.n && it >= g.iter_start[i + 1]) ++i;
-    const int kt = g.p[i].k_tiles_per_split;
-    const int local = it - g.iter_start[i];
-    const int tile = local / kt, k0 = local - tile * kt;
-    const int k1 = min(kt, k0 + (it_end - it));
-    gemm_tile<BM, BN, TA, TB, PF, CONV, false>(g.p[i], tile, k0, k1, !(k0 == 0 && k1 == kt));
-    __syncthreads();                     // the epilogue's LDS staging area is the next unit's stage buffer
-    it += k1 - k0;
-  }
-}
-
 // folds the split-K partials and applies the fused epilogue (bias / activation / dropout / residual / accumulate / dtype)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int splits) {
   const int n4 = (p.N + 3) / 4;
@@ -415,18 +388,8 @@ static int fill_params(const ph_gemm_args* a, GemmParams& p) {
 }
 
 template <int BM, bool TA, bool TB, int PF, int CONV = 0>
-static int launch_grouped(const GroupParams& g, int total, int max_blocks, int workers, hipStream_t s) {
+static int launch_grouped(const GroupParams& g, int total, int max_blocks, hipStream_t s) {
   constexpr int smem = 2 * ((TA ? TileBytes<BM>::ks : TileBytes<BM>::kc) + (TB ? TileBytes<BM>::ks : TileBytes<BM>::kc));
-  if (workers > 0) {                    // stream-K: `workers` blocks share the flat (tile, k-tile) iteration space equally
-    static bool attr_sk = false;
-    if (!attr_sk) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_streamk_kernel<BM, BM, TA, TB, PF, CONV>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-      attr_sk = true;
-    }
-    hipLaunchKernelGGL((gemm_streamk_kernel<BM, BM, TA, TB, PF, CONV>), dim3(workers), dim3(256), smem, s, g);
-    PH_LAUNCH_CHECK("gemm_streamk_kernel");
-    return PH_OK;
-  }
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<BM, BM, TA, TB, PF, CONV>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -438,11 +401,11 @@ static int launch_grouped(const GroupParams& g, int total, int max_blocks, int w
   return PH_OK;
 }
 template <int BM, int PF>
-static int launch_grouped_layout(const GroupParams& g, int total, int max_blocks, int workers, int ta, int tb, hipStream_t s) {
-  if (!ta && !tb) return launch_grouped<BM, false, false, PF>(g, total, max_blocks, workers, s);
-  if (!ta && tb) return launch_grouped<BM, false, true, PF>(g, total, max_blocks, workers, s);
-  if (ta && tb) return launch_grouped<BM, true, true, PF>(g, total, max_blocks, workers, s);
-  return launch_grouped<BM, true, false, PF>(g, total, max_blocks, workers, s);
+static int launch_grouped_layout(const GroupParams& g, int total, int max_blocks, int ta, int tb, hipStream_t s) {
+  if (!ta && !tb) return launch_grouped<BM, false, false, PF>(g, total, max_blocks, s);
+  if (!ta && tb) return launch_grouped<BM, false, true, PF>(g, total, max_blocks, s);
+  if (ta && tb) return launch_grouped<BM, true, true, PF>(g, total, max_blocks, s);
+  return launch_grouped<BM, true, false, PF>(g, total, max_blocks, s);
 }
 
 extern "C" int ph_gemm_grouped_bf16(const ph_gemm_args* args, int n, hipStream_t stream) {
@@ -516,52 +479,24 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
           tot += g.p[i].tiles_m * g.p[i].tiles_n;
         }
         g.tile_start[n] = tot;
-        g.iters_per_worker = 0;
         return big::launch_grouped_wgrad(g, tot, stream);
       }
-    }
-  }
-  // ---- stream-K for plain fp32-accumulate groups whose tile count does not fill whole block rounds (see gemm_streamk_kernel) ----
-  int workers = 0;
-  g.iters_per_worker = 0;
-  {
-    static int sk = -1;                 // PH_GEMM_STREAMK=1 enables it.  OFF by default: measured in the step (profiles/r2_ab_step_switches.txt) the
-                                        // fp32 atomics of the shared tiles cost more than the balance gains (+0.3 .. +1.6 ms per step)
-    if (sk < 0) { const char* e = getenv("PH_GEMM_STREAMK"); sk = e ? atoi(e) : 0; }
-    static int sk_min_kt = -1;          // PH_GEMM_STREAMK_MIN_KT: only groups whose reductions are at least this many k-tiles long
-    if (sk_min_kt < 0) { const char* e = getenv("PH_GEMM_STREAMK_MIN_KT"); sk_min_kt = e ? atoi(e) : 64; }
-    bool plain = sk != 0 && max_blocks == 0;
-    int64_t iters = 0;
-    for (int i = 0; i < n; ++i) {
-      const ph_gemm_args& a = args[i];
-      plain = plain && g.p[i].k_tiles_per_split >= sk_min_kt && !a.bias && !a.pre_out && !a.act_in && a.act == PH_ACT_NONE && !a.residual && !(a.drop_p > 0.0f) && a.out_f32 &&
-              a.accumulate && !a.col_stats && a.alpha == 1.0f;
-      g.iter_start[i] = (int)iters;
-      iters += (int64_t)g.p[i].tiles_m * g.p[i].tiles_n * g.p[i].k_tiles_per_split;
-    }
-    g.iter_start[n] = (int)iters;
-    const int slots = BMsel == 128 ? 512 : 1024;          // co-resident blocks of the chip: 2 (128x128) / 4 (64x64) per CU
-    const double rounds = (double)total / slots;
-    const double waste = ceil(rounds) / rounds - 1.0;      // idle share of the last block round (incl. a first round that is not full)
-    if (plain && iters < (1ll << 30) && waste > 0.08 && iters >= 8ll * slots) {
-      workers = slots;
-      g.iters_per_worker = (int)ceil_div64(iters, (int64_t)workers);
     }
   }
   const int ta = args[0].trans_a, tb = args[0].trans_b;
   if (conv) {               // gathered operand: forward (NN, A = im2col view) or weight gradient (TT, B = im2col view); no prefetch ring
     PH_CHECK_ARG(ta == tb, "ph_gemm_grouped_bf16: conv gather needs the NN or the TT layout");
-    if (!ta) return BMsel == 128 ? launch_grouped<128, false, false, 1, 1>(g, total, max_blocks, workers, stream)
-                                 : launch_grouped<64, false, false, 1, 1>(g, total, max_blocks, workers, stream);
-    return BMsel == 128 ? launch_grouped<128, true, true, 1, 2>(g, total, max_blocks, workers, stream)
-                        : launch_grouped<64, true, true, 1, 2>(g, total, max_blocks, workers, stream);
+    if (!ta) return BMsel == 128 ? launch_grouped<128, false, false, 1, 1>(g, total, max_blocks, stream)
+                                 : launch_grouped<64, false, false, 1, 1>(g, total, max_blocks, stream);
+    return BMsel == 128 ? launch_grouped<128, true, true, 1, 2>(g, total, max_blocks, stream)
+                        : launch_grouped<64, true, true, 1, 2>(g, total, max_blocks, stream);
   }
   if (BMsel == 128) {
-    if (kfull && PH_RING128 > 1 && !ta) return launch_grouped_layout<128, PH_RING128>(g, total, max_blocks, workers, ta, tb, stream);
-    return launch_grouped_layout<128, 1>(g, total, max_blocks, workers, ta, tb, stream);
+    if (kfull && PH_RING128 > 1 && !ta) return launch_grouped_layout<128, PH_RING128>(g, total, max_blocks, ta, tb, stream);
+    return launch_grouped_layout<128, 1>(g, total, max_blocks, ta, tb, stream);
   }
-  if (kfull && PH_RING64 > 1) return launch_grouped_layout<64, PH_RING64>(g, total, max_blocks, workers, ta, tb, stream);
-  return launch_grouped_layout<64, 1>(g, total, max_blocks, workers, ta, tb, stream);
+  if (kfull && PH_RING64 > 1) return launch_grouped_layout<64, PH_RING64>(g, total, max_blocks, ta, tb, stream);
+  return launch_grouped_layout<64, 1>(g, total, max_blocks, ta, tb, stream);
 }
 
 extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {

@@ -493,8 +493,6 @@ __device__ __forceinline__ void tile_colstats(const GemmParams& p, const float* 
 struct GroupParams {
   int n;
   int tile_start[PH_GEMM_GROUP_MAX + 1];
-  int iter_start[PH_GEMM_GROUP_MAX + 1];   // stream-K launches: prefix sums of tiles x k-tiles per problem
-  int iters_per_worker;                    // stream-K launches: length of one worker's slice of that iteration space
   GemmParams p[PH_GEMM_GROUP_MAX];
 };
 

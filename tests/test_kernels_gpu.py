@@ -224,64 +224,6 @@ def test_gemm_grouped_big_tile_wgrad(shapes, ops):
     assert rel_fro(gw - c0[0], refs[0]) < 3e-4
 
 
-def test_gemm_grouped_streamk_in_subprocess():
-    """the stream-K path is selected by environment variables the library reads once, and it is off by default -- so the default
-    suite runs its tests (below) in a child process with the switches set; the child's failures are this test's failure."""
-    import subprocess
-    import sys
-    if os.environ.get('PH_GEMM_STREAMK', '0') != '0':
-        pytest.skip('already running with stream-K enabled')
-    env = dict(os.environ, PH_GEMM_STREAMK='1', PH_GEMM_STREAMK_MIN_KT='16', PH_GEMM_BIG_GROUPED='0')
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-m', 'gpu', '-k', 'test_gemm_grouped_streamk and not subprocess',
-                        '-p', 'no:cacheprovider'], env=env, capture_output=True, text=True, timeout=600,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0 and ' passed' in r.stdout and 'skipped' not in r.stdout.splitlines()[-1], r.stdout[-2000:] + r.stderr[-1000:]
-
-
-@pytest.mark.parametrize('shapes,ta', [
-    ([(1536, 768, 9920)] * 2, True),                 # 144 tiles x 155 k-tiles: under-filled first round (the resampler K/V weight gradients)
-    ([(768, 768, 4160)] * 16 + [], True),            # 576 tiles: 1.125 rounds
-    ([(384, 768, 2048), (768, 384, 2048), (104, 200, 2048)] * 2, True),     # 64x64 tiles, ragged
-    ([(1536, 768, 1024)] * 8, False),                # NN layout (A = [M,K], B = [K,N])
-])
-def test_gemm_grouped_streamk(shapes, ta, ops):
-    """stream-K form of the grouped launch (plain fp32-accumulate groups that do not fill whole block rounds): workers take equal
-    slices of the (tile, k-tile) iteration space, shared tiles are combined with fp32 atomics -- same sums as the tile-per-block
-    launch (PH tile path forced through the capped entry point with a huge cap) and as fp32 torch, on top of a non-zero accumulator."""
-    from prismer_amd import _lib
-    if os.environ.get('PH_GEMM_STREAMK', '0') == '0':
-        pytest.skip('stream-K grouped launches are off by default (PH_GEMM_STREAMK=1 PH_GEMM_BIG_GROUPED=0 enables the path)')
-    shapes = shapes[:_lib.GEMM_GROUP_MAX]
-    ops_, refs = [], []
-    for i, (M, N, K) in enumerate(shapes):
-        if ta:
-            a_, b_ = rnd(K, M, scale=0.3, seed=20 + i), rnd(K, N, scale=0.3, seed=40 + i)
-            refs.append(a_.float().t() @ b_.float())
-        else:
-            a_, b_ = rnd(M, K, scale=0.3, seed=20 + i), rnd(K, N, scale=0.3, seed=40 + i)
-            refs.append(a_.float() @ b_.float())
-        ops_.append((a_, b_, torch.empty(M, N, device='cuda')))
-    c0 = [torch.randn_like(o[2]) for o in ops_]
-    results = []
-    for cap in (0, 1 << 30):                         # 0: default policy (stream-K for these groups); huge cap: one block per tile
-        arr = (_lib.GemmArgs * len(shapes))()
-        for g, (a_, b_, gw), c in zip(arr, ops_, c0):
-            gw.copy_(c)
-            g.A, g.B, g.C = a_.data_ptr(), b_.data_ptr(), gw.data_ptr()
-            g.M, g.N, g.K = gw.shape[0], gw.shape[1], a_.shape[0] if ta else a_.shape[1]
-            g.lda, g.ldb, g.ldc = a_.stride(0), b_.stride(0), gw.stride(0)
-            g.trans_a, g.trans_b, g.out_f32, g.accumulate, g.alpha = int(ta), 1, 1, 1, 1.0
-        for rep in range(3 if cap == 0 else 1):
-            for (a_, b_, gw), c in zip(ops_, c0):
-                gw.copy_(c)
-            _lib.check(_lib.lib.ph_gemm_grouped_capped_bf16(arr, len(shapes), cap, torch.cuda.current_stream().cuda_stream), 'grouped')
-            for (a_, b_, gw), ref, c in zip(ops_, refs, c0):
-                assert rel_fro(gw - c, ref) < 3e-4, (cap, rep, rel_fro(gw - c, ref))
-        results.append([o[2].clone() for o in ops_])
-    for x, y in zip(*results):
-        assert rel_fro(x, y) < 1e-5
-
-
 @pytest.mark.parametrize('M,N,K,tb', [(960, 768, 768, False), (960, 768, 3072, True), (960, 2304, 832, False), (200, 136, 512, True)])
 def test_gemm_intra_block_k_split(ops, M, N, K, tb):
     """gemm_ks2_kernel (64x64 tiles, 512 threads, two thread groups on alternate k-tiles, partial tiles summed by the write-out): the
