@@ -18,7 +18,7 @@ PEAK_TF, HBM_TBS = 2500.0, 8.0
 
 
 def short(n):
-    n = re.sub(r'\(anonymous namespace\)::', '', n or ''); n = re.sub(r'\(.*\)$', '', n); n = re.sub(r'^void ', '', n)
+    n = re.sub(r'\(anonymous namespace\)::|phg::', '', n or ''); n = re.sub(r'\(.*\)$', '', n); n = re.sub(r'^void ', '', n)
     return n[:90]
 
 

@@ -14,7 +14,7 @@ rows = list(cur.execute("select name, count(*), sum(end-start), avg(end-start), 
 tot = sum(r[2] for r in rows)
 steps = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
 def short(n):
-    n = re.sub(r'\(anonymous namespace\)::', '', n); n = re.sub(r'\(.*\)$', '', n); n = re.sub(r'^void ', '', n)
+    n = re.sub(r'\(anonymous namespace\)::|phg::', '', n); n = re.sub(r'\(.*\)$', '', n); n = re.sub(r'^void ', '', n)
     return n[:100]
 if len(sys.argv) > 2 and sys.argv[2] != '-':
     with open(sys.argv[2], 'w', newline='') as f:
