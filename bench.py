@@ -303,7 +303,7 @@ def main():
             fam = kernel_family_pass(tr, min(args.steps, 5))
             g = fam['gemm']
             ach = g['tflop_per_step'] / (g['ms_per_step'] / 1e3) if g['ms_per_step'] > 0 else 0.0
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_kernel<*> (all bf16 MFMA GEMM launches of one step)',
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_*kernel<*> (all bf16 MFMA GEMM launches of one step: gemm_kernel, gemm_ks2_kernel, gemm_grouped_kernel, big::gemm_big_kernel, big::gemm_big_grouped_kernel)',
                                'achieved': round(ach, 1), 'peak': PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_TFLOPS, 4),
                                'traffic': pmc_traffic()[0], 'traffic_source': pmc_traffic()[1], 'algorithmic_bytes_per_launch': round(g['gbytes_per_step'] * 1e9 / max(g['launches_per_step'], 1)),
                                'avg_launch_us': round(g['ms_per_step'] * 1e3 / max(g['launches_per_step'], 1), 2),
