@@ -111,3 +111,21 @@ def test_model_detects_a_too_shallow_wait():
             me.run(8)
     finally:
         me.schedule = orig
+
+
+def test_model_constants_match_the_kernel_source():
+    """the model above and gemm_big.hip must describe the same schedule: DMA instructions per tile, the counted waits, the tile each
+    group issues in its M phase, the skew barrier of group 1 and the trailing one of group 0"""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'prismer_amd', 'csrc', 'gemm_big.hip')).read()
+    m = re.search(r'constexpr int A_INSTR = BM \* 8 / NTHR, B_INSTR = BN \* 8 / NTHR;', src)
+    assert m and 'constexpr int NTHR = 512' in src
+    assert (256 * 8 + 128 * 8) // 512 == DMA_PER_TILE
+    body = src[src.index('// ---- ping-pong main loop'):src.index('drain the surplus DMA')]
+    assert body.count(f'"s_waitcnt vmcnt({DMA_PER_TILE})"') == 2                  # group 0 prologue, group 0 after M(t)
+    assert body.count(f'"s_waitcnt vmcnt({DMA_PER_TILE}) lgkmcnt(0)"') == 1       # group 1 at the end of R(t)
+    assert body.count(f'"s_waitcnt vmcnt({2 * DMA_PER_TILE})"') == 1              # group 1 prologue (three tiles issued)
+    assert 'issue(min(t + 2 + grp, nk - 1), sn)' in body and 'int sn = st + 2 + grp' in body
+    assert 'if (grp) __builtin_amdgcn_s_barrier();' in body and 'if (!grp) __builtin_amdgcn_s_barrier();' in body
+    assert body.count('__builtin_amdgcn_s_barrier()') == 5                        # B0, skew, end of R, end of M, trailing
