@@ -52,7 +52,13 @@ const char* ph_last_error(void);
  * operand loader, never written to memory.  Forward (trans_a = trans_b = 0): A = x, M = B*Ho*Wo, K = ks*ks*C rounded up to 8
  * (B = the [Cout][K] weight shadow).  Weight gradient (trans_a = trans_b = 1): B = x, reduction K = B*Ho*Wo, N = ks*ks*C rounded
  * up to 8 (A = dY [K][Cout]).  lda / ldb of the gathered operand are ignored. */
-typedef struct { int B, H, W, C, ks, stride; } ph_conv_gather;
+typedef struct {
+  int B, H, W, C, ks, stride;
+  /* round 3 -- generalised window (data gradients of the convolutions, gathered from dY): kh x kw taps, tap (ty, tx) reads pixel
+   * (oy * stride + off_y + ty, ox * stride + off_x + tx), k = (ty * kw + tx) * C + c, output grid Ho x Wo.  kh == 0 (all six zero):
+   * the square ks x ks window with pad ks / 2 described above.  Forward-shaped (A) gathers only. */
+  int kh, kw, off_y, off_x, Ho, Wo;
+} ph_conv_gather;
 #define PH_COLSTAT_SLABS 8
 
 typedef struct {
@@ -82,6 +88,10 @@ typedef struct {
                                      epilogue instead of a second pass over the output); plain epilogues, no split-K.  The
                                      accumulators are replicated PH_COLSTAT_SLABS times (a block adds to slab id % SLABS) to
                                      spread the atomics; consumers sum the slabs */
+  /* round 3 -- output row map (rowmap_wo > 0): result row m is stored at C row  m * rowmap_mul - (m % rowmap_wo) * rowmap_sub +
+   * rowmap_add  (the other row-indexed operands keep row m).  The data gradient of a stride-2 convolution is computed per parity
+   * class of the input pixel: row m = (b, a, c) of class (py, px) is pixel (2a + py, 2c + px) = row 4m - 2(m % Wo) + py * W + px. */
+  int rowmap_wo, rowmap_mul, rowmap_sub, rowmap_add;
 } ph_gemm_args;
 int ph_gemm_bf16(const ph_gemm_args* args, hipStream_t stream);
 
@@ -316,6 +326,18 @@ int ph_conv_grad_from_shadow(const float* dshadow, float* dw, int Cout, int Cin,
 typedef struct { const float* src; void* dst; int Cout, Cin, ks, Kp; } ph_conv_layout_item;
 int ph_conv_weight_to_shadow_grouped(const ph_conv_layout_item* items, int n, hipStream_t stream);
 int ph_conv_grad_from_shadow_grouped(const ph_conv_layout_item* items, int n, hipStream_t stream);
+/* Weight operand of the IMPLICIT data gradient of a 3x3 (pad 1) convolution (round 3; replaces dcol = dY . W + col2im):
+ *   dst bf16 [Cin][9 * Cout], dst[ci][t * Cout + co] = w[co][ci][ky(t)][kx(t)]
+ *   stride 1: t = ty * 3 + tx, (ky, kx) = (2 - ty, 2 - tx): dX = conv3x3(dY, pad 1) with this matrix as the [N = Cin][K] operand
+ *   stride 2: the taps of the four parity classes (py, px) of the input pixel back to back -- class (0,0): t = 0; (0,1): t = 1..2;
+ *             (1,0): t = 3..4; (1,1): t = 5..8 -- tap (ty, tx) of a class reads dY[a + ty][c + tx] and stands for
+ *             ky = py ? (ty ? 0 : 2) : 1, kx = px ? (tx ? 0 : 2) : 1.  Class GEMM: A = dY gathered with a (1 + py) x (1 + px)
+ *             window at offset 0, stride 1; B = dst + toff * Cout (ldb = 9 * Cout, K = ntaps * Cout); C = dX through rowmap_*. */
+typedef struct { const float* w; void* dst; int Cout, Cin, stride; } ph_conv_dgrad_item;
+int ph_conv_dgrad_shadow_grouped(const ph_conv_dgrad_item* items, int n, hipStream_t stream);
+/* launches per GEMM kernel class since the last reset (128x128, 64x64, intra-block k split, 256x128 single, 256x128 grouped,
+ * grouped 128/64, split-K reduce): out[0..n-1]; returns the number of classes.  Lets a test assert which kernels a program ran. */
+int ph_gemm_dispatch_counts(int64_t* out, int n, int reset);
 /* advance the dropout seed (device-side, graph-replay safe): seed[0] = splitmix(seed[0]) */
 int ph_advance_seed(uint64_t* seed, hipStream_t stream);
 

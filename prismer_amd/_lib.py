@@ -26,7 +26,8 @@ IDENT = RowMap(0, 0, 0)
 
 
 class ConvGather(C.Structure):
-    _fields_ = [('B', c_int), ('H', c_int), ('W', c_int), ('C', c_int), ('ks', c_int), ('stride', c_int)]
+    _fields_ = [('B', c_int), ('H', c_int), ('W', c_int), ('C', c_int), ('ks', c_int), ('stride', c_int),
+                ('kh', c_int), ('kw', c_int), ('off_y', c_int), ('off_x', c_int), ('Ho', c_int), ('Wo', c_int)]
 
 
 class GemmArgs(C.Structure):
@@ -41,7 +42,12 @@ class GemmArgs(C.Structure):
                 ('drop_p', c_float), ('drop_seed', c_void_p), ('drop_stream', c_u32),
                 ('out_f32', c_int), ('accumulate', c_int), ('alpha', c_float), ('split_k', c_int),
                 ('residual_f32', c_int), ('workspace', c_void_p), ('workspace_bytes', c_i64), ('pre_grad', c_int),
-                ('conv', C.POINTER(ConvGather)), ('col_stats', c_void_p)]
+                ('conv', C.POINTER(ConvGather)), ('col_stats', c_void_p),
+                ('rowmap_wo', c_int), ('rowmap_mul', c_int), ('rowmap_sub', c_int), ('rowmap_add', c_int)]
+
+
+class ConvDgradItem(C.Structure):
+    _fields_ = [('w', c_void_p), ('dst', c_void_p), ('Cout', c_int), ('Cin', c_int), ('stride', c_int)]
 
 
 class LnReduceItem(C.Structure):
@@ -161,6 +167,8 @@ _SIGS = {
     'ph_gemm_grouped_bf16': (c_int, [c_void_p, c_int, c_void_p]),
     'ph_gemm_grouped_capped_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p]),
     'ph_gemm_tuning': (c_int, [c_int, c_int]),
+    'ph_gemm_dispatch_counts': (c_int, [c_void_p, c_int, c_int]),
+    'ph_conv_dgrad_shadow_grouped': (c_int, [c_void_p, c_int, c_void_p]),
     'ph_add_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     'ph_act_bwd_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     'ph_copy_rows_bf16': (c_int, [c_void_p, c_int, RowMap, c_void_p, c_int, RowMap, c_int, c_int, c_int, c_void_p]),

@@ -15,6 +15,7 @@
 // Block = 4 waves; forward / dQ: 64 queries per block (16 per wave), K/V streamed in 64-key tiles through a
 // double-buffered LDS image; dK/dV: 64 keys per block, Q/dO streamed.
 #include <float.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -118,13 +119,22 @@ __device__ __forceinline__ float score_of(float s, float scale, float kstate, bo
   return kstate == 0.f ? sc : kstate;
 }
 
+// PLAIN kernels (round 3): no causal cut, no key mask, no probability dropout -- the ViT blocks and the resampler, i.e. the bulk of
+// the attention time.  The generic kernels spend ~15 VALU instructions per score element (scale, two mask selects with their index
+// arithmetic, subtract, multiply by log2(e), exp) against one MFMA per 4 elements: by counter they sat at 6-10 % MFMA utilisation,
+// VALU-bound.  The PLAIN path folds scale * log2(e) into one constant and works in base 2 (p = exp2(fma(s, c, -m)): two
+// instructions per element); only a tile that crosses the end of the sequence pays a bounds select.
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // =====================================================================================================
 // forward
 // =====================================================================================================
 // LDS image (all three kernels): [stage 0: tile X, tile Y][stage 1: tile X, tile Y][per-row fp32 side data, 2 x 128]
 //   forward / dQ : X = K, Y = V, side = key state (64 floats per stage)
 //   dK/dV        : X = Q, Y = dO, side = lse (64) + delta (64) per stage
-template <int DH>
+template <int DH, bool PLAIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 4 : 2))) void attn_fwd_kernel(ph_attn_fwd_args a) {
   using C = Cfg<DH>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -187,6 +197,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
     if (wave_live) {
       f32x4 s[4];
       float mx = -INFINITY;
+      const bool tail = kbase + 64 > a.Sk;            // (uniform) this tile crosses the end of the key sequence
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         if (kbase + nt * 16 < a.Sk) {                 // 16-key sub-tiles entirely beyond Sk cost nothing
@@ -194,12 +205,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
 #pragma unroll
           for (int ks = 0; ks < C::KS; ++ks)
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(kl, nt * 16, ks, lane), qf[ks], acc, 0, 0, 0);
-          const f32x4 st = *reinterpret_cast<const f32x4*>(kst + nt * 16 + g * 4);
+          if constexpr (PLAIN) {                      // base-2 scores: s * scale * log2(e)
+            const float c2 = a.scale * LOG2E;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            int ki = kbase + nt * 16 + g * 4 + r;
-            acc[r] = score_of(acc[r], a.scale, st[r], a.causal && ki > qi);
-            mx = fmaxf(mx, acc[r]);
+            for (int r = 0; r < 4; ++r) {
+              acc[r] *= c2;
+              if (tail) acc[r] = (kbase + nt * 16 + g * 4 + r < a.Sk) ? acc[r] : -INFINITY;
+              mx = fmaxf(mx, acc[r]);
+            }
+          } else {
+            const f32x4 st = *reinterpret_cast<const f32x4*>(kst + nt * 16 + g * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              int ki = kbase + nt * 16 + g * 4 + r;
+              acc[r] = score_of(acc[r], a.scale, st[r], a.causal && ki > qi);
+              mx = fmaxf(mx, acc[r]);
+            }
           }
           s[nt] = acc;
         } else {
@@ -208,13 +229,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
       }
       mx = xor_max(mx);
       float m_new = fmaxf(m, mx);
-      float alpha = __expf(m - m_new);
+      float alpha = PLAIN ? fast_exp2(m - m_new) : __expf(m - m_new);
       float rs = 0.f;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float p = __expf(s[nt][r] - m_new);
+          float p = PLAIN ? fast_exp2(s[nt][r] - m_new) : __expf(s[nt][r] - m_new);
           rs += p;
           s[nt][r] = p;
         }
@@ -258,14 +279,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
       bf16x4 t = {f2bf(o[d][0] * inv), f2bf(o[d][1] * inv), f2bf(o[d][2] * inv), f2bf(o[d][3] * inv)};
       *reinterpret_cast<bf16x4*>(O + d * 16 + g * 4) = t;
     }
-    if (g == 0 && a.lse) a.lse[(int64_t)(b * a.H + h) * a.Sq + qi] = m + __logf(lsum);
+    if (g == 0 && a.lse) a.lse[(int64_t)(b * a.H + h) * a.Sq + qi] = (PLAIN ? m * LN2 : m) + __logf(lsum);    // natural-log lse either way
   }
 }
 
 // =====================================================================================================
 // backward: dQ  (same streaming structure as forward)
 // =====================================================================================================
-template <int DH>
+template <int DH, bool PLAIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 4 : 2))) void attn_bwd_dq_kernel(ph_attn_bwd_args a) {
   using C = Cfg<DH>;
   const ph_attn_fwd_args& f = a.f;
@@ -350,16 +371,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(kl, nt * 16, ks, lane), qf[ks], acc, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(vl, nt * 16, ks, lane), dof[ks], dp, 0, 0, 0);
           }
-          const f32x4 st = *reinterpret_cast<const f32x4*>(kst + nt * 16 + g * 4);
-          u32x4 rnd;
-          if (drop) rnd = philox4x32((uint32_t)((kbase + nt * 16 + g * 4) >> 2), rowid, dc.stream, 0xa77eu, dc.k0, dc.k1);
+          if constexpr (PLAIN) {
+            const float c2 = f.scale * LOG2E, l2 = lse * LOG2E;
+            const bool tail = kbase + 64 > f.Sk;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            int ki = kbase + nt * 16 + g * 4 + r;
-            float p = __expf(score_of(acc[r], f.scale, st[r], f.causal && ki > qi) - lse);
-            float dpe = drop ? drop_apply(dc, rnd[r], dp[r]) : dp[r];
-            dsum += p * dpe;
-            ds[nt][r] = p * (dpe - delta);
+            for (int r = 0; r < 4; ++r) {
+              float p = fast_exp2(fmaf(acc[r], c2, -l2));
+              if (tail) p = (kbase + nt * 16 + g * 4 + r < f.Sk) ? p : 0.f;
+              dsum += p * dp[r];
+              ds[nt][r] = p * (dp[r] - delta);
+            }
+          } else {
+            const f32x4 st = *reinterpret_cast<const f32x4*>(kst + nt * 16 + g * 4);
+            u32x4 rnd;
+            if (drop) rnd = philox4x32((uint32_t)((kbase + nt * 16 + g * 4) >> 2), rowid, dc.stream, 0xa77eu, dc.k0, dc.k1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              int ki = kbase + nt * 16 + g * 4 + r;
+              float p = __expf(score_of(acc[r], f.scale, st[r], f.causal && ki > qi) - lse);
+              float dpe = drop ? drop_apply(dc, rnd[r], dp[r]) : dp[r];
+              dsum += p * dpe;
+              ds[nt][r] = p * (dpe - delta);
+            }
           }
         } else {
           ds[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -402,7 +435,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
 // =====================================================================================================
 // backward: dK, dV  (one key per lane; Q / dO streamed in 64-query tiles)
 // =====================================================================================================
-template <int DH>
+template <int DH, bool PLAIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 3 : 2))) void attn_bwd_dkv_kernel(ph_attn_bwd_args a) {
   using C = Cfg<DH>;
   const ph_attn_fwd_args& f = a.f;
@@ -481,6 +514,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
           }
           const f32x4 l4 = *reinterpret_cast<const f32x4*>(stl + qt * 16 + g * 4);
           const f32x4 d4 = *reinterpret_cast<const f32x4*>(stl + 64 + qt * 16 + g * 4);
+          if constexpr (PLAIN) {
+            const float c2 = f.scale * LOG2E;
+            const bool tail = (qbase + 64 > f.Sq) || (k0 + 16 > f.Sk);     // (wave-uniform) this tile pair touches padding rows / keys
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float p = fast_exp2(fmaf(acc[r], c2, -l4[r] * LOG2E));
+              if (tail) p = (qbase + qt * 16 + g * 4 + r < f.Sq && ki < f.Sk) ? p : 0.f;
+              pd[qt][r] = p;
+              ds[qt][r] = p * (dp[r] - d4[r]);
+            }
+          } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             int qi = qbase + qt * 16 + g * 4 + r;         // C layout here: row = query, col (lane & 15) = key
@@ -502,6 +546,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
               pd[qt][r] = 0.f;
               ds[qt][r] = 0.f;
             }
+          }
           }
         } else {
           pd[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -542,6 +587,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
   }
 }
 
+// no causal cut, no key mask, no probability dropout -> the PLAIN kernels (PH_ATTN_PLAIN=0: A/B against the generic ones)
+bool attn_plain_ok(const ph_attn_fwd_args* f) {
+  static const bool on = [] { const char* e = getenv("PH_ATTN_PLAIN"); return !e || atoi(e) != 0; }();
+  return on && !f->causal && !f->key_mask && !(f->drop_p > 0.f);
+}
+
 template <typename KernelT>
 int set_smem(KernelT k, int bytes) {
   if (bytes > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -565,10 +616,16 @@ extern "C" int ph_attention_fwd(const ph_attn_fwd_args* a, hipStream_t stream) {
   if (rc) return rc;
   ProfScope prof__(PH_FAM_ATTN_FWD, 4.0 * a->B * (double)a->H * a->Sq * (double)a->Sk * a->dh, 0.0, stream);
   dim3 grid(ceil_div(a->Sq, 64), a->B * a->H);
-#define PH_FWD(DHV)                                                                        \
-  case DHV: {                                                                              \
-    int smem = set_smem(attn_fwd_kernel<DHV>, 4 * Cfg<DHV>::TILE * 2 + 1024);                      \
-    hipLaunchKernelGGL(attn_fwd_kernel<DHV>, grid, dim3(256), smem, stream, *a);           \
+  const bool plain = attn_plain_ok(a);
+#define PH_FWD(DHV)                                                                               \
+  case DHV: {                                                                                     \
+    if (plain) {                                                                                  \
+      int smem = set_smem(attn_fwd_kernel<DHV, true>, 4 * Cfg<DHV>::TILE * 2 + 1024);             \
+      hipLaunchKernelGGL((attn_fwd_kernel<DHV, true>), grid, dim3(256), smem, stream, *a);        \
+    } else {                                                                                      \
+      int smem = set_smem(attn_fwd_kernel<DHV, false>, 4 * Cfg<DHV>::TILE * 2 + 1024);            \
+      hipLaunchKernelGGL((attn_fwd_kernel<DHV, false>), grid, dim3(256), smem, stream, *a);       \
+    }                                                                                             \
   } break;
   switch (a->dh) { PH_FWD(32) PH_FWD(64) PH_FWD(96) PH_FWD(128) }
 #undef PH_FWD
@@ -585,12 +642,20 @@ extern "C" int ph_attention_bwd(const ph_attn_bwd_args* a, hipStream_t stream) {
   PH_CHECK_ARG(((a->do_ts | a->dq_ts | a->dk_ts | a->dv_ts | a->do_bs | a->dq_bs | a->dk_bs | a->dv_bs) % 8) == 0, "ph_attention_bwd: strides must be multiples of 8");
   const ph_attn_fwd_args& f = a->f;
   dim3 gq(ceil_div(f.Sq, 64), f.B * f.H), gk(ceil_div(f.Sk, 64), f.B * f.H);
-#define PH_BWD(DHV)                                                                          \
-  case DHV: {                                                                                \
-    int smem = set_smem(attn_bwd_dq_kernel<DHV>, 4 * Cfg<DHV>::TILE * 2 + 1024);                     \
-    set_smem(attn_bwd_dkv_kernel<DHV>, smem);                                                \
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<DHV>, gq, dim3(256), smem, stream, *a);            \
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<DHV>, gk, dim3(256), smem, stream, *a);           \
+  const bool plain = attn_plain_ok(&f);
+#define PH_BWD(DHV)                                                                                       \
+  case DHV: {                                                                                             \
+    if (plain) {                                                                                          \
+      int smem = set_smem(attn_bwd_dq_kernel<DHV, true>, 4 * Cfg<DHV>::TILE * 2 + 1024);                  \
+      set_smem(attn_bwd_dkv_kernel<DHV, true>, smem);                                                     \
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<DHV, true>), gq, dim3(256), smem, stream, *a);               \
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<DHV, true>), gk, dim3(256), smem, stream, *a);              \
+    } else {                                                                                              \
+      int smem = set_smem(attn_bwd_dq_kernel<DHV, false>, 4 * Cfg<DHV>::TILE * 2 + 1024);                 \
+      set_smem(attn_bwd_dkv_kernel<DHV, false>, smem);                                                    \
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<DHV, false>), gq, dim3(256), smem, stream, *a);              \
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<DHV, false>), gk, dim3(256), smem, stream, *a);             \
+    }                                                                                                     \
   } break;
   switch (f.dh) { PH_BWD(32) PH_BWD(64) PH_BWD(96) PH_BWD(128) }
 #undef PH_BWD

@@ -288,11 +288,8 @@ __global__ __launch_bounds__(512) void gemm_ks2_kernel(GemmParams p) {
 template <bool TA, bool TB>
 int launch_ks2(const GemmParams& p, hipStream_t s) {
   constexpr int smem = 4 * ((TA ? TileBytes<64>::ks : TileBytes<64>::kc) + (TB ? TileBytes<64>::ks : TileBytes<64>::kc));
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ks2_kernel<TA, TB>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+  PH_SET_SMEM_ONCE((&gemm_ks2_kernel<TA, TB>), smem);
+  count_launch(PH_GEMM_CLS_KS2);
   hipLaunchKernelGGL((gemm_ks2_kernel<TA, TB>), dim3(p.tiles_m * p.tiles_n), dim3(512), smem, s, p);
   PH_LAUNCH_CHECK("gemm_ks2_kernel");
   return PH_OK;
@@ -301,15 +298,10 @@ int launch_ks2(const GemmParams& p, hipStream_t s) {
 template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0>
 int launch_pf(const GemmParams& p, int splits, hipStream_t s) {
   constexpr int smem_min = 2 * ((TA ? TileBytes<BM>::ks : TileBytes<BM>::kc) + (TB ? TileBytes<BN>::ks : TileBytes<BN>::kc));
-  static int extra = -1;            // PH_GEMM_EXTRA_LDS=<bytes>: occupancy experiments only (pads the dynamic LDS request)
-  if (extra < 0) { const char* e = getenv("PH_GEMM_EXTRA_LDS"); extra = e ? atoi(e) : 0; }
+  static const int extra = env_int("PH_GEMM_EXTRA_LDS", 0);            // occupancy experiments only (pads the dynamic LDS request)
   const int smem = smem_min + extra;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, TA, TB, PF, CONV>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+  PH_SET_SMEM_ONCE((&gemm_kernel<BM, BN, TA, TB, PF, CONV>), smem);
+  count_launch(BM == 64 ? PH_GEMM_CLS_64 : PH_GEMM_CLS_128);
   dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
   hipLaunchKernelGGL((gemm_kernel<BM, BN, TA, TB, PF, CONV>), grid, dim3(256), smem, s, p);
   PH_LAUNCH_CHECK("gemm_kernel");
@@ -339,12 +331,33 @@ int dispatch_layout(const GemmParams& p, int ta, int tb, int splits, hipStream_t
 }  // namespace
 
 
-static int g_big_mode = -1, g_big_min_tiles = -1;
+namespace phg { std::atomic<long long> g_gemm_counts[PH_GEMM_CLS_COUNT]; }
+// run-time tuning (ph_gemm_tuning); -1 = not set yet: the first reader takes the environment default
+static std::atomic<int> g_big_mode{-1}, g_big_min_tiles{-1};
+static int big_mode_now() {
+  int m = g_big_mode.load(std::memory_order_relaxed);
+  if (m < 0) { static const int dflt = env_int("PH_GEMM_BIG", 5); m = dflt; }
+  return m;
+}
+static int big_min_tiles_now() {
+  int m = g_big_min_tiles.load(std::memory_order_relaxed);
+  if (m < 0) { static const int dflt = env_int("PH_GEMM_BIG_MIN_TILES", 128); m = dflt; }
+  return m;
+}
 
 extern "C" int ph_gemm_tuning(int big_mode, int big_min_tiles) {
-  if (big_mode >= 0) g_big_mode = big_mode;
-  if (big_min_tiles >= 0) g_big_min_tiles = big_min_tiles;
+  if (big_mode >= 0) g_big_mode.store(big_mode, std::memory_order_relaxed);
+  if (big_min_tiles >= 0) g_big_min_tiles.store(big_min_tiles, std::memory_order_relaxed);
   return PH_OK;
+}
+
+extern "C" int ph_gemm_dispatch_counts(int64_t* out, int n, int reset) {
+  PH_CHECK_ARG(n >= 0 && (out || n == 0), "ph_gemm_dispatch_counts: null output");
+  for (int i = 0; i < PH_GEMM_CLS_COUNT; ++i) {
+    const long long v = reset ? g_gemm_counts[i].exchange(0, std::memory_order_relaxed) : g_gemm_counts[i].load(std::memory_order_relaxed);
+    if (i < n) out[i] = (int64_t)v;
+  }
+  return PH_GEMM_CLS_COUNT;
 }
 
 // argument validation + kernel parameter block shared by the single and the grouped entry point
@@ -368,19 +381,28 @@ static int fill_params(const ph_gemm_args* a, GemmParams& p) {
   p.ws = nullptr; p.ldws = (a->N + 3) / 4 * 4;
   p.col_stats = a->col_stats;
   p.cv = ConvGather{};
+  p.rm_wo = a->rowmap_wo; p.rm_mul = a->rowmap_mul; p.rm_sub = a->rowmap_sub; p.rm_add = a->rowmap_add;
+  p.rm_inv_wo = a->rowmap_wo > 0 ? 1.0f / (float)a->rowmap_wo : 0.f;
+  PH_CHECK_ARG(a->rowmap_wo >= 0 && (a->rowmap_wo == 0 || (!a->pre_out && !a->accumulate && a->split_k <= 1 && a->M < (1 << 24) && a->rowmap_mul >= 1 && a->rowmap_sub >= 0)),
+               "ph_gemm_bf16: output row map needs a plain store epilogue (no pre_out / accumulate / split-K) and M < 2^24");
   if (a->conv) {
     const ph_conv_gather& c = *a->conv;
-    PH_CHECK_ARG(c.B > 0 && c.H > 0 && c.W > 0 && c.C > 0 && (c.C % 8) == 0 && (c.ks == 1 || c.ks == 3) && c.stride >= 1,
+    const bool general = c.kh > 0;
+    PH_CHECK_ARG(c.B > 0 && c.H > 0 && c.W > 0 && c.C > 0 && (c.C % 8) == 0 && (general || c.ks == 1 || c.ks == 3) && c.stride >= 1,
                  "ph_gemm_bf16: bad conv gather (C %% 8 == 0, ks 1 or 3)");
-    const int pad = c.ks / 2, Ho = (c.H + 2 * pad - c.ks) / c.stride + 1, Wo = (c.W + 2 * pad - c.ks) / c.stride + 1;
+    PH_CHECK_ARG(!general || (c.kh >= 1 && c.kh <= 3 && c.kw >= 1 && c.kw <= 3 && c.Ho > 0 && c.Wo > 0 && !a->trans_a && !a->trans_b),
+                 "ph_gemm_bf16: generalised conv window: 1..3 x 1..3 taps, forward-shaped gather only");
+    const int pad = c.ks / 2;
+    const int Ho = general ? c.Ho : (c.H + 2 * pad - c.ks) / c.stride + 1, Wo = general ? c.Wo : (c.W + 2 * pad - c.ks) / c.stride + 1;
     const int64_t rows = (int64_t)c.B * Ho * Wo;
     PH_CHECK_ARG(rows < (1 << 24) && (int64_t)c.B * c.H * c.W < (1ll << 31) / 1, "ph_gemm_bf16: conv gather index space too large");
-    const int Kreal = c.ks * c.ks * c.C;
+    const int Kreal = general ? c.kh * c.kw * c.C : c.ks * c.ks * c.C;
     if (!a->trans_a && !a->trans_b) PH_CHECK_ARG(a->M == rows && a->K >= Kreal && (a->K % 8) == 0, "ph_gemm_bf16: conv A: M must be B*Ho*Wo (%lld), K >= ks*ks*C", (long long)rows);
     else if (a->trans_a && a->trans_b) PH_CHECK_ARG(a->K == rows && a->N >= Kreal, "ph_gemm_bf16: conv B: K must be B*Ho*Wo (%lld), N >= ks*ks*C", (long long)rows);
     else return ph_fail(PH_ERR_UNSUPPORTED, "ph_gemm_bf16: conv gather is defined for the NN (forward) and TT (weight gradient) layouts");
     p.cv.H = c.H; p.cv.W = c.W; p.cv.C = c.C; p.cv.ks = c.ks; p.cv.stride = c.stride; p.cv.Ho = Ho; p.cv.Wo = Wo; p.cv.Kreal = Kreal;
     p.cv.inv_howo = 1.0f / (float)(Ho * Wo); p.cv.inv_wo = 1.0f / (float)Wo; p.cv.inv_c = 1.0f / (float)c.C;
+    p.cv.kh = general ? c.kh : c.ks; p.cv.kw = general ? c.kw : c.ks; p.cv.offy = general ? c.off_y : -pad; p.cv.offx = general ? c.off_x : -pad;
   }
   PH_CHECK_ARG(!a->col_stats || (!a->bias && a->act == PH_ACT_NONE && !a->act_in && !a->residual && !(a->drop_p > 0.f) && !a->accumulate),
                "ph_gemm_bf16: col_stats needs a plain epilogue");
@@ -390,11 +412,8 @@ static int fill_params(const ph_gemm_args* a, GemmParams& p) {
 template <int BM, bool TA, bool TB, int PF, int CONV = 0>
 static int launch_grouped(const GroupParams& g, int total, int max_blocks, hipStream_t s) {
   constexpr int smem = 2 * ((TA ? TileBytes<BM>::ks : TileBytes<BM>::kc) + (TB ? TileBytes<BM>::ks : TileBytes<BM>::kc));
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_grouped_kernel<BM, BM, TA, TB, PF, CONV>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+  PH_SET_SMEM_ONCE((&gemm_grouped_kernel<BM, BM, TA, TB, PF, CONV>), smem);
+  count_launch(PH_GEMM_CLS_GROUPED);
   const int grid = (max_blocks > 0 && max_blocks < total) ? max_blocks : total;
   hipLaunchKernelGGL((gemm_grouped_kernel<BM, BM, TA, TB, PF, CONV>), dim3(grid), dim3(256), smem, s, g);
   PH_LAUNCH_CHECK("gemm_grouped_kernel");
@@ -453,10 +472,8 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
   g.tile_start[n] = total;
   // ---- weight-gradient groups with long reductions: the 256x128 ping-pong kernel, one persistent block per CU ----
   {
-    if (g_big_mode < 0) { const char* e = getenv("PH_GEMM_BIG"); g_big_mode = e ? atoi(e) : 5; }
-    static int big_grp = -1;            // PH_GEMM_BIG_GROUPED=0: keep every group on the 128x128 / 64x64 grouped kernel
-    if (big_grp < 0) { const char* e = getenv("PH_GEMM_BIG_GROUPED"); big_grp = e ? atoi(e) : 1; }
-    bool ok = g_big_mode > 0 && big_grp && !conv && max_blocks == 0 && args[0].trans_a && args[0].trans_b;
+    static const int big_grp = env_int("PH_GEMM_BIG_GROUPED", 1);   // 0: keep every group on the 128x128 / 64x64 grouped kernel
+    bool ok = big_mode_now() > 0 && big_grp && !conv && max_blocks == 0 && args[0].trans_a && args[0].trans_b;
     int tbig = 0, kt_min = 1 << 30, kt_big = 0;
     for (int i = 0; i < n && ok; ++i) {
       const ph_gemm_args& a = args[i];
@@ -486,8 +503,15 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
   const int ta = args[0].trans_a, tb = args[0].trans_b;
   if (conv) {               // gathered operand: forward (NN, A = im2col view) or weight gradient (TT, B = im2col view); no prefetch ring
     PH_CHECK_ARG(ta == tb, "ph_gemm_grouped_bf16: conv gather needs the NN or the TT layout");
-    if (!ta) return BMsel == 128 ? launch_grouped<128, false, false, 1, 1>(g, total, max_blocks, stream)
-                                 : launch_grouped<64, false, false, 1, 1>(g, total, max_blocks, stream);
+    if (!ta) {
+      // gathered A operand through the register prefetch ring as well (round 3): the gather loads are unconditional (clamped address +
+      // select), so the ring's straight-line bookkeeping holds for any K.  PH_GEMM_CONV_RING=0: the round-2 one-deep schedule
+      static const int conv_ring = env_int("PH_GEMM_CONV_RING", 1);
+      if (conv_ring) return BMsel == 128 ? launch_grouped<128, false, false, PH_RING128, 1>(g, total, max_blocks, stream)
+                                         : launch_grouped<64, false, false, PH_RING64, 1>(g, total, max_blocks, stream);
+      return BMsel == 128 ? launch_grouped<128, false, false, 1, 1>(g, total, max_blocks, stream)
+                          : launch_grouped<64, false, false, 1, 1>(g, total, max_blocks, stream);
+    }
     return BMsel == 128 ? launch_grouped<128, true, true, 1, 2>(g, total, max_blocks, stream)
                         : launch_grouped<64, true, true, 1, 2>(g, total, max_blocks, stream);
   }
@@ -501,6 +525,34 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
 
 extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
   PH_CHECK_ARG(a && a->A && a->B && a->C, "ph_gemm_bf16: null pointer");
+  // ---- tail split (round 3): a launch whose tile count is a little above a whole number of block rounds pays a full extra round for
+  // a handful of tiles (c_fc 8320 x 3072: 65 x 24 = 1560 tiles of 128x128 on 512 block slots = 3.05 rounds -> 4 tile times, ~95 us).
+  // The rows that cause the overshoot (the last, partial row panels) are cut off and computed by a second, small launch:
+  // 8192 x 3072 = exactly 3 rounds (+ 128 x 3072 on 64x64 tiles, ~10 us beside an otherwise idle chip).
+  {   // (before the profiling scope of this call: the two halves are profiled as two launches)
+    static const int tail_split = env_int("PH_GEMM_TAIL_SPLIT", 1);
+    const int64_t tn128 = ceil_div(a->N, 128), tm128 = ceil_div(a->M, 128);
+    const int64_t tiles = tm128 * tn128, slots = 512;
+    if (tail_split && !a->trans_a && !a->conv && !a->col_stats && !(a->drop_p > 0.0f) && a->split_k <= 0 && tiles > slots && (a->K % BK) == 0) {
+      const int64_t over = tiles % slots;
+      const int64_t panels_main = (tiles / slots) * slots / tn128;              // row panels that fit the whole rounds
+      const int64_t m_main = panels_main * 128, m_rem = a->M - m_main;
+      // worth it when the overshoot is small (<= 12 % of a round) and the cut-off part is itself a small problem
+      if (over > 0 && over * 100 <= slots * 12 && m_rem > 0 && m_rem <= 512 && (m_main % 256) == 0 && m_main >= 2048) {
+        ph_gemm_args b = *a, c = *a;
+        b.M = (int)m_main;
+        c.M = (int)m_rem;
+        c.A = (const char*)a->A + (size_t)m_main * a->lda * 2;
+        c.C = (char*)a->C + (size_t)m_main * a->ldc * (a->out_f32 ? 4 : 2);
+        if (a->pre_out) c.pre_out = (char*)a->pre_out + (size_t)m_main * a->ldc * 2;
+        if (a->act_in) c.act_in = (const char*)a->act_in + (size_t)m_main * a->ld_act * 2;
+        if (a->residual) c.residual = (const char*)a->residual + (size_t)m_main * a->ldr * (a->residual_f32 ? 4 : 2);
+        int rc = ph_gemm_bf16(&b, stream);
+        if (rc != PH_OK) return rc;
+        return ph_gemm_bf16(&c, stream);
+      }
+    }
+  }
   char desc__[96];
   if (g_ph_prof_enabled) snprintf(desc__, sizeof(desc__), "gemm M=%d N=%d K=%d ta=%d tb=%d f32=%d acc=%d", a->M, a->N, a->K, a->trans_a, a->trans_b, a->out_f32, a->accumulate);
   ProfScope prof__(PH_FAM_GEMM, 2.0 * a->M * (double)a->N * a->K, 2.0 * ((double)a->M * a->K + (double)a->N * a->K + (double)a->M * a->N), stream, desc__);
@@ -516,14 +568,11 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
   {
     // g_big_mode (PH_GEMM_BIG / ph_gemm_tuning): 0 = off, 1 = plain main loop (round-2 first version), 5 = ping-pong main loop (the
     // two waves of a SIMD alternate read and MFMA phases; default), 6 = ping-pong + s_setprio around the MFMA phase
-    if (g_big_mode < 0) { const char* e = getenv("PH_GEMM_BIG"); g_big_mode = e ? atoi(e) : 5; }
-    if (g_big_min_tiles < 0) { const char* e = getenv("PH_GEMM_BIG_MIN_TILES"); g_big_min_tiles = e ? atoi(e) : 128; }
-    const int big_mode = g_big_mode, big_min_tiles = g_big_min_tiles;
+    const int big_mode = big_mode_now(), big_min_tiles = big_min_tiles_now();
     const int64_t tb = (int64_t)ceil_div(a->M, big::BM) * ceil_div(a->N, big::BN);
-    static int wide = -1;             // PH_GEMM_BIG_WIDE=1: also the wide-N, short-K launches (in the step they do not gain, see below)
-    if (wide < 0) { const char* e = getenv("PH_GEMM_BIG_WIDE"); wide = e ? atoi(e) : 0; }
-    static int tb_ok = -1;            // PH_GEMM_BIG_TB=0: keep the [K][N]-B (dgrad-shaped) problems on the 128x128 kernel
-    if (tb_ok < 0) { const char* e = getenv("PH_GEMM_BIG_TB"); tb_ok = e ? atoi(e) : 1; }
+    static const int wide = env_int("PH_GEMM_BIG_WIDE", 0);    // 1: also the wide-N, short-K launches (in the step they do not gain, see below)
+    const bool wide_ok = wide != 0;
+    static const int tb_ok = env_int("PH_GEMM_BIG_TB", 1);     // 0: keep the [K][N]-B (dgrad-shaped) problems on the 128x128 kernel
     // block rounds of either kernel (constants from the per-shape fits, us): a 256x128 block alone on its CU, a pair of co-resident
     // 128x128 blocks, a lone 128x128 block (what the last, half-empty round of that kernel is made of -- the reason a tile count just
     // above a multiple of 256 favours it: 41 x 8 tiles of 256x128 are two full rounds, 81 x 8 of 128x128 one pair round + one lone round)
@@ -538,7 +587,7 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
     }
     if (big_mode > 0 && !a->conv && !a->col_stats && !a->trans_a && (!a->trans_b || tb_ok) && (a->K % BK) == 0 && a->K >= 2 * BK && a->split_k <= 0 && a->M >= big::BM &&
         (a->N % 8) == 0 && a->N >= 8 && tb >= big_min_tiles && (tb >= 192 || a->K >= 32 * BK || big_min_tiles <= 1) && big_cheaper &&
-        (wide || a->N <= 1024 || a->K >= 2048 || big_min_tiles <= 1)) {      // (short-K launches that fill < 3/4 of the CUs with one round: 128x128)
+        (wide_ok || a->N <= 1024 || a->K >= 2048 || big_min_tiles <= 1)) {      // (short-K launches that fill < 3/4 of the CUs with one round: 128x128)
       // Forward-shaped (B = [N][K]) and dgrad-shaped (B = [K][N], trans_b) problems alike.  Isolated (tools/big_probe.py,
       // profiles/r2_ab_big_tile_gemm.txt) the ping-pong kernel beats the 128x128 register-staged kernel on every shape of the
       // step; inside the step (rocprofv3 per-grid durations, profiles/r2_gemm_by_grid.txt) only the launches with N <= 1024 or a
@@ -577,7 +626,8 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
     if (a->M <= 64 || a->N <= 64 || t128 * splits < 128) BM = 64;
   } else {
     double best = 1e30;
-    const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48};
+    const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256};   // (the stems' first-layer weight gradients:
+                                                                                       //  2 output tiles, 6272 k-tiles -- 48 splits left them at 94 us)
     for (int bm = 64; bm <= 128; bm += 64) {
       if (bm == 128 && (a->M <= 64 || a->N <= 64)) continue;
       // tools/gemm_probe.py on MI355X: 8320x768 NT, K 768 -> 3072: 1.07 us per k-tile for one wave of co-resident
@@ -593,8 +643,7 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
     }
   }
   {
-    static int force = -1;           // PH_GEMM_FORCE_TILE=64|128: tile-shape experiments (tools/ab_probe.py)
-    if (force < 0) { const char* e = getenv("PH_GEMM_FORCE_TILE"); force = e ? atoi(e) : 0; }
+    static const int force = env_int("PH_GEMM_FORCE_TILE", 0);           // 64|128: tile-shape experiments (tools/ab_probe.py)
     if (force == 64 || (force == 128 && a->M > 64 && a->N > 64)) { BM = force; if (a->split_k <= 0) splits = 1; }
     if (force == 12864 && a->M > 64) { BM = 128; BN = 64; if (a->split_k <= 0) splits = 1; }
   }
@@ -615,8 +664,7 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
     // 64x64-tile launches that leave CUs with a single block (the decoder's M = 960 rows): split the k loop inside the block instead
     // of over gridDim.z + a reduce launch.  PH_GEMM_KS2: 0 = off, 1 = when the tile/split choice above was 64x64 unsplit,
     // 2 = also instead of a workspace split-K of a 64x64 launch
-    static int ks2 = -1;
-    if (ks2 < 0) { const char* e = getenv("PH_GEMM_KS2"); ks2 = e ? atoi(e) : 2; }
+    static const int ks2 = env_int("PH_GEMM_KS2", 2);
     const bool plain64 = BM == 64 && BN == 64 && !a->conv && !a->col_stats && !a->trans_a && (a->K % BK) == 0 && kt >= 8 && a->split_k <= 0;
     if (ks2 > 0 && plain64 && t64 <= 512 && (splits == 1 || ks2 >= 2)) {
       p.tiles_m = ceil_div(a->M, 64); p.tiles_n = ceil_div(a->N, 64);
@@ -629,6 +677,7 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
                       : dispatch_layout<128, 128>(p, a->trans_a, a->trans_b, splits, stream);
   if (rc != PH_OK || !p.ws) return rc;
   int grid = (int)min((int64_t)2048, ceil_div64((int64_t)a->M * ((a->N + 3) / 4), 256));
+  count_launch(PH_GEMM_CLS_SPLITK_REDUCE);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, p, splits);
   PH_LAUNCH_CHECK("splitk_reduce_kernel");
   return PH_OK;

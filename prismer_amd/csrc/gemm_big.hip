@@ -218,11 +218,8 @@ __global__ __launch_bounds__(NTHR) void gemm_big_kernel(GemmParams p) {
 
 template <int VARIANT, bool TA, bool TB>
 int launch(const GemmParams& p, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<VARIANT, TA, TB>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    attr_set = true;
-  }
+  PH_SET_SMEM_ONCE((&gemm_big_kernel<VARIANT, TA, TB>), SMEM);
+  count_launch(PH_GEMM_CLS_BIG);
   hipLaunchKernelGGL((gemm_big_kernel<VARIANT, TA, TB>), dim3(p.tiles_m * p.tiles_n), dim3(NTHR), SMEM, s, p);
   PH_LAUNCH_CHECK("gemm_big_kernel");
   return PH_OK;
@@ -249,11 +246,8 @@ __global__ __launch_bounds__(NTHR) void gemm_big_grouped_kernel(GroupParams g) {
 }
 template <int VARIANT, bool TA, bool TB>
 int launch_grouped(const GroupParams& g, int total, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_grouped_kernel<VARIANT, TA, TB>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    attr_set = true;
-  }
+  PH_SET_SMEM_ONCE((&gemm_big_grouped_kernel<VARIANT, TA, TB>), SMEM);
+  count_launch(PH_GEMM_CLS_BIG_GROUPED);
   hipLaunchKernelGGL((gemm_big_grouped_kernel<VARIANT, TA, TB>), dim3(total < 256 ? total : 256), dim3(NTHR), SMEM, s, g);
   PH_LAUNCH_CHECK("gemm_big_grouped_kernel");
   return PH_OK;

@@ -7,6 +7,8 @@
 #include <stdlib.h>
 
 #include <math.h>
+#include <atomic>
+#include <mutex>
 #include <utility>
 
 #include "common.h"
@@ -35,6 +37,7 @@ struct TileBytes {
 struct ConvGather {
   int H, W, C, ks, stride, Ho, Wo, Kreal;
   float inv_howo, inv_wo, inv_c;      // reciprocals for the index decompositions (operands < 2^24: one float multiply + fix-up)
+  int kh, kw, offy, offx;             // window: tap (ty, tx) reads pixel (oy * stride + offy + ty, ox * stride + offx + tx); 3x3 pad 1: 3, 3, -1, -1
 };
 __device__ __forceinline__ int fdiv(int a, int d, float inv) {          // a / d for 0 <= a < 2^24, d > 0
   int q = (int)((float)a * inv);
@@ -57,8 +60,16 @@ struct GemmParams {
   int tiles_m, tiles_n;
   float* ws; int ldws;     // split-K partial tiles: ws[split][M][ldws] fp32 (plain stores), folded by splitk_reduce_kernel
   double* col_stats;       // optional fp64 [2][N]: += column sums / sums of squares of the (bf16-rounded) outputs (BatchNorm statistics)
+  int rm_wo, rm_mul, rm_sub, rm_add; float rm_inv_wo;     // output row map (rm_wo > 0): C row of result row m = m * mul - (m % wo) * sub + add
   ConvGather cv;           // CONV kernels only: geometry of the gathered operand (A for CONV=1, B for CONV=2)
 };
+
+// C row of result row m (identity unless an output row map is set: parity-class data gradients of the stride-2 convolutions)
+__device__ __forceinline__ size_t crow(const GemmParams& p, int m) {
+  if (p.rm_wo == 0) return (size_t)m;
+  const int q = fdiv(m, p.rm_wo, p.rm_inv_wo);
+  return (size_t)(m * p.rm_mul - (m - q * p.rm_wo) * p.rm_sub + p.rm_add);
+}
 
 // ---- global -> register staging ------------------------------------------------------------------------
 // K-contiguous operand: tile = R rows x 64 k. chunk id -> (row = id/8, c = id%8), 16 B each.
@@ -132,8 +143,7 @@ __device__ __forceinline__ PixRow pix_of(const ConvGather& cv, int m) {
   int b = fdiv(m, cv.Ho * cv.Wo, cv.inv_howo);
   int rem = m - b * cv.Ho * cv.Wo;
   int oy = fdiv(rem, cv.Wo, cv.inv_wo), ox = rem - oy * cv.Wo;
-  const int pad = cv.ks >> 1;
-  return PixRow{b * cv.H * cv.W, oy * cv.stride - pad, ox * cv.stride - pad};
+  return PixRow{b * cv.H * cv.W, oy * cv.stride + cv.offy, ox * cv.stride + cv.offx};
 }
 template <int R>
 __device__ __forceinline__ void load_kc_conv(const ConvGather& cv, const bf16* __restrict__ x, const PixRow (&px)[R * 8 / 256], int k0,
@@ -142,7 +152,7 @@ __device__ __forceinline__ void load_kc_conv(const ConvGather& cv, const bf16* _
   const bool kin = k < cv.Kreal;
   const int kk = kin ? k : 0;
   const int tap = fdiv(kk, cv.C, cv.inv_c), c0 = kk - tap * cv.C;
-  const int ky = cv.ks == 3 ? (tap >= 6 ? 2 : (tap >= 3 ? 1 : 0)) : 0, kx = tap - ky * cv.ks;
+  const int ky = cv.kw == 3 ? (tap >= 6 ? 2 : (tap >= 3 ? 1 : 0)) : (cv.kw == 2 ? (tap >> 1) : tap), kx = tap - ky * cv.kw;
 #pragma unroll
   for (int i = 0; i < R * 8 / 256; ++i) {
     const int iy = px[i].iy0 + ky, ix = px[i].ix0 + kx;
@@ -247,7 +257,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
     return;
   }
   if (splitk) {   // no workspace: raw fp32 atomics into C (host guarantees a plain fp32 accumulate epilogue)
-    float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+    float* c = reinterpret_cast<float*>(p.C) + crow(p, m) * p.ldc + n;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
       if (n + e < p.N) atomicAdd(c + e, v[e]);
@@ -295,7 +305,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
     for (int e = 0; e < 4; ++e) v[e] += bf2f(q[min(e, p.N - 1 - n)]);
   }
   if (p.out_f32) {
-    float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+    float* c = reinterpret_cast<float*>(p.C) + crow(p, m) * p.ldc + n;
     if (p.accumulate) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += c[e];
@@ -306,7 +316,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
       for (int e = 0; e < 4; ++e) if (n + e < p.N) c[e] = v[e];
     }
   } else {
-    bf16* c = reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n;
+    bf16* c = reinterpret_cast<bf16*>(p.C) + crow(p, m) * p.ldc + n;
     if (p.accumulate) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += bf2f(c[e]);
@@ -376,7 +386,7 @@ __device__ __forceinline__ void epi_apply8(const GemmParams& p, int m, int n, fl
     for (int e = 0; e < 8; ++e) v[e] += bf2f(t[e]);
   }
   if (p.out_f32) {
-    float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+    float* c = reinterpret_cast<float*>(p.C) + crow(p, m) * p.ldc + n;
     if (p.accumulate) {
       f32x4 c0 = *reinterpret_cast<const f32x4*>(c), c1 = *reinterpret_cast<const f32x4*>(c + 4);
 #pragma unroll
@@ -386,7 +396,7 @@ __device__ __forceinline__ void epi_apply8(const GemmParams& p, int m, int n, fl
     *reinterpret_cast<f32x4*>(c) = o0;
     *reinterpret_cast<f32x4*>(c + 4) = o1;
   } else {
-    bf16* c = reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n;
+    bf16* c = reinterpret_cast<bf16*>(p.C) + crow(p, m) * p.ldc + n;
     if (p.accumulate) {
       bf16x8 t = *reinterpret_cast<const bf16x8*>(c);
 #pragma unroll
@@ -495,6 +505,21 @@ struct GroupParams {
   int tile_start[PH_GEMM_GROUP_MAX + 1];
   GemmParams p[PH_GEMM_GROUP_MAX];
 };
+
+// ---- process-wide state of the GEMM entry points (thread-safe: the C ABI may be entered from the host thread and from autograd's
+// backward thread at once).  Environment switches are read once through function-local statics (C++11: initialised exactly once);
+// kernel attributes are set through std::call_once; the tuning values ph_gemm_tuning() may change at run time are atomics.
+inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#define PH_SET_SMEM_ONCE(kernel_expr, bytes)                                                                                   \
+  do {                                                                                                                         \
+    static std::once_flag once__;                                                                                              \
+    std::call_once(once__, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_expr), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); }); \
+  } while (0)
+// launches per kernel class since the last reset (ph_gemm_dispatch_counts): lets a test assert WHICH kernels a program ran through
+enum { PH_GEMM_CLS_128 = 0, PH_GEMM_CLS_64, PH_GEMM_CLS_KS2, PH_GEMM_CLS_BIG, PH_GEMM_CLS_BIG_GROUPED, PH_GEMM_CLS_GROUPED,
+       PH_GEMM_CLS_SPLITK_REDUCE, PH_GEMM_CLS_COUNT };
+extern std::atomic<long long> g_gemm_counts[PH_GEMM_CLS_COUNT];
+inline void count_launch(int cls) { g_gemm_counts[cls].fetch_add(1, std::memory_order_relaxed); }
 
 // launchers of the 256x128 kernels (gemm_big.hip); variant: 0 plain main loop, 4 ping-pong, 5 ping-pong + s_setprio
 namespace big {

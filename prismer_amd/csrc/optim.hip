@@ -266,6 +266,46 @@ __global__ void probe_kernel(const bf16* __restrict__ in, float* __restrict__ ou
   for (int r = 0; r < 16; ++r) out[512 + l * 16 + r] = c2[r];
 }
 
+// ---- weight operand of the implicit data gradient (include/prismer_hip.h: ph_conv_dgrad_shadow_grouped) ----------------------------
+struct ConvDgradGroup {
+  int n;
+  int blk_start[PH_CONV_GROUP_MAX + 1];
+  ph_conv_dgrad_item it[PH_CONV_GROUP_MAX];
+};
+// one block per (layer, 32 x 32 tile of [Cout x Cin]): the nine taps of the tile are read row-wise from w[co][ci][3][3] (288
+// consecutive floats per co), transposed through LDS and written as 64-B runs of consecutive co (first version: one thread per
+// output element with a Cin*36-byte read stride -- 313 us per step for the 18 layers)
+__global__ __launch_bounds__(256) void conv_dgrad_shadow_grouped_kernel(ConvDgradGroup g) {
+  __shared__ float tile[32][32 * 9 + 1];
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.blk_start[i + 1]) ++i;
+  const ph_conv_dgrad_item& a = g.it[i];
+  const int tiles_ci = (a.Cin + 31) / 32;
+  const int tb = blockIdx.x - g.blk_start[i];
+  const int co0 = (tb / tiles_ci) * 32, ci0 = (tb % tiles_ci) * 32;
+  const int nci = min(32, a.Cin - ci0), nco = min(32, a.Cout - co0);
+  for (int e = threadIdx.x; e < 32 * 288; e += 256) {             // tile[co][(ci, ky, kx)]
+    const int co = e / 288, r = e - co * 288;
+    tile[co][r] = (co < nco && r < nci * 9) ? a.w[((size_t)(co0 + co) * a.Cin + ci0) * 9 + r] : 0.f;
+  }
+  __syncthreads();
+  bf16* dst = reinterpret_cast<bf16*>(a.dst);
+  for (int e = threadIdx.x; e < 32 * 9 * 32; e += 256) {          // (ci, t, co): co fastest
+    const int co = e & 31, t = (e >> 5) % 9, ci = e / (32 * 9);
+    if (co >= nco || ci >= nci) continue;
+    int ky, kx;
+    if (a.stride == 1) {
+      ky = 2 - t / 3; kx = 2 - t % 3;
+    } else {                                                       // parity classes (0,0) | (0,1) | (1,0) | (1,1) back to back
+      const int py = t >= 3, px = (t >= 1 && t < 3) || t >= 5;
+      const int tt = t - (t >= 5 ? 5 : (t >= 3 ? 3 : (t >= 1 ? 1 : 0)));
+      const int ty = px && py ? tt >> 1 : (py ? tt : 0), tx = px && py ? tt & 1 : (px ? tt : 0);
+      ky = py ? (ty ? 0 : 2) : 1;
+      kx = px ? (tx ? 0 : 2) : 1;
+    }
+    dst[(size_t)(ci0 + ci) * 9 * a.Cout + (size_t)t * a.Cout + co0 + co] = f2bf(tile[co][ci * 9 + ky * 3 + kx]);
+  }
+}
 inline int grid_for(int64_t work_items) { return (int)std::min<int64_t>(ceil_div64(work_items, 256), 256 * 16); }
 
 }  // namespace
@@ -440,6 +480,24 @@ extern "C" int ph_conv_weight_to_shadow_grouped(const ph_conv_layout_item* items
 extern "C" int ph_conv_grad_from_shadow_grouped(const ph_conv_layout_item* items, int n, hipStream_t stream) {
   ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_conv_grad_from_shadow_grouped");
   return conv_group_launch(items, n, false, stream, "ph_conv_grad_from_shadow_grouped");
+}
+extern "C" int ph_conv_dgrad_shadow_grouped(const ph_conv_dgrad_item* items, int n, hipStream_t stream) {
+  PH_CHECK_ARG(items && n >= 1 && n <= PH_CONV_GROUP_MAX, "ph_conv_dgrad_shadow_grouped: need 1..%d items, got %d", PH_CONV_GROUP_MAX, n);
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_conv_dgrad_shadow_grouped");
+  ConvDgradGroup g;
+  g.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    PH_CHECK_ARG(items[i].w && items[i].dst && items[i].Cout > 0 && items[i].Cin > 0 && (items[i].stride == 1 || items[i].stride == 2),
+                 "ph_conv_dgrad_shadow_grouped: bad item %d (3x3 kernels, stride 1 or 2)", i);
+    g.it[i] = items[i];
+    g.blk_start[i] = total;
+    total += ((items[i].Cin + 31) / 32) * ((items[i].Cout + 31) / 32);
+  }
+  g.blk_start[n] = total;
+  hipLaunchKernelGGL(conv_dgrad_shadow_grouped_kernel, dim3(total), dim3(256), 0, stream, g);
+  PH_LAUNCH_CHECK("conv_dgrad_shadow_grouped_kernel");
+  return PH_OK;
 }
 extern "C" int ph_advance_seed(uint64_t* seed, hipStream_t stream) {
   PH_CHECK_ARG(seed, "ph_advance_seed: null");

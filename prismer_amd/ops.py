@@ -696,6 +696,57 @@ def conv_layout_grouped(items, to_shadow):
         check(fn(arr, len(part), _stream()), 'ph_conv_layout_grouped')
 
 
+def conv_dgrad_shadows(items):
+    """items: [(w fp32 [Cout,Cin,3,3], dst bf16 [Cin, 9*Cout], Cout, Cin, stride)]: weight operands of the implicit data gradients,
+    one launch per PH_CONV_GROUP_MAX layers (include/prismer_hip.h: ph_conv_dgrad_shadow_grouped)"""
+    for i0 in range(0, len(items), _lib.CONV_GROUP_MAX):
+        part = items[i0:i0 + _lib.CONV_GROUP_MAX]
+        arr = (_lib.ConvDgradItem * len(part))()
+        for it, (w, dst, Co, Ci, stride) in zip(arr, part):
+            it.w, it.dst, it.Cout, it.Cin, it.stride = w.data_ptr(), dst.data_ptr(), Co, Ci, stride
+        check(lib.ph_conv_dgrad_shadow_grouped(arr, len(part), _stream()), 'ph_conv_dgrad_shadow_grouped')
+
+
+# parity classes of the input pixel of a stride-2, 3x3, pad-1 convolution: (py, px) -> (first tap, taps) in the dgrad shadow
+DGRAD_CLASSES = (((0, 0), 0, 1), ((0, 1), 1, 2), ((1, 0), 3, 2), ((1, 1), 5, 4))
+
+
+def conv_dgrad_grouped(items):
+    """Implicit data gradients of 3x3 (pad 1) convolutions, the same layer of several stems in grouped launches (round 3; replaces
+    dcol = dY . W followed by the col2im gather: 9 x the output in transient traffic and, for stride 2, 4 x the useful FLOPs).
+    items: [(dy [B*Ho*Wo, Cout] bf16, wd [Cin, 9*Cout] dgrad shadow, dx [B*H*W, Cin] bf16 out, (B, H, W, Cin, Cout, stride))].
+    stride 1: dX = conv3x3(dY) with flipped taps, one problem.  stride 2: one problem per parity class of the input pixel: the
+    A operand gathers a (1+py) x (1+px) window of dY, the output rows are scattered to the class's pixels (GemmArgs.rowmap_*)."""
+    probs, keep = [], []
+    for dy, wd, dx, (B, H, W, Ci, Co, stride) in items:
+        Ho, Wo = (H, W) if stride == 1 else (H // 2, W // 2)
+        if stride == 1:
+            classes = (((0, 0), 0, 9),)
+        else:
+            assert H % 2 == 0 and W % 2 == 0 and stride == 2
+            classes = DGRAD_CLASSES
+        for (py, px), t0, nt in classes:
+            g = _lib.GemmArgs()
+            if stride == 1:
+                cg = _lib.ConvGather(B, Ho, Wo, Co, 3, 1, 3, 3, -1, -1, Ho, Wo)
+            else:
+                cg = _lib.ConvGather(B, Ho, Wo, Co, 3, 1, 1 + py, 1 + px, 0, 0, Ho, Wo)
+                g.rowmap_wo, g.rowmap_mul, g.rowmap_sub, g.rowmap_add = Wo, 4, 2, py * W + px
+            g.A, g.B, g.C = dy.data_ptr(), wd.data_ptr() + 2 * t0 * Co, dx.data_ptr()
+            g.M, g.N, g.K = B * Ho * Wo, Ci, nt * Co
+            g.lda, g.ldb, g.ldc = nt * Co, wd.stride(0), dx.stride(0)
+            g.alpha = 1.0
+            g.conv = C.pointer(cg)
+            probs.append(g)
+            keep.append((cg, dy, wd, dx))
+    for i0 in range(0, len(probs), _lib.GEMM_GROUP_MAX):
+        part = probs[i0:i0 + _lib.GEMM_GROUP_MAX]
+        arr = (_lib.GemmArgs * len(part))()
+        for i, g in enumerate(part):
+            arr[i] = g
+        check(lib.ph_gemm_grouped_bf16(arr, len(part), _stream()), 'ph_gemm_grouped_bf16 (conv dgrad)')
+
+
 def advance_seed(seed):
     check(lib.ph_advance_seed(seed.data_ptr(), _stream()), 'ph_advance_seed')
 

@@ -19,6 +19,10 @@ from .. import ops
 from .._lib import ACT_QUICKGELU, ACT_RELU2, ACT_SAVED_GRAD, COLSTAT_SLABS, IDENT, RowMap
 from ..config import LABEL_DOMAINS
 
+# data gradients of the stems' 3x3 convolutions: implicit GEMMs gathered from dY (round 3) instead of dcol = dY . W + col2im
+# (PRISMER_IMPLICIT_DGRAD=0: the round-2 path, kept as the A/B reference)
+IMPLICIT_DGRAD = os.environ.get('PRISMER_IMPLICIT_DGRAD', '1') != '0'
+
 BF16, F32 = torch.bfloat16, torch.float32
 
 
@@ -125,6 +129,13 @@ class EncoderProgram:
         Kp = _rup(ks * ks * Ci, 8)
         return self.P.derived_buffer(name, (Co, Kp), lambda t: ops.conv_weight_to_shadow(self.P.f(name), t, Co, Ci, ks, Kp),
                                      conv=(name, Co, Ci, ks, Kp)), Kp
+
+    def conv_dgrad_shadow(self, name, stride):
+        """[Cin, 9*Cout] weight operand of the implicit data gradient of a 3x3 conv (ops.conv_dgrad_grouped), re-derived with the
+        other shadows after every optimizer step"""
+        Co, Ci = self.P.shape[name][0], self.P.shape[name][1]
+        return self.P.derived_buffer(name + '#dgrad', (Ci, 9 * Co), lambda t: ops.conv_dgrad_shadows([(self.P.f(name), t, Co, Ci, stride)]),
+                                     conv=('dgrad', name, Co, Ci, stride))
 
     def conv_wgrad(self, name, ks, dy, col):
         """dW (shadow layout [Cout, Kp], fp32) = dy^T . col, folded back into the [Cout,Cin,k,k] gradient."""
@@ -360,11 +371,19 @@ class EncoderProgram:
                         ds = ops.gemm(dy, s['col0'], trans_a=True, trans_b=True, out_f32=True, M=Co, N=Kp, K=dy.shape[0])
                     ops.WQ.add_conv_fold(ds, g, Co, C, 3, Kp)
                 if i > 0:
-                    shadow, _ = self.conv_shadow(wname, 3)
-                    dcol = torch.empty(dy.shape[0], Kp, dtype=BF16, device=dev)
-                    dcol_probs.append((dy, shadow, dcol, dy.shape[0], Kp, Co))
-                    dcols.append(dcol)
-            if i > 0:
+                    if IMPLICIT_DGRAD:
+                        da = torch.empty(s['B'] * H * H, C, dtype=BF16, device=dev)
+                        dcol_probs.append((dy, self.conv_dgrad_shadow(wname, stride), da, (s['B'], H, H, C, Co, stride)))
+                        dcols.append(da)
+                    else:
+                        shadow, _ = self.conv_shadow(wname, 3)
+                        dcol = torch.empty(dy.shape[0], Kp, dtype=BF16, device=dev)
+                        dcol_probs.append((dy, shadow, dcol, dy.shape[0], Kp, Co))
+                        dcols.append(dcol)
+            if i > 0 and IMPLICIT_DGRAD:
+                ops.conv_dgrad_grouped(dcol_probs)               # data gradients gathered from dY (no dcol matrix, no col2im pass)
+                das = dcols
+            elif i > 0:
                 ops.gemm_grouped(dcol_probs, trans_b=True)
                 das = []
                 for s, dcol in zip(S, dcols):

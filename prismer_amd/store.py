@@ -169,15 +169,20 @@ class ParamStore:
     def refresh_derived(self):
         """re-derive every buffer that is a function of the parameters (after an optimizer step).  Conv weight shadows
         (im2col column order) go through ONE grouped launch per 32 layers instead of a launch per layer."""
-        conv = []
+        conv, dgrad = [], []
         for t, fn, meta in self.derived.values():
-            if meta is not None:
+            if meta is not None and meta[0] == 'dgrad':          # weight operand of the implicit data gradient (ops.conv_dgrad_shadows)
+                _, name, Co, Ci, stride = meta
+                dgrad.append((self.f(name), t, Co, Ci, stride))
+            elif meta is not None:
                 name, Co, Ci, ks, Kp = meta
                 conv.append((self.f(name), t, Co, Ci, ks, Kp))
             else:
                 fn(t)
         if conv:
             ops.conv_layout_grouped(conv, True)
+        if dgrad:
+            ops.conv_dgrad_shadows(dgrad)
 
     def derived_buffer(self, key, shape, fn, conv=None):
         if key not in self.derived:

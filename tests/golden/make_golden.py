@@ -12,6 +12,8 @@ from prismer_amd/synth.py (integer-hash generator), so a fixture holds only what
   bn.*          running_mean / running_var / num_batches_tracked of every BatchNorm after ONE train forward
   gnorm.* gsamp.* gfull.*   gradients of `total_train` under the reference freeze rule 'freeze_vision'
                 (model/prismer.py:39-59 executed by the reference's own Prismer.prepare_to_train)
+  gproj.*       N_PROJ fixed random projections of every gradient tensor (cases.grad_projections): a full-tensor error estimate
+  ac_rel.*      exact full-tensor relative error of the bf16-autocast gradient (yardstick for the projection estimate)
   requires_grad names joined by '\n'
   ac_samp.* ac_norm.* ac_enc_train   error of PyTorch's own bf16 autocast (same reference modules, CPU) w.r.t. the fp32
                 values above: the noise yardstick for the bf16 HIP path
@@ -70,9 +72,11 @@ def run_case(name):
         g = p.grad.detach()
         out['gnorm.' + n] = np.float64(g.double().norm().item())
         out['gsamp.' + n] = g.flatten()[C.sample_idx(n, g.numel())].numpy()
+        out['gproj.' + n] = C.grad_projections(n, g)
         if n in C.FULL_GRAD_KEYS:
             out['gfull.' + n] = g.numpy()
     out['requires_grad'] = np.array('\n'.join(names))
+    ref_full = {n: p.grad.detach().clone() for n, p in holder.named_parameters() if p.requires_grad}
     # yardstick: what eager PyTorch's OWN bf16 autocast does to the same gradients on the same modules (CPU).
     # The HIP path (bf16 storage, fp32 accumulate) is held to max(6e-2, 2x this) per parameter in tests/test_parity_gpu.py.
     for p in holder.parameters():
@@ -92,6 +96,8 @@ def run_case(name):
         s = p.grad.detach().flatten()[C.sample_idx(n, p.numel())].float().numpy()
         out['ac_samp.' + n] = np.float64(np.linalg.norm(s - ref_s) / (np.linalg.norm(ref_s) + 1e-30))
         out['ac_norm.' + n] = np.float64(abs(p.grad.double().norm().item() - float(out['gnorm.' + n])) / (float(out['gnorm.' + n]) + 1e-30))
+        # FULL-tensor error of autocast (exact, the reference gradient is still at hand): yardstick of the projection test
+        out['ac_rel.' + n] = np.float64((p.grad.double() - ref_full[n].double()).norm().item() / (float(out['gnorm.' + n]) + 1e-30))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), name + '.npz')
     np.savez_compressed(path, **out)
     print(f'{name}: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)  loss_eval={out["loss_eval"]}  '

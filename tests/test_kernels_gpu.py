@@ -549,6 +549,35 @@ def test_implicit_gemm_conv_forward_stats_and_wgrad(ops, B, H, C, Cout, stride, 
     assert float(ds[:, ks * ks * C:].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize('B,H,C,Cout,stride', [(2, 16, 24, 40, 2), (3, 12, 96, 64, 1), (2, 28, 96, 192, 2), (1, 8, 8, 16, 2), (4, 56, 96, 192, 2)])
+def test_implicit_conv_data_gradient(ops, B, H, C, Cout, stride):
+    """round 3: dX of a 3x3 pad-1 convolution as implicit GEMMs gathered from dY (stride 1: one flipped-tap convolution; stride 2: one
+    problem per parity class of the input pixel, rows scattered through the output row map) -- against F.conv2d autograd in fp32 and
+    against the dcol = dY.W + col2im path it replaces."""
+    g = torch.Generator().manual_seed(11)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) * 0.05).cuda()
+    Ho = ops.conv_out_size(H, 3, stride)
+    M = B * Ho * Ho
+    dy = rnd(M, Cout, scale=0.3, seed=34)
+    wd = torch.zeros(C, 9 * Cout, dtype=BF, device='cuda')
+    ops.conv_dgrad_shadows([(w, wd, Cout, C, stride)])
+    dx = torch.full((B * H * H, C), float('nan'), dtype=BF, device='cuda')          # every row must be written exactly once
+    ops.conv_dgrad_grouped([(dy, wd, dx, (B, H, H, C, Cout, stride))])
+    wb = w.to(BF).float()                                                            # the bf16-rounded weights the kernel multiplies
+    xr = torch.zeros(B, C, H, H, device='cuda', requires_grad=True)
+    F.conv2d(xr, wb, stride=stride, padding=1).backward(dy.float().view(B, Ho, Ho, Cout).permute(0, 3, 1, 2))
+    ref = xr.grad.permute(0, 2, 3, 1).reshape(B * H * H, C)
+    assert torch.isfinite(dx.float()).all()
+    assert rel_fro(dx, ref) < 6e-3, rel_fro(dx, ref)
+    # the round-2 path: dcol = dY . W (shadow layout) then the col2im gather
+    Kp = (9 * C + 7) // 8 * 8
+    shadow = torch.zeros(Cout, Kp, dtype=BF, device='cuda')
+    ops.conv_weight_to_shadow(w, shadow, Cout, C, 3, Kp)
+    dcol = ops.gemm(dy, shadow, trans_b=True)
+    old = ops.col2im(dcol, B, H, H, C, 3, stride, Kp)
+    assert rel_fro(dx, old.float().view(B * H * H, C)) < 1e-2                        # (dcol is rounded to bf16 before the 9-tap sum)
+
+
 @pytest.mark.parametrize('M,C', [(5000, 96), (777, 32), (3000, 768)])
 def test_batchnorm(ops, M, C):
     y = rnd(M, C, seed=50) * 2 + 0.5
