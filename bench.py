@@ -74,7 +74,8 @@ def make_inputs(dims, batch, T, seed, device, compact_labels=False):
     return x, ids, mask, labels
 
 
-def build_trainer(batch, use_graph, rank, T=30, workload='base_caption', freeze='freeze_vision', compact_labels=False):
+def build_trainer(batch, use_graph, rank, T=30, workload='base_caption', freeze='freeze_vision', compact_labels=False, grad_payload='fp32',
+                  shard=False):
     from prismer_amd import config as pcfg
     from prismer_amd.model.prismer_caption import PrismerCaption
     from prismer_amd.model.prismer_vqa import PrismerVQA
@@ -95,7 +96,7 @@ def build_trainer(batch, use_graph, rank, T=30, workload='base_caption', freeze=
         model = PrismerCaption(cfg).cuda()
     tr = Trainer(model, lr=5e-5, weight_decay=0.05, total_steps=10000, task='caption', use_graph=use_graph,
                  micro_batches=int(os.environ.get('PRISMER_MICRO_BATCHES', '1')),
-                 side_stream=os.environ.get('PRISMER_SIDE_STREAM', '0') != '0')
+                 side_stream=os.environ.get('PRISMER_SIDE_STREAM', '0') != '0', grad_payload=grad_payload, shard_optimizer=shard)
     from prismer_amd import ops as _ops
     _ops.WQ.enabled = os.environ.get('PRISMER_WGRAD_QUEUE', '1') != '0'      # A/B switch: grouped deferred wgrads
     _ops.WQ.eager_flush = os.environ.get('PRISMER_WGRAD_EAGER_FLUSH', '0') != '0'
@@ -137,7 +138,7 @@ def pmc_traffic():
     WRITE_SIZE in separate runs of this bench, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md; tools/run13.sh is the
     recipe); counters cannot be read from inside the process, so this is (None, None) when the file is absent.  Returns the
     per-launch bytes and the launch count the passes saw, so that a stale file shows next to the live launch count."""
-    for name in ('r2_pmc_gemm.json', 'r1_pmc_gemm.json'):
+    for name in ('r3_pmc_gemm.json', 'r2_pmc_gemm.json', 'r1_pmc_gemm.json'):
         p = os.path.join(ROOT, 'profiles', name)
         if os.path.isfile(p):
             d = json.load(open(p))
@@ -200,6 +201,12 @@ def main():
     ap.add_argument('--compact-labels', action='store_true',
                     help='label experts as uint8 maps + feature tables, in-painted on the device (SURVEY 8f #2; secondary: the headline '
                          'keeps the reference loader contract of dense 64-channel fp32 maps)')
+    ap.add_argument('--grad-payload', default='fp32', choices=['fp32', 'bf16'],
+                    help='N > 1: gradient exchange payload. fp32 = DDP semantics (default); bf16 = pre-scaled by 1/world, half the bytes')
+    ap.add_argument('--shard', default='none', choices=['none', 'zero1', 'rs_ag'],
+                    help='N > 1: none = replicated AdamW behind an all-reduce; zero1 = sharded AdamW + broadcasts; rs_ag = reduce-scatter + '
+                         'sharded AdamW + all-gather (FSDP SHARD_GRAD_OP pattern)')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary workloads (BASELINE configs 2 and 5) of the N=1 line')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -246,7 +253,8 @@ def main():
         assert ranks_seen == world, (ranks_seen, world)
 
     tr, dims, n_train = build_trainer(args.batch, not args.no_graph, rank, workload=args.workload, freeze=args.freeze,
-                                      compact_labels=args.compact_labels)
+                                      compact_labels=args.compact_labels, grad_payload=args.grad_payload,
+                                      shard={'none': False, 'zero1': True, 'rs_ag': 'rs_ag'}[args.shard])
     # algorithmic train GFLOP per image (SURVEY 8d / BASELINE.md section 2): (freeze_vision, none)
     gf_img = {'base_caption': (TRAIN_GF_PER_IMG, 307.26), 'z_base_caption': (134.30, 167.59), 'large_vqa': (2987.8, 3724.7)}[args.workload][
         0 if args.freeze == 'freeze_vision' else 1]
@@ -260,6 +268,8 @@ def main():
     for _ in range(args.warmup):
         tr.step()
     barrier()
+    if world > 1 and tr.exchange is not None:
+        tr.exchange.timing = True                          # events on the communication stream + around the join (a few us per step)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = tr.step()
@@ -271,6 +281,10 @@ def main():
         dt = t.item()
     ms = dt / args.steps * 1e3
     value = world * args.batch * args.steps / dt
+    comm = tr.comm_timing() if world > 1 else None
+    if comm is not None:                                   # diagnosis of the first multi-GPU run: how much of the exchange is hidden
+        comm['rccl_env'] = {k: os.environ[k] for k in ('NCCL_ALGO', 'NCCL_PROTO', 'NCCL_MIN_NCHANNELS', 'NCCL_MAX_NCHANNELS', 'NCCL_NCHANNELS_PER_PEER',
+                                                        'RCCL_MSCCL_ENABLE', 'HSA_ENABLE_IPC_MODE_LEGACY') if k in os.environ}
     final_loss = float(loss.item())
     if not args.no_graph and not (tr.use_graph and tr.graphs is not None):
         raise SystemExit('bench.py: hipGraph replay was requested but the Trainer is running eager launches')
@@ -290,7 +304,7 @@ def main():
                                 'freeze_vision, weighted loss, dropout 0.1, train-mode BatchNorm'),
                    'model': {'base_caption': 'prismer_base', 'z_base_caption': 'prismerz_base', 'large_vqa': 'prismer_large (VQA, 480^2, T=40)'}[args.workload], 'global_batch': world * args.batch, 'seq_len': dims.seq_len, 'text_len': 30 if args.workload == 'base_caption' else 40,
                    'parallelism': f'dp{world}', 'ranks_in_collective': ranks_seen, 'collective_backend': ('rccl' if backend == 'nccl' else backend) if world > 1 else None,
-                   'grad_exchange': tr.exchange_desc() if world > 1 else None,
+                   'grad_exchange': dict(tr.exchange_desc() or {}, **(comm or {})) if world > 1 else None,
                    'trainable_params': n_train, 'hip_graph': bool(tr.use_graph and tr.graphs is not None),
                    'final_loss': round(final_loss, 4)},
         'step_tflops': round(value / world * gf_img / 1e3, 2),
@@ -311,6 +325,36 @@ def main():
             out['kernel_families_ms_per_step'] = {k: round(v['ms_per_step'], 3) for k, v in fam.items()}
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
+        if headline and not args.no_secondary and not args.no_graph:
+            # BASELINE configs 2 and 5 on one GPU, under the same clock as the headline (round 3): 10 timed steps each after 3 warm-up
+            # steps, hipGraph replay, same synthetic-input recipe.  Reported beside the headline so that a dispatch tuned on one
+            # workload cannot silently regress another.
+            del tr
+            import gc
+            gc.collect(); torch.cuda.empty_cache()
+            sec = {}
+            for wl, bs, gf in (('z_base_caption', 32, 134.30), ('large_vqa', 16, 2987.8)):
+                try:
+                    tr2, d2, _ = build_trainer(bs, True, 0, workload=wl)
+                    for _ in range(3):
+                        tr2.step()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(10):
+                        l2 = tr2.step()
+                    torch.cuda.synchronize()
+                    dt2 = time.perf_counter() - t1
+                    v2 = bs * 10 / dt2
+                    sec[wl] = dict(value=round(v2, 2), unit='images/sec', batch=bs, steps=10, warmup=3, ms_per_step=round(dt2 / 10 * 1e3, 3),
+                                   step_mfma_frac=round(v2 * gf / 1e3 / PEAK_TFLOPS, 4), hip_graph=bool(tr2.graphs is not None),
+                                   final_loss=round(float(l2.item()), 4),
+                                   config='PrismerZ-BASE caption fine-tune, 224^2, rgb only (BASELINE config 2)' if wl == 'z_base_caption' else
+                                          'Prismer-LARGE VQAv2 fine-tune, 480^2, 6 experts, T=35+5, weighted loss (BASELINE config 5, one GPU)')
+                    del tr2
+                    gc.collect(); torch.cuda.empty_cache()
+                except Exception as e:                     # a secondary leg must never take the headline line down
+                    sec[wl] = dict(error=f'{type(e).__name__}: {e}'[:300])
+            out['secondary'] = sec
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

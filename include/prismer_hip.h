@@ -299,6 +299,8 @@ int ph_adamw(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, co
  * separate pass over the 1 GB gradient buffers) */
 int ph_cast_f32_to_bf16(const float* x, void* y, int64_t n, hipStream_t stream);
 int ph_cast_bf16_to_f32(const void* x, float* y, int64_t n, hipStream_t stream);
+/* y = bf16(x * scale): the gradient pack of the bf16 exchange payload, pre-scaled by 1/world BEFORE the rounding (round 3) */
+int ph_scale_cast_f32_to_bf16(const float* x, void* y, int64_t n, float scale, hipStream_t stream);
 /* out[n] += sum_m x[m,n]  (bias gradients) */
 int ph_colsum_bf16(const void* x, int M, int N, int ld, float* out, hipStream_t stream);
 /* the same for n <= PH_GEMM_GROUP_MAX tensors in one launch (the bias gradients that go with ph_gemm_grouped_bf16) */

@@ -356,3 +356,27 @@ def adamw_step(p, g, m, v, step, lr, wd=0.05, b1=0.9, b2=0.999, eps=1e-8):
     mh = m / (1 - b1 ** step)
     vh = v / (1 - b2 ** step)
     return p - lr * mh / (vh.sqrt() + eps), m, v
+
+
+def rank_answers(dec_sd, enc_out, start_ids, start_att, ans_ids, ans_att, k_test, heads, pad=1):
+    """`inference='rank'` of the caption and VQA heads (model/prismer_caption.py:59-112, model/prismer_vqa.py:64-113):
+    (1) logits of the prompt's last position -> softmax -> probability of every candidate answer's FIRST token -> top-k answers;
+    (2) prompt (tiled k times, reference `tile`: item-major) || each of the k answers, targets = the answer span only (pad -> -100);
+    (3) length-normalised log-probability  -loss / #target tokens  (loss = per-sample SUM of the shifted, label-smoothed CE of
+        text_decoder, roberta.py:381-387) -> arg-max over k -> the answer index.
+    enc_out: [B, S, D] encoder states (batch first).  Returns (best answer index [B], topk_ids [B, k], log-probs [B, k])."""
+    B = start_ids.shape[0]
+    logits, _ = text_decoder(dec_sd, start_ids, start_att, enc_out, heads)
+    prob_first = torch.softmax(logits[:, -1, :].float(), dim=1).index_select(1, ans_ids[:, 0])
+    _, topk_ids = prob_first.topk(k_test, dim=1)
+    a_ids = torch.cat([ans_ids.index_select(0, t) for t in topk_ids], 0)
+    a_att = torch.cat([ans_att.index_select(0, t) for t in topk_ids], 0)
+    rep = torch.arange(B).repeat_interleave(k_test)                     # reference tile(): rows b*k .. b*k+k-1 are item b
+    input_ids = torch.cat([start_ids[rep], a_ids], 1).long()
+    att = torch.cat([start_att[rep], a_att], 1)
+    targets = input_ids.masked_fill(input_ids == pad, -100)
+    targets[:, :-ans_ids.shape[1]] = -100
+    _, loss = text_decoder(dec_sd, input_ids, att, enc_out[rep], heads, targets, pad=pad)
+    lp = (-loss / (targets != -100).sum(-1)).view(-1, k_test)
+    best = lp.argmax(1)
+    return topk_ids[torch.arange(B), best], topk_ids, lp

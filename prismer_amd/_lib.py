@@ -158,6 +158,7 @@ _SIGS = {
                          c_float, c_float, c_int, c_void_p]),
     'ph_cast_f32_to_bf16': (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     'ph_cast_bf16_to_f32': (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
+    'ph_scale_cast_f32_to_bf16': (c_int, [c_void_p, c_void_p, c_i64, c_float, c_void_p]),
     'ph_colsum_bf16': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'ph_colsum_grouped_bf16': (c_int, [c_void_p, c_int, c_void_p]),
     'ph_layernorm_bwd_blocks': (c_int, [c_int]),

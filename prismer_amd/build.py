@@ -32,7 +32,7 @@ def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     stamp = os.path.join(LIBDIR, 'build.stamp')
     dig = _digest()
-    if not force and os.path.isfile(LIB) and os.path.isfile(COMM_LIB) and os.path.isfile(stamp) and open(stamp).read() == dig:
+    if not force and os.path.isfile(LIB) and os.path.isfile(stamp) and open(stamp).read() == dig:
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = []
@@ -50,10 +50,14 @@ def build(force=False, verbose=True):
     r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n' + r.stderr[-4000:])
+    # the RCCL transport is optional (transport='native' of the Trainer): a box without <rccl/rccl.h> still gets the compute library
     r = subprocess.run([hipcc, '-O2', '-std=c++17', '-fPIC', '-shared', '-I/opt/rocm/include', os.path.join(CSRC, 'comm.cpp'), '-o', COMM_LIB,
                         '-ldl'], capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError('hipcc failed on comm.cpp:\n' + r.stderr[-4000:])
+        import warnings
+        warnings.warn('libprismer_comm.so (native RCCL gradient exchange) was not built: ' + r.stderr[-500:])
+        if os.path.isfile(COMM_LIB):
+            os.remove(COMM_LIB)
     open(stamp, 'w').write(dig)
     if verbose:
         print(f'built {LIB} ({os.path.getsize(LIB) / 1e6:.1f} MB)')

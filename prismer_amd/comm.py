@@ -16,7 +16,10 @@ def lib():
     if _lib is None:
         path = _build.COMM_LIB
         if not os.path.isfile(path):
-            _build.build(verbose=False)
+            _build.build(force=True, verbose=False)
+        if not os.path.isfile(path):
+            raise RuntimeError('libprismer_comm.so is not available on this machine (built without <rccl/rccl.h>?); '
+                               "use transport='torch.distributed'")
         L = C.CDLL(path)
         L.ph_comm_last_error.restype = C.c_char_p
         L.ph_comm_unique_id.argtypes = [C.c_void_p]

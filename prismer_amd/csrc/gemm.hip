@@ -91,7 +91,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int block_i
   if constexpr (CONV == 2) coltaps_of<BN>(p.cv, n0, p.N, ct);
   auto gload = [&](int kt, u32x4 (&xa)[BM * 8 / 256], u32x4 (&xb)[BN * 8 / 256]) {
     int k0 = kt * BK;
-    constexpr bool KF = PF > 1;                 // ring kernels are only launched when K % BK == 0
+    // plain ring kernels are only launched when K % BK == 0 (no k predicate); with a gathered operand K = taps * C is any multiple
+    // of 8 and the OTHER operand keeps its predicate -- the gather zero-fills k >= K, but 0 x (whatever lies behind the weight row,
+    // possibly NaN bit patterns at the end of an allocation) is not 0
+    constexpr bool KF = PF > 1 && CONV == 0;
     if constexpr (CONV == 1) load_kc_conv<BM>(p.cv, p.A, px, k0, xa);
     else if (TA) load_ks<BM, KF>(p.A, p.lda, m0, p.M, k0, p.K, xa, tid); else load_kc<BM, KF>(p.A, p.lda, m0, p.M, k0, p.K, xa, tid);
     if constexpr (CONV == 2) load_ks_conv<BN>(p.cv, p.B, ct, k0, p.K, xb);

@@ -55,14 +55,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   }
 }
 
-__global__ __launch_bounds__(256) void cast_f2b_kernel(const float* __restrict__ x, bf16* __restrict__ y, int64_t n) {
+__global__ __launch_bounds__(256) void cast_f2b_kernel(const float* __restrict__ x, bf16* __restrict__ y, int64_t n, float scale) {
   int64_t n4 = n >> 2;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     f32x4 t = reinterpret_cast<const f32x4*>(x)[i];
-    bf16x4 o = {f2bf(t[0]), f2bf(t[1]), f2bf(t[2]), f2bf(t[3])};
+    bf16x4 o = {f2bf(t[0] * scale), f2bf(t[1] * scale), f2bf(t[2] * scale), f2bf(t[3] * scale)};
     reinterpret_cast<bf16x4*>(y)[i] = o;
   }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { int64_t i = (n4 << 2) + threadIdx.x; y[i] = f2bf(x[i]); }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { int64_t i = (n4 << 2) + threadIdx.x; y[i] = f2bf(x[i] * scale); }
 }
 __global__ __launch_bounds__(256) void cast_b2f_kernel(const bf16* __restrict__ x, float* __restrict__ y, int64_t n) {
   int64_t n4 = n >> 2;
@@ -323,7 +323,14 @@ extern "C" int ph_adamw(float* p, float* g, float* m, float* v, void* p_bf16, in
 extern "C" int ph_cast_f32_to_bf16(const float* x, void* y, int64_t n, hipStream_t stream) {
   PH_CHECK_ARG(x && y && n > 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 7) == 0, "ph_cast_f32_to_bf16: bad args");
   ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_cast_f32_to_bf16");
-  hipLaunchKernelGGL(cast_f2b_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, stream, x, (bf16*)y, n);
+  hipLaunchKernelGGL(cast_f2b_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, stream, x, (bf16*)y, n, 1.0f);
+  PH_LAUNCH_CHECK("cast_f2b_kernel");
+  return PH_OK;
+}
+extern "C" int ph_scale_cast_f32_to_bf16(const float* x, void* y, int64_t n, float scale, hipStream_t stream) {
+  PH_CHECK_ARG(x && y && n > 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 7) == 0, "ph_scale_cast_f32_to_bf16: bad args");
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_scale_cast_f32_to_bf16");
+  hipLaunchKernelGGL(cast_f2b_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, stream, x, (bf16*)y, n, scale);
   PH_LAUNCH_CHECK("cast_f2b_kernel");
   return PH_OK;
 }

@@ -5,8 +5,16 @@ Each rank owns flat fp32 gradient buffers (prismer_amd/store.py).  The Trainer c
 layer order; as soon as a segment has finished, the buffer ranges whose gradients are complete are handed to
 `GradExchange.issue`, which -- on the communication stream, behind an event recorded after that segment -- packs the range
 to bf16 (half the bytes on the xGMI links: 485 MB instead of 970 MB per step for Prismer-BASE), SUM-all-reduces it in chunks
-and unpacks it back into the fp32 buffer, all overlapping the remaining backward.  The 1/world factor is folded into the
-fused AdamW (`grad_scale`).  `payload='fp32'` skips the pack/unpack (bit-for-bit DDP semantics).
+and unpacks it back into the fp32 buffer, all overlapping the remaining backward.
+
+Payload (round 3): the DEFAULT is 'fp32' -- DDP's own payload (SUM of fp32 gradients, 1/world folded into the fused AdamW as
+`post_scale`).  'bf16' is opt-in: every rank pre-scales its gradient by 1/world BEFORE the cast (the sum of world bf16 values
+then has the magnitude of one of them: no overflow head-room lost, no extra rounding step after the sum) and `post_scale` is 1.
+
+Mode (round 3): 'allreduce' (above) or 'rs_ag' -- reduce-scatter + all-gather, the all-links form SURVEY 8e asks for and the
+communication pattern of accelerate's FSDP SHARD_GRAD_OP flag (train_caption.py:56-66): each issued range is cut into `world`
+equal chunks, rank r receives the reduced chunk r (reduce-scatter: half the bytes of an all-reduce on every link), runs AdamW on
+the chunks it owns (optimizer state and update time 1/world) and the updated fp32 parameters are all-gathered per range.
 
 Transport: RCCL, reached either through torch.distributed (backend 'nccl' = RCCL; default) or through the library's own
 communicator (include/prismer_comm.h, `transport='native'`).  Nothing here needs a GPU by itself: the pack / unpack / reduce
@@ -49,22 +57,41 @@ def contiguous_stages(names, offset, numel, stage_of, align):
     return [tuple(r) for r in runs]
 
 
+RS_ALIGN = 256          # chunk granularity of the reduce-scatter (elements): keeps every owned piece 1 KB aligned for the AdamW kernel
+
+
+def rs_chunk(n, world):
+    """elements per rank when a range of n elements is reduce-scattered over `world` ranks"""
+    return ((n + world - 1) // world + RS_ALIGN - 1) // RS_ALIGN * RS_ALIGN
+
+
 class GradExchange:
-    def __init__(self, world, all_reduce, pack=None, unpack=None, payload='bf16', chunk_elems=64 << 20, comm_stream=None,
-                 transport='torch.distributed'):
+    def __init__(self, world, all_reduce, pack=None, unpack=None, payload='fp32', chunk_elems=64 << 20, comm_stream=None,
+                 transport='torch.distributed', mode='allreduce', rank=0, reduce_scatter=None, all_gather=None):
         """all_reduce(t): in-place SUM over ranks, enqueued on the CURRENT stream (torch: dist.all_reduce; native:
-        ph_allreduce_bucket).  pack(src_f32, dst_bf16) / unpack(src_bf16, dst_f32): cast kernels (bf16 payload only)."""
-        assert payload in ('bf16', 'fp32')
+        ph_allreduce_bucket).  pack(src_f32, dst_bf16, scale) / unpack(src_bf16, dst_f32): cast kernels (bf16 payload only).
+        mode 'rs_ag': reduce_scatter(out[c], inp[world * c]) and all_gather(out[world * c], inp[c]) (torch:
+        dist.reduce_scatter_tensor / all_gather_into_tensor)."""
+        assert payload in ('bf16', 'fp32') and mode in ('allreduce', 'rs_ag')
         self.world, self.all_reduce, self.pack, self.unpack = world, all_reduce, pack, unpack
         self.payload, self.chunk, self.comm_stream, self.transport = payload, chunk_elems, comm_stream, transport
+        self.mode, self.rank, self.reduce_scatter, self.all_gather = mode, rank, reduce_scatter, all_gather
+        # what is left of the 1/world average after the exchange: the bf16 payload is pre-scaled, the fp32 one (DDP's) is not
+        self.post_scale = 1.0 if payload == 'bf16' else 1.0 / world
         self.scratch = {}          # id(flat) -> bf16 bucket buffer of the same length
+        self.stage = {}            # (id(flat), lo) -> (staging buffer [world * c], reduced chunk [c])  (rs_ag)
+        self.owned = {}            # id(flat) -> {lo: (a, b)}: the piece of range [lo, hi) this rank owns after the reduce-scatter
+        self.ranges = {}           # id(flat) -> {lo: hi}
         self.log = []              # [(tag, lo, hi, n_collectives)] in issue order (tests assert the overlap structure on this)
         self.bytes_per_step = 0
+        self.timing = False        # True: every issue() is bracketed by events on the communication stream (bench.py --gpus N)
+        self.events = []           # [(start, end)] of the current step
+        self.comm_ms = []          # per finished step: summed duration of its issue() brackets (busy time of the communication stream)
 
     def describe(self):
-        return dict(payload=self.payload, transport=self.transport, chunk_mb=self.chunk * (2 if self.payload == 'bf16' else 4) >> 20,
+        return dict(payload=self.payload, transport=self.transport, mode=self.mode, chunk_mb=self.chunk * (2 if self.payload == 'bf16' else 4) >> 20,
                     collectives_per_step=sum(e[3] for e in self.log_last), bytes_per_step=self.bytes_last,
-                    ranges_per_step=len(self.log_last))
+                    ranges_per_step=len(self.log_last), post_scale=self.post_scale)
 
     log_last, bytes_last = (), 0
 
@@ -72,6 +99,17 @@ class GradExchange:
         if self.log:
             self.log_last, self.bytes_last = tuple(self.log), self.bytes_per_step
         self.log, self.bytes_per_step = [], 0
+        if self.timing and self.events:
+            pend = self.events
+            self.events = []
+            self._pending = getattr(self, '_pending', []) + [pend]
+
+    def collect_timing(self):
+        """(after a device synchronise) ms the communication stream was busy, per recorded step"""
+        steps = getattr(self, '_pending', []) + ([self.events] if self.events else [])
+        self._pending, self.events = [], []
+        self.comm_ms += [sum(a.elapsed_time(b) for a, b in st) for st in steps]
+        return self.comm_ms
 
     def _bucket(self, flat):
         b = self.scratch.get(id(flat))
@@ -89,18 +127,77 @@ class GradExchange:
             self.comm_stream.wait_event(after)
         n = 0
         with ctx:
-            for a, b in bucket_ranges(hi, self.chunk, lo):
-                if self.payload == 'bf16':
-                    buf = self._bucket(flat)
-                    self.pack(flat[a:b], buf[a:b])
-                    self.all_reduce(buf[a:b])
-                    self.unpack(buf[a:b], flat[a:b])
-                    self.bytes_per_step += 2 * (b - a)
-                else:
-                    self.all_reduce(flat[a:b])
-                    self.bytes_per_step += 4 * (b - a)
-                n += 1
+            if self.timing:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            if self.mode == 'rs_ag':
+                self._issue_rs(flat, lo, hi)
+                n = 1
+            else:
+                for a, b in bucket_ranges(hi, self.chunk, lo):
+                    if self.payload == 'bf16':
+                        buf = self._bucket(flat)
+                        self.pack(flat[a:b], buf[a:b], 1.0 / self.world)
+                        self.all_reduce(buf[a:b])
+                        self.unpack(buf[a:b], flat[a:b])
+                        self.bytes_per_step += 2 * (b - a)
+                    else:
+                        self.all_reduce(flat[a:b])
+                        self.bytes_per_step += 4 * (b - a)
+                    n += 1
+            if self.timing:
+                ev1.record()
+                self.events.append((ev0, ev1))
         self.log.append((tag, lo, hi, n))
+
+    # ---------------------------------------------------------------------------------------- reduce-scatter / all-gather
+    def piece(self, lo, hi):
+        """[a, b): the part of range [lo, hi) rank `self.rank` owns (chunk r of `world` equal chunks; the last ones may be short
+        or empty)"""
+        c = rs_chunk(hi - lo, self.world)
+        a = min(lo + self.rank * c, hi)
+        return a, min(a + c, hi)
+
+    def _issue_rs(self, flat, lo, hi):
+        n, W = hi - lo, self.world
+        c = rs_chunk(n, W)
+        key = (id(flat), lo)
+        if key not in self.stage:
+            dt = torch.bfloat16 if self.payload == 'bf16' else torch.float32
+            self.stage[key] = (torch.zeros(W * c, dtype=dt, device=flat.device), torch.empty(c, dtype=dt, device=flat.device))
+        stage, red = self.stage[key]
+        if self.payload == 'bf16':
+            self.pack(flat[lo:hi], stage[:n], 1.0 / W)                  # (the pad tail of the staging buffer stays zero)
+        else:
+            stage[:n].copy_(flat[lo:hi])
+        self.reduce_scatter(red, stage)
+        a, b = self.piece(lo, hi)
+        if b > a:
+            if self.payload == 'bf16':
+                self.unpack(red[:b - a], flat[a:b])
+            else:
+                flat[a:b].copy_(red[:b - a])
+        self.owned.setdefault(id(flat), {})[lo] = (a, b)
+        self.ranges.setdefault(id(flat), {})[lo] = hi
+        self.bytes_per_step += stage.element_size() * n * (W - 1) // W
+
+    def gather(self, flat_grad, values):
+        """all-gather of `values` (fp32 master parameters, same indexing as the gradient buffer `flat_grad` whose ranges were
+        reduce-scattered): every rank contributes the pieces it owns and receives everybody else's.  Enqueued on the CURRENT stream."""
+        W = self.world
+        for lo, hi in sorted(self.ranges.get(id(flat_grad), {}).items()):
+            n = hi - lo
+            c = rs_chunk(n, W)
+            key = ('ag', id(flat_grad), lo)
+            if key not in self.stage:
+                self.stage[key] = (torch.empty(W * c, dtype=values.dtype, device=values.device), torch.zeros(c, dtype=values.dtype, device=values.device))
+            full, mine = self.stage[key]
+            a, b = self.piece(lo, hi)
+            if b > a:
+                mine[:b - a].copy_(values[a:b])
+            self.all_gather(full, mine)
+            values[lo:hi].copy_(full[:n])
+            self.bytes_per_step += values.element_size() * n * (W - 1) // W
 
 
 class _null:

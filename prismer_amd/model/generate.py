@@ -62,6 +62,7 @@ def beam_search_from_logits(step_fn, input_ids, num_beams=3, max_length=20, min_
         hyp_len[b, s] = length[ok]
         n_hyp[ok & (n_hyp < nb)] += 1
 
+    T_start = cur
     while cur < Tmax:
         logits = step_fn(ids[:, :cur])
         logp = torch.log_softmax(logits.float(), dim=-1)
@@ -102,6 +103,9 @@ def beam_search_from_logits(step_fn, input_ids, num_beams=3, max_length=20, min_
         if reorder_fn is not None:
             reorder_fn(rows)
         cur += 1
+        # transformers breaks out once every item is done (beam_scorer.is_done); one small device->host sync every 4 steps here
+        if (cur - T_start) % 4 == 0 and bool(done.all()):
+            break
     # finalize: running beams of unfinished items become hypotheses (score / cur_len ** lp)
     cur_ids = ids.view(B, nb, Tmax)
     for k in range(nb):

@@ -21,7 +21,7 @@ class PrismerCaption(Prismer):
         t = self._tokenize(text, return_tensors='pt', **kw).to(device)
         return t.input_ids, t.attention_mask
 
-    def forward(self, experts, caption=None, answer=None, train=True, prefix='', inference='generate', k_test=32):
+    def forward(self, experts, caption=None, answer=None, train=True, prefix='', inference='generate', k_test=32, return_scores=False):
         device = experts['rgb'].device
         pad = self.text_decoder.config.pad_token_id
         if train:
@@ -79,4 +79,6 @@ class PrismerCaption(Prismer):
             out = self.text_decoder(input_ids, attention_mask=att, encoder_hidden_states=enc, labels=targets, return_dict=True)
             lp = (-out.loss / torch.sum(targets != -100, dim=-1)).view(-1, k_test)
             best = lp.argmax(dim=1)
+            if return_scores:                                   # (extension for the parity tests: the candidates and their scores)
+                return topk_ids[best >= 0, best], topk_ids, lp
             return topk_ids[best >= 0, best]

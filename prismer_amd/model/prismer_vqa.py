@@ -14,7 +14,7 @@ class PrismerVQA(Prismer):
         t = self._tokenize(text, return_tensors='pt', **kw).to(device)
         return t.input_ids, t.attention_mask
 
-    def forward(self, experts, question, answer=None, weights=None, train=True, inference='rank', k_test=128):
+    def forward(self, experts, question, answer=None, weights=None, train=True, inference='rank', k_test=128, return_scores=False):
         device = experts['rgb'].device
         pad = self.text_decoder.config.pad_token_id
         if isinstance(question, (list, tuple)) and question and isinstance(question[0], str):
@@ -59,4 +59,6 @@ class PrismerVQA(Prismer):
             out = self.text_decoder(input_ids, attention_mask=att, encoder_hidden_states=tile(enc, 0, k_test), labels=targets, return_dict=True)
             lp = (-out.loss / torch.sum(targets != -100, dim=-1)).view(-1, k_test)
             best = lp.argmax(dim=1)
+            if return_scores:                                   # (extension for the parity tests: the candidates and their scores)
+                return topk_ids[best >= 0, best], topk_ids, lp
             return topk_ids[best >= 0, best]

@@ -278,5 +278,5 @@ def load_decoder(name: str, config, checkpoint_path: str = None):
         raise RuntimeError(f'Model {name} not found')
     roberta = RobertaForCausalLMModified(config)
     if checkpoint_path is not None:
-        roberta.load_state_dict(convert_roberta_state_dict(torch.load(checkpoint_path, map_location='cpu', weights_only=False)), strict=False)
+        roberta.load_state_dict(convert_roberta_state_dict(torch.load(checkpoint_path, map_location='cpu', weights_only=True)), strict=False)      # (a plain state dict: no unpickling of code)
     return roberta

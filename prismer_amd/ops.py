@@ -628,10 +628,13 @@ def adamw(p, g, m, v, p_bf16, n, hyper, beta1=0.9, beta2=0.999, eps=1e-8, weight
                        weight_decay, grad_scale, int(zero_grad), _stream()), 'ph_adamw')
 
 
-def cast_to_bf16(x, out=None):
+def cast_to_bf16(x, out=None, scale=1.0):
     if out is None:
         out = torch.empty(x.shape, dtype=BF16, device=x.device)
-    check(lib.ph_cast_f32_to_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), 'ph_cast_f32_to_bf16')
+    if scale == 1.0:
+        check(lib.ph_cast_f32_to_bf16(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), 'ph_cast_f32_to_bf16')
+    else:
+        check(lib.ph_scale_cast_f32_to_bf16(x.data_ptr(), out.data_ptr(), x.numel(), float(scale), _stream()), 'ph_scale_cast_f32_to_bf16')
     return out
 
 

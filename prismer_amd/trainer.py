@@ -14,8 +14,9 @@ a step cost a handful of graph launches on the host; the collectives stay outsid
 stream events), which keeps the multi-GPU path identical to the single-GPU one plus three all_reduce sweeps.  With more
 than one rank the encoder backward is cut after the trunk (Trainer._schedule): the trunk's gradients are exchanged while the
 stems' backward runs, only the stems' own gradients wait on the critical path.
-Data parallel semantics = DDP's: every rank holds all parameters, gradients are summed over ranks and divided by
-world size (folded into the AdamW kernel as grad_scale), BatchNorm uses per-rank batch statistics (no SyncBN in the
+Data parallel semantics = DDP's: every rank holds all parameters, gradients are summed over ranks in fp32 and divided by
+world size (folded into the AdamW kernel as grad_scale; `grad_payload='bf16'` is an opt-in that halves the bytes: each rank
+pre-scales by 1/world and rounds to bf16 before the sum), BatchNorm uses per-rank batch statistics (no SyncBN in the
 reference).  DDP's per-step buffer broadcast from rank 0 is replaced by rank-local BN running statistics
 (documented deviation).
 """
@@ -39,7 +40,7 @@ from .schedules import cosine_lr                          # noqa: E402  (utils.p
 class Trainer:
     def __init__(self, model, lr=5e-5, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8, min_lr=0.0, total_steps=1000,
                  task='caption', use_graph=True, process_group=None, bucket_mb=64, side_stream=False, micro_batches=1, keep_grads=False,
-                 max_text_len=None, grad_payload='bf16', transport='torch.distributed', dec_backward_stages=3, lr_schedule=None,
+                 max_text_len=None, grad_payload='fp32', transport='torch.distributed', dec_backward_stages=3, lr_schedule=None,
                  shard_optimizer=False):
         self.model = model
         self.enc, self.dec = model.expert_encoder, model.text_decoder
@@ -70,11 +71,19 @@ class Trainer:
         # shard_optimizer (ZeRO-1 style, the role of accelerate's --shard_grad_op flag in train_pretrain.py:56-91,104-107): every
         # rank keeps Adam moments for, and updates, only ITS contiguous 1/world slice of each flat buffer, then the owners
         # broadcast their updated fp32 slices.  Optimizer state and AdamW time shrink by 1/world; off by default.
+        # shard_optimizer='rs_ag' (round 3; the communication pattern of FSDP SHARD_GRAD_OP, train_caption.py:56-66): gradients are
+        # REDUCE-SCATTERED per finished range (each rank receives 1/world of every range), AdamW runs on the owned pieces only and the
+        # updated fp32 parameters are ALL-GATHERED -- half the bytes of an all-reduce per link for the gradients, optimizer state and
+        # update 1/world, no broadcast fan-out.
         self.rank = torch.distributed.get_rank(process_group) if self.world > 1 else 0
-        self.shard = bool(shard_optimizer) and self.world > 1
+        self.rs_ag = shard_optimizer == 'rs_ag' and self.world > 1
+        self.shard = bool(shard_optimizer) and not self.rs_ag and self.world > 1
         own = [self._shard_bounds(i)[self.rank] for i in range(len(self.stores))] if self.shard else [(0, st.n_train) for st in self.stores]
+        if self.rs_ag:
+            own = [(0, 0) for _ in self.stores]                # moments live per owned piece (self.piece_state), allocated on first use
         self.m = [torch.zeros(max(hi - lo, 1), dtype=F32, device=dev) for lo, hi in own]
         self.v = [torch.zeros(max(hi - lo, 1), dtype=F32, device=dev) for lo, hi in own]
+        self.piece_state = {}                                  # rs_ag: (store index, a, b) -> (m, v)
         self.hyper = torch.zeros(3, dtype=F32, device=dev)
         # per-step host values travel through a ring of pinned slots: a slot is rewritten only after the async copy that read
         # it last has executed (event per slot), so a host that runs ahead of the device (no loss.item() in the loop) can
@@ -120,6 +129,7 @@ class Trainer:
         else:
             ops.SIDE, ops.POOL, ops.MICRO = None, ops._NoPool(), ops._NoPool()
         self.loss = None
+        self.exposed_events = []
         self.trace = []
         self._grads_clean = False
         self.keep_grads = keep_grads           # True: gradients stay readable after step() (tests); False: AdamW zeroes them
@@ -146,9 +156,20 @@ class Trainer:
         else:
             def reduce_fn(t):
                 torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=self.pg)
-        return GradExchange(self.world, reduce_fn, pack=lambda src, dst: ops.cast_to_bf16(src, out=dst),
+        if (self.rs_ag or self.shard) and transport == 'native':
+            # (the sharded updates issue torch.distributed collectives; a second RCCL communicator driven from another stream is the
+            # classic multi-communicator ordering hazard -- one transport per Trainer)
+            raise ValueError("shard_optimizer uses torch.distributed collectives: combine it with transport='torch.distributed', not 'native'")
+
+        def rs_fn(out, inp):
+            torch.distributed.reduce_scatter_tensor(out, inp, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+
+        def ag_fn(out, inp):
+            torch.distributed.all_gather_into_tensor(out, inp, group=self.pg)
+        return GradExchange(self.world, reduce_fn, pack=lambda src, dst, scale=1.0: ops.cast_to_bf16(src, out=dst, scale=scale),
                             unpack=lambda src, dst: ops.cast_to_f32(src, out=dst), payload=payload, chunk_elems=self.bucket_elems,
-                            comm_stream=self.comm_stream, transport='rccl via ' + ('prismer_comm (native)' if transport == 'native' else 'torch.distributed'))
+                            comm_stream=self.comm_stream, transport='rccl via ' + ('prismer_comm (native)' if transport == 'native' else 'torch.distributed'),
+                            mode='rs_ag' if self.rs_ag else 'allreduce', rank=self.rank, reduce_scatter=rs_fn, all_gather=ag_fn)
 
     def exchange_desc(self):
         return None if self.exchange is None else self.exchange.describe()
@@ -197,7 +218,29 @@ class Trainer:
 
     def _wait_comm(self):
         if self.world > 1:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            cur = torch.cuda.current_stream()
+            if self.exchange is not None and self.exchange.timing:
+                # exposed communication = how long the compute stream sits in this join (everything before it overlapped the backward)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(cur)
+                cur.wait_stream(self.comm_stream)
+                b.record(cur)
+                self.exposed_events.append((a, b))
+                return
+            cur.wait_stream(self.comm_stream)
+
+    exposed_events = []
+
+    def comm_timing(self):
+        """(bench.py --gpus N) after a device synchronise: mean ms per step the communication stream was busy, and the part of it the
+        compute stream had to wait for at the join before the optimizer (the rest overlapped the backward)"""
+        if self.exchange is None:
+            return None
+        busy = self.exchange.collect_timing()
+        exposed = [a.elapsed_time(b) for a, b in self.exposed_events]
+        self.exposed_events = []
+        n = max(len(exposed), 1)
+        return dict(comm_ms_total=round(sum(busy) / max(len(busy), 1), 3), comm_ms_exposed=round(sum(exposed) / n, 3), steps_timed=len(exposed))
 
     # ------------------------------------------------------------------------------------------ step pieces
     def _slices(self, B):
@@ -294,7 +337,7 @@ class Trainer:
         lo, hi = bounds[self.rank]
         if hi > lo:
             ops.adamw(st.master[lo:hi], st.grad[lo:hi], self.m[i], self.v[i], st.shadow[lo:hi], hi - lo, self.hyper, self.betas[0],
-                      self.betas[1], self.eps, self.wd, 1.0 / self.world, zero_grad=False)
+                      self.betas[1], self.eps, self.wd, self._post_scale(), zero_grad=False)
         for k, (a, b) in enumerate(bounds):
             if b > a:
                 src = torch.distributed.get_global_rank(self.pg, k) if self.pg is not None else k
@@ -305,8 +348,37 @@ class Trainer:
     def _adamw(self, i):
         st = self.stores[i]
         ops.adamw(st.master, st.grad, self.m[i], self.v[i], st.shadow, st.n_train, self.hyper, self.betas[0], self.betas[1], self.eps,
-                  self.wd, 1.0 / self.world, zero_grad=not self.keep_grads)
+                  self.wd, self._post_scale(), zero_grad=not self.keep_grads)
         st.refresh_derived()
+
+    def _post_scale(self):
+        """what is left of DDP's 1/world average after the exchange (1/world for the fp32 SUM, 1 for the pre-scaled bf16 payload)"""
+        return 1.0 if self.exchange is None else self.exchange.post_scale
+
+    def _adamw_rs(self, i):
+        """rs_ag: AdamW on the pieces of store i this rank received from the reduce-scatters, all-gather of the updated fp32
+        parameters, bf16 shadows re-derived.  Eager, on the current stream (collectives cannot sit inside a captured segment)."""
+        st = self.stores[i]
+        ex = self.exchange
+        for lo, (a, b) in sorted(ex.owned.get(id(st.grad), {}).items()):
+            if b <= a:
+                continue
+            key = (i, a, b)
+            if key not in self.piece_state:
+                self.piece_state[key] = (torch.zeros(b - a, dtype=F32, device=self.device), torch.zeros(b - a, dtype=F32, device=self.device))
+            m, v = self.piece_state[key]
+            ops.adamw(st.master[a:b], st.grad[a:b], m, v, st.shadow[a:b], b - a, self.hyper, self.betas[0], self.betas[1], self.eps,
+                      self.wd, ex.post_scale, zero_grad=False)
+        ex.gather(st.grad, st.master)
+        ops.cast_to_bf16(st.master[:st.n_train], st.shadow[:st.n_train])
+        st.refresh_derived()
+
+    def _tail_rs(self):
+        """rs_ag: both updates run after the last reduce-scatter (gradients are re-zeroed by the next step's first segment)"""
+        self._adamw_rs(1)
+        self._adamw_rs(0)
+        ops.advance_seed(self.seed)
+        self._grads_clean = False
 
     def _seg_enc_backward_with_dec_adamw(self):
         """one rank: the decoder's gradients are final when the encoder backward starts, and nothing in the encoder backward
@@ -387,9 +459,12 @@ class Trainer:
         for k in range(1, nst):
             sched.append(((lambda k=k: self._seg_dec_backward(cuts[k], cuts[k + 1])), (lambda k=k: self._issue(f'dec{k}'))))
         seg, host = sched[-1]
-        sched[-1] = (seg, lambda host=host: (host(), self._dec_adamw_after_comm()))
+        if not self.rs_ag:
+            sched[-1] = (seg, lambda host=host: (host(), self._dec_adamw_after_comm()))
         sched += [(self._seg_enc_trunk_backward_joined, lambda: self._issue('trunk'))]
-        if self.shard:
+        if self.rs_ag:
+            sched += [(self._seg_enc_front_backward, lambda: (self._issue('front'), self._wait_comm(), self._tail_rs()))]
+        elif self.shard:
             sched += [(self._seg_enc_front_backward, lambda: (self._issue('front'), self._wait_comm(), self._tail_sharded()))]
         else:
             # (stream joins are host actions BETWEEN replays: a wait recorded inside a captured segment would be frozen at capture)
@@ -477,7 +552,8 @@ class Trainer:
         BatchNorm running statistics / counters, the dropout seed, the iteration counter and Python's RNG (instance draws)"""
         return dict(master=[st.master.clone() for st in self.stores], m=[t.clone() for t in self.m], v=[t.clone() for t in self.v],
                     bufs=[b.clone() for mod in (self.enc, self.dec) for b in mod.buffers()], seed=self.seed.clone(), it=self.it,
-                    rng=random.getstate(), grads=[st.grad.clone() for st in self.stores], clean=self._grads_clean)
+                    rng=random.getstate(), grads=[st.grad.clone() for st in self.stores], clean=self._grads_clean,
+                    pieces={k: (m.clone(), v.clone()) for k, (m, v) in self.piece_state.items()})
 
     def _restore(self, snap):
         for st, t in zip(self.stores, snap['master']):
@@ -489,6 +565,10 @@ class Trainer:
             b.copy_(t)
         for st, t in zip(self.stores, snap['grads']):
             st.grad.copy_(t)
+        for m, v in self.piece_state.values():                 # rs_ag: moments of pieces first touched during the warm-up start from zero
+            m.zero_(); v.zero_()
+        for k, (m, v) in snap.get('pieces', {}).items():
+            self.piece_state[k][0].copy_(m); self.piece_state[k][1].copy_(v)
         self.seed.copy_(snap['seed'])
         self.it, self._grads_clean = snap['it'], snap['clean']
         random.setstate(snap['rng'])
@@ -563,13 +643,16 @@ class Trainer:
         the model weights, train_caption.py:103-108).  With shard_optimizer the Adam moments are this rank's slice."""
         return dict(it=self.it, m=[t.clone() for t in self.m], v=[t.clone() for t in self.v],
                     model={k: t.detach().clone() for k, t in self.model.state_dict().items()},      # (state_dict() aliases the live buffers)
-                    seed=self.seed.clone(), rng=random.getstate(), world=self.world, shard_optimizer=self.shard)
+                    seed=self.seed.clone(), rng=random.getstate(), world=self.world,
+                    shard_optimizer='rs_ag' if self.rs_ag else self.shard,
+                    pieces={k: (m.clone(), v.clone()) for k, (m, v) in self.piece_state.items()})       # rs_ag: moments of the owned pieces
 
     def load_state_dict(self, sd, strict=True):
         """resume: masters (the module parameters are views of the flat buffers), bf16 shadows and derived conv shadows re-derived from
         them, Adam moments, iteration counter (LR schedule position), dropout seed and Python RNG (instance-embedding draws).  Captured
         graphs stay valid: they reference the buffers, not their contents."""
-        if bool(sd.get("shard_optimizer", False)) != self.shard or (self.shard and sd.get("world", 1) != self.world):
+        mine = 'rs_ag' if self.rs_ag else self.shard
+        if (sd.get("shard_optimizer", False) or False) != mine or ((self.shard or self.rs_ag) and sd.get("world", 1) != self.world):
             raise ValueError('Trainer.load_state_dict: optimizer sharding of the checkpoint '
                              f"(shard_optimizer={sd.get('shard_optimizer')}, world={sd.get('world')}) differs from this Trainer's")
         if len(sd['m']) != len(self.m) or any(a.shape != b.shape for a, b in zip(sd['m'] + sd['v'], self.m + self.v)):
@@ -579,6 +662,7 @@ class Trainer:
             st.refresh()
         for dst, src in zip(self.m + self.v, list(sd['m']) + list(sd['v'])):
             dst.copy_(src)
+        self.piece_state = {k: (m.to(self.device).clone(), v.to(self.device).clone()) for k, (m, v) in sd.get('pieces', {}).items()}
         self.it = int(sd['it'])
         if 'seed' in sd:
             self.seed.copy_(sd['seed'])

@@ -58,7 +58,7 @@ def _worker_bf16(rank, world, port, out):
     g = torch.randn(5000) * torch.logspace(-4, 0, 5000)           # gradients spanning four decades
     flat32, flat16 = g.clone(), g.clone()
     ex32 = GradExchange(world, lambda t: dist.all_reduce(t), payload='fp32', chunk_elems=1024)
-    ex16 = GradExchange(world, lambda t: dist.all_reduce(t), pack=lambda s, d: d.copy_(s), unpack=lambda s, d: d.copy_(s),
+    ex16 = GradExchange(world, lambda t: dist.all_reduce(t), pack=lambda s, d, scale=1.0: d.copy_(s * scale), unpack=lambda s, d: d.copy_(s),
                         payload='bf16', chunk_elems=1024)
     for ex, flat in ((ex32, flat32), (ex16, flat16)):
         ex.begin_step()
@@ -77,6 +77,8 @@ def test_bf16_bucket_exchange_matches_fp32_within_1e2():
     mp.spawn(_worker_bf16, args=(world, _free_port(), out), nprocs=world, join=True)
     f32, f16, log, b16, b32 = out[0]
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])       # every rank ends with the same sums
+    # (round 3) the bf16 payload is pre-scaled by 1/world before the rounding: it delivers the MEAN (post_scale 1), the fp32 payload the SUM
+    f16 = f16 * world
     rel = ((f16 - f32).norm() / f32.norm()).item()
     assert rel < 1e-2, rel
     mag = torch.zeros(5000)
@@ -98,3 +100,53 @@ def test_contiguous_stages_cover_the_buffer_in_order():
     runs = contiguous_stages(names, offset, numel, stage.get, 64)
     assert runs == [('last', 0, 128 + 64 + 320), ('mid', 512, 576), ('first', 576, 576 + 128 + 64)]
     assert runs[0][1] == 0 and all(a[2] == b[1] for a, b in zip(runs, runs[1:]))
+
+
+def _worker_rs(rank, world, port, out, payload):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    g = torch.randn(5003) * torch.logspace(-3, 0, 5003)
+    flat = g.clone()
+    ex = GradExchange(world, lambda t: dist.all_reduce(t), pack=lambda s, d, scale=1.0: d.copy_(s * scale), unpack=lambda s, d: d.copy_(s),
+                      payload=payload, mode='rs_ag', rank=rank,
+                      reduce_scatter=lambda o, i: dist.reduce_scatter_tensor(o, i), all_gather=lambda o, i: dist.all_gather_into_tensor(o, i))
+    ex.begin_step()
+    ex.issue(flat, 3000, 5003, 'late')            # ragged: 2003 elements over `world` chunks of 256-element granularity
+    ex.issue(flat, 700, 3000, 'mid')
+    ex.issue(flat, 0, 700, 'early')               # (a range shorter than world * 256: the last ranks own nothing)
+    owned = dict(ex.owned[id(flat)])
+    # "optimizer": the owner turns its reduced gradient piece into new parameter values; everybody else's copy is stale
+    params = torch.full((5003,), float('nan'))
+    for lo, (a, b) in owned.items():
+        params[a:b] = flat[a:b] * ex.post_scale * 2.0 + 1.0
+    ex.gather(flat, params)
+    out[rank] = (flat.clone(), params.clone(), owned, ex.post_scale)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,payload', [(2, 'fp32'), (3, 'fp32'), (2, 'bf16')])
+def test_reduce_scatter_all_gather_exchange(world, payload):
+    """mode='rs_ag': every rank ends up owning disjoint pieces that tile each issued range and hold the reduced gradient there; the
+    all-gather of values computed on the owned pieces reconstructs the same full vector on every rank."""
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_worker_rs, args=(world, _free_port(), out, payload), nprocs=world, join=True)
+    gs = []
+    for r in range(world):
+        torch.manual_seed(100 + r); gs.append(torch.randn(5003) * torch.logspace(-3, 0, 5003))
+    mean = sum(gs) / world
+    cover = torch.zeros(5003)
+    for r in range(world):
+        flat, params, owned, post = out[r]
+        for lo, (a, b) in owned.items():
+            cover[a:b] += 1
+            got = flat[a:b] * post                                               # the average DDP would hand the optimizer
+            tol = 1e-6 if payload == 'fp32' else 2.0 ** -7
+            assert (got - mean[a:b]).abs().max() <= tol * sum(x[a:b].abs() for x in gs).max() + 1e-9
+    assert torch.equal(cover, torch.ones(5003))                                  # the owned pieces tile [0, 5003) exactly once
+    ref = out[0][1]
+    assert torch.isfinite(ref).all()
+    for r in range(1, world):
+        assert torch.equal(out[r][1], ref)                                       # identical parameters everywhere after the gather
+    want = mean * 2.0 + 1.0
+    assert (ref - want).abs().max() < (1e-5 if payload == 'fp32' else 5e-2)

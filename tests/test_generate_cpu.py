@@ -46,7 +46,7 @@ def test_vectorised_beam_search_matches_loop_oracle(seed, lp, eos_boost):
         return torch.log_softmax(z.float(), -1).tolist()
     want = beam_search_loops(step_list, prompt.tolist(), nb, Tmax, Tmin, eos, pad, lp)
     assert [g_.tolist() for g_ in got] == want
-    assert all(len(w) <= Tmax for w in want) and len(calls) == Tmax - T0
+    assert all(len(w) <= Tmax for w in want) and len(calls) <= Tmax - T0      # (round 3: the loop leaves once every item is done, like transformers)
     assert all((eos not in w[:Tmin]) for w in want)                        # min_length: no EOS before position Tmin
 
 

@@ -21,6 +21,8 @@ def _setup(name, B=None):
     enc, dec, esd, dsd = build(case)
     enc.eval(); dec.eval()
     x = case.inputs()[0]
+    if B is not None:                                           # the first B items of the fixture's batch
+        x = {k: ({kk: vv[:B] for kk, vv in v.items()} if isinstance(v, dict) else v[:B]) for k, v in x.items()}
     tab = case.instance_table(x)
     enc.instance_table = None if tab is None else torch.tensor(tab, dtype=torch.int32).cuda()
     with torch.no_grad():
@@ -74,10 +76,11 @@ def test_cached_decode_matches_full_prefix_recompute(name):
         assert rel_fro(lg, full) < 4e-3
 
 
-@pytest.mark.parametrize('name,lp', [('tiny_caption', 1.0), ('tiny_vqa', -1.0)])
+@pytest.mark.parametrize('name,lp', [('tiny_caption', 1.0), ('tiny_vqa', -1.0), ('base_b8', 1.0)])
 def test_beam_search_cached_equals_recompute_and_oracle(name, lp):
+    """(round 3: also at the Prismer-BASE geometry, 4 images x 3 beams, full depth)"""
     from prismer_amd.model.generate import beam_search
-    case, dec, _, dsd, _, _, e = _setup(name)
+    case, dec, _, dsd, _, _, e = _setup(name, B=4 if name == 'base_b8' else None)
     d = case.dims
     B = e.shape[0]
     prompt = torch.tensor([[0, 83 % d.vocab_size, 170 % d.vocab_size, 9]] * B).cuda()
@@ -86,7 +89,13 @@ def test_beam_search_cached_equals_recompute_and_oracle(name, lp):
     with torch.no_grad():
         fast = beam_search(dec, prompt, att, e, use_cache=True, **kw)
         slow = beam_search(dec, prompt, att, e, use_cache=False, **kw)
-    assert [f.tolist() for f in fast] == [s.tolist() for s in slow]
+    if name == 'base_b8':
+        # random-init BASE weights give near-uniform next-token distributions over 50 265 words: the bf16 noise between the cached
+        # and the full-prefix decode can swap a near-tied continuation, so identity is required for all but one item here (the
+        # token-for-token identity of the two decoders is pinned at the tiny geometry, where the distributions are peaked)
+        assert sum(f.tolist() == s_.tolist() for f, s_ in zip(fast, slow)) >= B - 1, ([f.tolist() for f in fast], [s_.tolist() for s_ in slow])
+    else:
+        assert [f.tolist() for f in fast] == [s.tolist() for s in slow]
     out = dec.generate(input_ids=prompt, encoder_hidden_states=e, attention_mask=att, num_beams=3, max_length=14, min_length=8,
                        length_penalty=lp)
     assert out.shape[0] == B and [o[:len(f)].tolist() for o, f in zip(out, fast)] == [f.tolist() for f in fast]

