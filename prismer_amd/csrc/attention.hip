@@ -15,6 +15,7 @@
 // Block = 4 waves; forward / dQ: 64 queries per block (16 per wave), K/V streamed in 64-key tiles through a
 // double-buffered LDS image; dK/dV: 64 keys per block, Q/dO streamed.
 #include <float.h>
+#include <type_traits>
 #include <stdlib.h>
 
 #include "common.h"
@@ -134,8 +135,27 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // LDS image (all three kernels): [stage 0: tile X, tile Y][stage 1: tile X, tile Y][per-row fp32 side data, 2 x 128]
 //   forward / dQ : X = K, Y = V, side = key state (64 floats per stage)
 //   dK/dV        : X = Q, Y = dO, side = lse (64) + delta (64) per stage
-template <int DH, bool PLAIN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 4 : 2))) void attn_fwd_kernel(ph_attn_fwd_args a) {
+// XCD-aware block placement (round 3).  Hardware puts block L of a 1-D grid on XCD L % 8, each XCD with its own L2.  With the plain
+// (x = tile of the sequence, y = head) grid the 5 query blocks of a ViT head landed on 5 different XCDs, i.e. every head's K / V was
+// pulled into five L2s.  The linear id is re-mapped so that an XCD walks whole heads: slot = L / 8, head = (slot / nx) * 8 + L % 8,
+// x = slot % nx (heads beyond the last multiple of 8 keep the plain order).
+struct BlockXY { int x, y; };
+__device__ __forceinline__ BlockXY block_xy(int nx, int ny) {
+  const int L = blockIdx.x;
+  const int full = (ny / 8) * 8 * nx;                  // blocks of the heads that fill whole groups of 8
+  if (L < full) {
+    const int xcd = L & 7, slot = L >> 3;
+    return BlockXY{slot % nx, (slot / nx) * 8 + xcd};
+  }
+  const int r = L - full;
+  return BlockXY{r % nx, (ny / 8) * 8 + r / nx};
+}
+
+// QT (round 3): 16-query sub-tiles per wave.  QT = 2 -> a wave owns 32 queries: every K / V fragment fetched from LDS feeds two
+// MFMAs instead of one (the kernels were LDS-bound: ~16 KB of fragment reads per wave and 64-key tile against 256 cycles of MFMA),
+// and a block covers 128 queries, so the K / V tiles of a head are staged by half as many blocks.
+template <int DH, bool PLAIN, int QT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? (QT == 1 ? 4 : 2) : 2))) void attn_fwd_kernel(ph_attn_fwd_args a) {
   using C = Cfg<DH>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16* smem = reinterpret_cast<bf16*>(smem_raw);
@@ -143,30 +163,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
-  const int q0 = blockIdx.x * 64 + wave * 16;
-  const int qi = q0 + c;
-  const bool wave_live = q0 < a.Sq;                 // a wave whose 16 queries are all padding only helps staging
+  const BlockXY bxy = block_xy((a.Sq + 64 * QT - 1) / (64 * QT), a.B * a.H);
+  const int b = bxy.y / a.H, h = bxy.y % a.H;
+  const int q0 = bxy.x * (64 * QT) + wave * (16 * QT);
+  const bool wave_live = q0 < a.Sq;                 // a wave whose queries are all padding only helps staging
   const bf16* Q = reinterpret_cast<const bf16*>(a.q) + b * a.q_bs + (int64_t)h * DH;
   const bf16* K = reinterpret_cast<const bf16*>(a.k) + b * a.k_bs + (int64_t)h * DH;
   const bf16* V = reinterpret_cast<const bf16*>(a.v) + b * a.v_bs + (int64_t)h * DH;
   const uint8_t* km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
 
-  bf16x8 qf[C::KS];
-  {
-    int qr = qi < a.Sq ? qi : a.Sq - 1;
+  int qi[QT];
+  bf16x8 qf[QT][C::KS];
+  f32x4 o[QT][C::DT];
+  float m[QT], lsum[QT];
+  uint32_t rowid[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    qi[t] = q0 + t * 16 + c;
+    const int qr = qi[t] < a.Sq ? qi[t] : a.Sq - 1;
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks)
-      qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (int64_t)qr * a.q_ts + ks * 32 + g * 8);
-  }
-  f32x4 o[C::DT];
+      qf[t][ks] = *reinterpret_cast<const bf16x8*>(Q + (int64_t)qr * a.q_ts + ks * 32 + g * 8);
 #pragma unroll
-  for (int d = 0; d < C::DT; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m = NEG_MASK, lsum = 0.f;
+    for (int d = 0; d < C::DT; ++d) o[t][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    m[t] = NEG_MASK; lsum[t] = 0.f;
+    rowid[t] = (uint32_t)((b * a.H + h) * a.Sq + qr);
+  }
   DropCtx dc;
-  const bool drop = a.drop_p > 0.f;
+  const bool drop = !PLAIN && a.drop_p > 0.f;
   if (drop) dc = make_drop(a.drop_seed, a.drop_stream, a.drop_p);
-  const uint32_t rowid = (uint32_t)((b * a.H + h) * a.Sq + (qi < a.Sq ? qi : a.Sq - 1));
 
   const int ntiles = (a.Sk + 63) / 64;
   u32x4 rk[C::NLD], rv[C::NLD];
@@ -176,92 +201,136 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
   tile_gload<DH>(V, a.v_ts, 0, a.Sk, rv);
   if (threadIdx.x < 64) kraw = key_raw(km, kraw_i, a.Sk);
 #pragma unroll
-  for (int ks = 0; ks < C::KS; ++ks) settle(qf[ks]);
+  for (int t = 0; t < QT; ++t)
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) settle(qf[t][ks]);
   tile_lstore<DH>(smem, rk);
   tile_lstore<DH>(smem + C::TILE, rv);
   if (threadIdx.x < 64) side[threadIdx.x] = key_state(kraw, kraw_i, a.Sk);
   __syncthreads();
   int cur = 0;
-  for (int t = 0; t < ntiles; ++t) {
-    const bool more = t + 1 < ntiles;
+  for (int tl = 0; tl < ntiles; ++tl) {
+    const bool more = tl + 1 < ntiles;
     if (more) {
-      tile_gload<DH>(K, a.k_ts, (t + 1) * 64, a.Sk, rk);
-      tile_gload<DH>(V, a.v_ts, (t + 1) * 64, a.Sk, rv);
-      kraw_i = (t + 1) * 64 + threadIdx.x;
+      tile_gload<DH>(K, a.k_ts, (tl + 1) * 64, a.Sk, rk);
+      tile_gload<DH>(V, a.v_ts, (tl + 1) * 64, a.Sk, rv);
+      kraw_i = (tl + 1) * 64 + threadIdx.x;
       if (threadIdx.x < 64) kraw = key_raw(km, kraw_i, a.Sk);
     }
     const bf16* kl = smem + cur * 2 * C::TILE;
     const bf16* vl = kl + C::TILE;
     const float* kst = side + cur * 128;
-    const int kbase = t * 64;
-    if (wave_live) {
-      f32x4 s[4];
-      float mx = -INFINITY;
-      const bool tail = kbase + 64 > a.Sk;            // (uniform) this tile crosses the end of the key sequence
+    const int kbase = tl * 64;
+    // TAIL = false: a PLAIN tile entirely inside the key sequence -- no bounds selects, no sub-tile guards (they cost more VALU
+    // issue slots than the softmax itself: 51 v_cndmask + 18 v_cmp per 16 MFMAs in the first PLAIN build)
+    auto tile_body = [&](auto tail_c) {
+      constexpr bool TAIL = decltype(tail_c)::value;
+      f32x4 s[QT][4];
+      float mx[QT];
+#pragma unroll
+      for (int t = 0; t < QT; ++t) mx[t] = -INFINITY;
+      // fragment prefetch (interior tiles): ALL K and V^T fragments of the tile are requested up front -- the 24 LDS round trips then
+      // overlap the QK^T MFMAs and the softmax arithmetic instead of each MFMA waiting for its own operand (by counter the waves sat
+      // in s_waitcnt 46 % of their cycles)
+      bf16x8 kpre[TAIL ? 1 : 4][C::KS], vpre[TAIL ? 1 : 2][C::DT];
+      if constexpr (!TAIL) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int ks = 0; ks < C::KS; ++ks) kpre[nt][ks] = frag_rows<DH>(kl, nt * 16, ks, lane);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int d = 0; d < C::DT; ++d) vpre[k2][d] = frag_tr<DH>(vl, k2 * 32, d * 16, lane);
+      }
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        if (kbase + nt * 16 < a.Sk) {                 // 16-key sub-tiles entirely beyond Sk cost nothing
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (!TAIL || kbase + nt * 16 < a.Sk) {        // 16-key sub-tiles entirely beyond Sk cost nothing
+          f32x4 acc[QT];
 #pragma unroll
-          for (int ks = 0; ks < C::KS; ++ks)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(kl, nt * 16, ks, lane), qf[ks], acc, 0, 0, 0);
+          for (int t = 0; t < QT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < C::KS; ++ks) {
+            bf16x8 kfr;
+            if constexpr (TAIL) kfr = frag_rows<DH>(kl, nt * 16, ks, lane); else kfr = kpre[nt][ks];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[t][ks], acc[t], 0, 0, 0);
+          }
           if constexpr (PLAIN) {                      // base-2 scores: s * scale * log2(e)
             const float c2 = a.scale * LOG2E;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              acc[r] *= c2;
-              if (tail) acc[r] = (kbase + nt * 16 + g * 4 + r < a.Sk) ? acc[r] : -INFINITY;
-              mx = fmaxf(mx, acc[r]);
-            }
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                acc[t][r] *= c2;
+                if (TAIL) acc[t][r] = (kbase + nt * 16 + g * 4 + r < a.Sk) ? acc[t][r] : -INFINITY;
+                mx[t] = fmaxf(mx[t], acc[t][r]);
+              }
           } else {
             const f32x4 st = *reinterpret_cast<const f32x4*>(kst + nt * 16 + g * 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              int ki = kbase + nt * 16 + g * 4 + r;
-              acc[r] = score_of(acc[r], a.scale, st[r], a.causal && ki > qi);
-              mx = fmaxf(mx, acc[r]);
-            }
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                int ki = kbase + nt * 16 + g * 4 + r;
+                acc[t][r] = score_of(acc[t][r], a.scale, st[r], a.causal && ki > qi[t]);
+                mx[t] = fmaxf(mx[t], acc[t][r]);
+              }
           }
-          s[nt] = acc;
+#pragma unroll
+          for (int t = 0; t < QT; ++t) s[t][nt] = acc[t];
         } else {
-          s[nt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+          for (int t = 0; t < QT; ++t) s[t][nt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         }
       }
-      mx = xor_max(mx);
-      float m_new = fmaxf(m, mx);
-      float alpha = PLAIN ? fast_exp2(m - m_new) : __expf(m - m_new);
-      float rs = 0.f;
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+      for (int t = 0; t < QT; ++t) {
+        const float mxt = xor_max(mx[t]);
+        const float m_new = fmaxf(m[t], mxt);
+        const float alpha = PLAIN ? fast_exp2(m[t] - m_new) : __expf(m[t] - m_new);
+        float rs = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float p = PLAIN ? fast_exp2(s[nt][r] - m_new) : __expf(s[nt][r] - m_new);
-          rs += p;
-          s[nt][r] = p;
-        }
-      rs = xor_sum(rs);
-      lsum = lsum * alpha + rs;
-      m = m_new;
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int d = 0; d < C::DT; ++d) o[d] *= alpha;
-      if (drop) {
+          for (int r = 0; r < 4; ++r) {
+            float p = PLAIN ? fast_exp2(s[t][nt][r] - m_new) : __expf(s[t][nt][r] - m_new);
+            rs += p;
+            s[t][nt][r] = p;
+          }
+        rs = xor_sum(rs);
+        lsum[t] = lsum[t] * alpha + rs;
+        m[t] = m_new;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          int k4 = (kbase + nt * 16 + g * 4) >> 2;
-          u32x4 rnd = philox4x32((uint32_t)k4, rowid, dc.stream, 0xa77eu, dc.k0, dc.k1);
+        for (int d = 0; d < C::DT; ++d) o[t][d] *= alpha;
+        if (drop) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[nt][r] = drop_apply(dc, rnd[r], s[nt][r]);
+          for (int nt = 0; nt < 4; ++nt) {
+            int k4 = (kbase + nt * 16 + g * 4) >> 2;
+            u32x4 rnd = philox4x32((uint32_t)k4, rowid[t], dc.stream, 0xa77eu, dc.k0, dc.k1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[t][nt][r] = drop_apply(dc, rnd[r], s[t][nt][r]);
+          }
         }
       }
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
-        if (kbase + k2 * 32 < a.Sk) {
-          bf16x8 pf = pack2(s[2 * k2], s[2 * k2 + 1]);
+        if (!TAIL || kbase + k2 * 32 < a.Sk) {
+          bf16x8 pf[QT];
 #pragma unroll
-          for (int d = 0; d < C::DT; ++d)
-            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(vl, k2 * 32, d * 16, lane), pf, o[d], 0, 0, 0);
+          for (int t = 0; t < QT; ++t) pf[t] = pack2(s[t][2 * k2], s[t][2 * k2 + 1]);
+#pragma unroll
+          for (int d = 0; d < C::DT; ++d) {
+            bf16x8 vfr;
+            if constexpr (TAIL) vfr = frag_tr<DH>(vl, k2 * 32, d * 16, lane); else vfr = vpre[k2][d];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, pf[t], o[t][d], 0, 0, 0);
+          }
         }
       }
+    };
+    if (wave_live) {
+      if (!PLAIN || kbase + 64 > a.Sk) tile_body(std::true_type{}); else tile_body(std::false_type{});
     }
     if (more) {
       tile_lstore<DH>(smem + (cur ^ 1) * 2 * C::TILE, rk);
@@ -271,23 +340,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
     __syncthreads();
     cur ^= 1;
   }
-  if (qi < a.Sq) {
-    float inv = 1.0f / lsum;
-    bf16* O = reinterpret_cast<bf16*>(a.o) + b * a.o_bs + (int64_t)qi * a.o_ts + (int64_t)h * DH;
 #pragma unroll
-    for (int d = 0; d < C::DT; ++d) {
-      bf16x4 t = {f2bf(o[d][0] * inv), f2bf(o[d][1] * inv), f2bf(o[d][2] * inv), f2bf(o[d][3] * inv)};
-      *reinterpret_cast<bf16x4*>(O + d * 16 + g * 4) = t;
+  for (int t = 0; t < QT; ++t) {
+    if (qi[t] < a.Sq) {
+      float inv = 1.0f / lsum[t];
+      bf16* O = reinterpret_cast<bf16*>(a.o) + b * a.o_bs + (int64_t)qi[t] * a.o_ts + (int64_t)h * DH;
+#pragma unroll
+      for (int d = 0; d < C::DT; ++d) {
+        bf16x4 tt = {f2bf(o[t][d][0] * inv), f2bf(o[t][d][1] * inv), f2bf(o[t][d][2] * inv), f2bf(o[t][d][3] * inv)};
+        *reinterpret_cast<bf16x4*>(O + d * 16 + g * 4) = tt;
+      }
+      if (g == 0 && a.lse) a.lse[(int64_t)(b * a.H + h) * a.Sq + qi[t]] = (PLAIN ? m[t] * LN2 : m[t]) + __logf(lsum[t]);    // natural-log lse either way
     }
-    if (g == 0 && a.lse) a.lse[(int64_t)(b * a.H + h) * a.Sq + qi] = (PLAIN ? m * LN2 : m) + __logf(lsum);    // natural-log lse either way
   }
 }
 
 // =====================================================================================================
 // backward: dQ  (same streaming structure as forward)
 // =====================================================================================================
-template <int DH, bool PLAIN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 4 : 2))) void attn_bwd_dq_kernel(ph_attn_bwd_args a) {
+template <int DH, bool PLAIN, int QT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? (QT == 1 ? 3 : 2) : 2))) void attn_bwd_dq_kernel(ph_attn_bwd_args a) {
   using C = Cfg<DH>;
   const ph_attn_fwd_args& f = a.f;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -295,10 +367,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
   float* side = reinterpret_cast<float*>(smem + 4 * C::TILE);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int b = blockIdx.y / f.H, h = blockIdx.y % f.H;
-  const int q0 = blockIdx.x * 64 + wave * 16;
-  const int qi = q0 + c;
-  const int qr = qi < f.Sq ? qi : f.Sq - 1;
+  const BlockXY bxy = block_xy((f.Sq + 64 * QT - 1) / (64 * QT), f.B * f.H);
+  const int b = bxy.y / f.H, h = bxy.y % f.H;
+  const int q0 = bxy.x * (64 * QT) + wave * (16 * QT);
   const bool wave_live = q0 < f.Sq;
   const bf16* Q = reinterpret_cast<const bf16*>(f.q) + b * f.q_bs + (int64_t)h * DH;
   const bf16* K = reinterpret_cast<const bf16*>(f.k) + b * f.k_bs + (int64_t)h * DH;
@@ -306,22 +377,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
   const bf16* dO = reinterpret_cast<const bf16*>(a.d_o) + b * a.do_bs + (int64_t)h * DH;
   const uint8_t* km = f.key_mask ? f.key_mask + (int64_t)b * f.Sk : nullptr;
 
-  bf16x8 qf[C::KS], dof[C::KS];
+  int qi[QT];
+  int64_t ridx[QT];
+  bf16x8 qf[QT][C::KS], dof[QT][C::KS];
+  float lse[QT], delta[QT], dsum[QT];
+  f32x4 dq[QT][C::DT];
 #pragma unroll
-  for (int ks = 0; ks < C::KS; ++ks) {
-    qf[ks] = *reinterpret_cast<const bf16x8*>(Q + (int64_t)qr * f.q_ts + ks * 32 + g * 8);
-    dof[ks] = *reinterpret_cast<const bf16x8*>(dO + (int64_t)qr * a.do_ts + ks * 32 + g * 8);
+  for (int t = 0; t < QT; ++t) {
+    qi[t] = q0 + t * 16 + c;
+    const int qr = qi[t] < f.Sq ? qi[t] : f.Sq - 1;
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      qf[t][ks] = *reinterpret_cast<const bf16x8*>(Q + (int64_t)qr * f.q_ts + ks * 32 + g * 8);
+      dof[t][ks] = *reinterpret_cast<const bf16x8*>(dO + (int64_t)qr * a.do_ts + ks * 32 + g * 8);
+    }
+    ridx[t] = (int64_t)(b * f.H + h) * f.Sq + qr;
+    lse[t] = f.lse[ridx[t]];
+    delta[t] = 0.f; dsum[t] = 0.f;
+#pragma unroll
+    for (int d = 0; d < C::DT; ++d) dq[t][d] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const int64_t ridx = (int64_t)(b * f.H + h) * f.Sq + qr;
-  float lse = f.lse[ridx];
   DropCtx dc;
-  const bool drop = f.drop_p > 0.f;
+  const bool drop = !PLAIN && f.drop_p > 0.f;
   if (drop) dc = make_drop(f.drop_seed, f.drop_stream, f.drop_p);
-  const uint32_t rowid = (uint32_t)ridx;
-
-  f32x4 dq[C::DT];
-#pragma unroll
-  for (int d = 0; d < C::DT; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // Two sweeps over the K/V tiles, run as ONE loop of 2*ntiles steps so that the prefetch never drains in between.
   // Sweep 0 computes delta_i = sum_j P_ij * dP_ij in fp32 from the SAME recomputed P and dP sweep 1 uses (softmax backward
@@ -337,20 +415,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
   tile_gload<DH>(V, f.v_ts, 0, f.Sk, rv);
   if (threadIdx.x < 64) kraw = key_raw(km, kraw_i, f.Sk);
 #pragma unroll
-  for (int ks = 0; ks < C::KS; ++ks) { settle(qf[ks]); settle(dof[ks]); }
-  settle(lse);
+  for (int t = 0; t < QT; ++t) {
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) { settle(qf[t][ks]); settle(dof[t][ks]); }
+    settle(lse[t]);
+  }
   tile_lstore<DH>(smem, rk);
   tile_lstore<DH>(smem + C::TILE, rv);
   if (threadIdx.x < 64) side[threadIdx.x] = key_state(kraw, kraw_i, f.Sk);
   __syncthreads();
   int cur = 0;
-  float delta = 0.f, dsum = 0.f;
   for (int u = 0; u < nsteps; ++u) {
     const bool sweep1 = u >= ntiles;
-    const int t = sweep1 ? u - ntiles : u;
+    const int tl = sweep1 ? u - ntiles : u;
     const bool more = u + 1 < nsteps;
     if (more) {
-      const int tn = (t + 1 == ntiles) ? 0 : t + 1;
+      const int tn = (tl + 1 == ntiles) ? 0 : tl + 1;
       tile_gload<DH>(K, f.k_ts, tn * 64, f.Sk, rk);
       tile_gload<DH>(V, f.v_ts, tn * 64, f.Sk, rv);
       kraw_i = tn * 64 + threadIdx.x;
@@ -359,60 +439,86 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
     const bf16* kl = smem + cur * 2 * C::TILE;
     const bf16* vl = kl + C::TILE;
     const float* kst = side + cur * 128;
-    const int kbase = t * 64;
-    if (wave_live) {
-      f32x4 ds[4];
+    const int kbase = tl * 64;
+    auto tile_body = [&](auto tail_c) {                  // TAIL = false: PLAIN tile inside the key sequence (see attn_fwd_kernel)
+      constexpr bool TAIL = decltype(tail_c)::value;
+      f32x4 ds[QT][4];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        if (kbase + nt * 16 < f.Sk) {
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        if (!TAIL || kbase + nt * 16 < f.Sk) {
+          f32x4 acc[QT], dp[QT];
+#pragma unroll
+          for (int t = 0; t < QT; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
           for (int ks = 0; ks < C::KS; ++ks) {
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(kl, nt * 16, ks, lane), qf[ks], acc, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(vl, nt * 16, ks, lane), dof[ks], dp, 0, 0, 0);
+            const bf16x8 kfr = frag_rows<DH>(kl, nt * 16, ks, lane);
+            const bf16x8 vfr = frag_rows<DH>(vl, nt * 16, ks, lane);
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+              acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[t][ks], acc[t], 0, 0, 0);
+              dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, dof[t][ks], dp[t], 0, 0, 0);
+            }
           }
           if constexpr (PLAIN) {
-            const float c2 = f.scale * LOG2E, l2 = lse * LOG2E;
-            const bool tail = kbase + 64 > f.Sk;
+            const float c2 = f.scale * LOG2E;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float p = fast_exp2(fmaf(acc[r], c2, -l2));
-              if (tail) p = (kbase + nt * 16 + g * 4 + r < f.Sk) ? p : 0.f;
-              dsum += p * dp[r];
-              ds[nt][r] = p * (dp[r] - delta);
+            for (int t = 0; t < QT; ++t) {
+              const float l2 = lse[t] * LOG2E;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float p = fast_exp2(fmaf(acc[t][r], c2, -l2));
+                if (TAIL) p = (kbase + nt * 16 + g * 4 + r < f.Sk) ? p : 0.f;
+                dsum[t] += p * dp[t][r];
+                ds[t][nt][r] = p * (dp[t][r] - delta[t]);
+              }
             }
           } else {
             const f32x4 st = *reinterpret_cast<const f32x4*>(kst + nt * 16 + g * 4);
-            u32x4 rnd;
-            if (drop) rnd = philox4x32((uint32_t)((kbase + nt * 16 + g * 4) >> 2), rowid, dc.stream, 0xa77eu, dc.k0, dc.k1);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              int ki = kbase + nt * 16 + g * 4 + r;
-              float p = __expf(score_of(acc[r], f.scale, st[r], f.causal && ki > qi) - lse);
-              float dpe = drop ? drop_apply(dc, rnd[r], dp[r]) : dp[r];
-              dsum += p * dpe;
-              ds[nt][r] = p * (dpe - delta);
+            for (int t = 0; t < QT; ++t) {
+              u32x4 rnd;
+              if (drop) rnd = philox4x32((uint32_t)((kbase + nt * 16 + g * 4) >> 2), (uint32_t)ridx[t], dc.stream, 0xa77eu, dc.k0, dc.k1);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                int ki = kbase + nt * 16 + g * 4 + r;
+                float p = __expf(score_of(acc[t][r], f.scale, st[r], f.causal && ki > qi[t]) - lse[t]);
+                float dpe = drop ? drop_apply(dc, rnd[r], dp[t][r]) : dp[t][r];
+                dsum[t] += p * dpe;
+                ds[t][nt][r] = p * (dpe - delta[t]);
+              }
             }
           }
         } else {
-          ds[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < QT; ++t) ds[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
       if (sweep1) {
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
-          if (kbase + k2 * 32 < f.Sk) {
-            bf16x8 dsf = pack2(ds[2 * k2], ds[2 * k2 + 1]);
+          if (!TAIL || kbase + k2 * 32 < f.Sk) {
+            bf16x8 dsf[QT];
 #pragma unroll
-            for (int d = 0; d < C::DT; ++d)
-              dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(kl, k2 * 32, d * 16, lane), dsf, dq[d], 0, 0, 0);
+            for (int t = 0; t < QT; ++t) dsf[t] = pack2(ds[t][2 * k2], ds[t][2 * k2 + 1]);
+#pragma unroll
+            for (int d = 0; d < C::DT; ++d) {
+              const bf16x8 kfr = frag_tr<DH>(kl, k2 * 32, d * 16, lane);
+#pragma unroll
+              for (int t = 0; t < QT; ++t) dq[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, dsf[t], dq[t][d], 0, 0, 0);
+            }
           }
         }
       }
       if (u == ntiles - 1) {
-        delta = xor_sum(dsum);
-        if (g == 0 && qi < f.Sq) a.delta[ridx] = delta;    // consumed by the dK/dV kernel (launched after this one)
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          delta[t] = xor_sum(dsum[t]);
+          if (g == 0 && qi[t] < f.Sq) a.delta[ridx[t]] = delta[t];    // consumed by the dK/dV kernel (launched after this one)
+        }
       }
+    };
+    if (wave_live) {
+      if (!PLAIN || kbase + 64 > f.Sk) tile_body(std::true_type{}); else tile_body(std::false_type{});
     }
     if (more) {
       tile_lstore<DH>(smem + (cur ^ 1) * 2 * C::TILE, rk);
@@ -422,21 +528,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
     __syncthreads();
     cur ^= 1;
   }
-  if (qi < f.Sq) {
-    bf16* dQ = reinterpret_cast<bf16*>(a.dq) + b * a.dq_bs + (int64_t)qi * a.dq_ts + (int64_t)h * DH;
 #pragma unroll
-    for (int d = 0; d < C::DT; ++d) {
-      bf16x4 t = {f2bf(dq[d][0] * f.scale), f2bf(dq[d][1] * f.scale), f2bf(dq[d][2] * f.scale), f2bf(dq[d][3] * f.scale)};
-      *reinterpret_cast<bf16x4*>(dQ + d * 16 + g * 4) = t;
+  for (int t = 0; t < QT; ++t) {
+    if (qi[t] < f.Sq) {
+      bf16* dQ = reinterpret_cast<bf16*>(a.dq) + b * a.dq_bs + (int64_t)qi[t] * a.dq_ts + (int64_t)h * DH;
+#pragma unroll
+      for (int d = 0; d < C::DT; ++d) {
+        bf16x4 tt = {f2bf(dq[t][d][0] * f.scale), f2bf(dq[t][d][1] * f.scale), f2bf(dq[t][d][2] * f.scale), f2bf(dq[t][d][3] * f.scale)};
+        *reinterpret_cast<bf16x4*>(dQ + d * 16 + g * 4) = tt;
+      }
     }
   }
 }
 
 // =====================================================================================================
-// backward: dK, dV  (one key per lane; Q / dO streamed in 64-query tiles)
+// backward: dK, dV  (one key per lane and sub-tile; Q / dO streamed in 64-query tiles)
 // =====================================================================================================
-template <int DH, bool PLAIN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 3 : 2))) void attn_bwd_dkv_kernel(ph_attn_bwd_args a) {
+template <int DH, bool PLAIN, int QT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? (QT == 1 ? 3 : 2) : 2))) void attn_bwd_dkv_kernel(ph_attn_bwd_args a) {
   using C = Cfg<DH>;
   const ph_attn_fwd_args& f = a.f;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -444,10 +553,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
   float* side = reinterpret_cast<float*>(smem + 4 * C::TILE);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int b = blockIdx.y / f.H, h = blockIdx.y % f.H;
-  const int k0 = blockIdx.x * 64 + wave * 16;
-  const int ki = k0 + c;
-  const int kr = ki < f.Sk ? ki : f.Sk - 1;
+  const BlockXY bxy = block_xy((f.Sk + 64 * QT - 1) / (64 * QT), f.B * f.H);
+  const int b = bxy.y / f.H, h = bxy.y % f.H;
+  const int k0 = bxy.x * (64 * QT) + wave * (16 * QT);
   const bool wave_live = k0 < f.Sk;
   const bf16* Q = reinterpret_cast<const bf16*>(f.q) + b * f.q_bs + (int64_t)h * DH;
   const bf16* K = reinterpret_cast<const bf16*>(f.k) + b * f.k_bs + (int64_t)h * DH;
@@ -455,14 +563,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
   const bf16* dO = reinterpret_cast<const bf16*>(a.d_o) + b * a.do_bs + (int64_t)h * DH;
   const uint8_t* km = f.key_mask ? f.key_mask + (int64_t)b * f.Sk : nullptr;
 
-  bf16x8 kf[C::KS], vf[C::KS];
+  int ki[QT];
+  bf16x8 kf[QT][C::KS], vf[QT][C::KS];
+  float kstate[QT];
+  f32x4 dk[QT][C::DT], dv[QT][C::DT];
 #pragma unroll
-  for (int ks = 0; ks < C::KS; ++ks) {
-    kf[ks] = *reinterpret_cast<const bf16x8*>(K + (int64_t)kr * f.k_ts + ks * 32 + g * 8);
-    vf[ks] = *reinterpret_cast<const bf16x8*>(V + (int64_t)kr * f.v_ts + ks * 32 + g * 8);
+  for (int t = 0; t < QT; ++t) {
+    ki[t] = k0 + t * 16 + c;
+    const int kr = ki[t] < f.Sk ? ki[t] : f.Sk - 1;
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      kf[t][ks] = *reinterpret_cast<const bf16x8*>(K + (int64_t)kr * f.k_ts + ks * 32 + g * 8);
+      vf[t][ks] = *reinterpret_cast<const bf16x8*>(V + (int64_t)kr * f.v_ts + ks * 32 + g * 8);
+    }
+    kstate[t] = key_raw(km, kr, f.Sk) ? 0.f : 1.f;   // this lane's key: excluded by key_mask?
+#pragma unroll
+    for (int d = 0; d < C::DT; ++d) { dk[t][d] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[t][d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   }
   DropCtx dc;
-  const bool drop = f.drop_p > 0.f;
+  const bool drop = !PLAIN && f.drop_p > 0.f;
   if (drop) dc = make_drop(f.drop_seed, f.drop_stream, f.drop_p);
   const float* lse_base = f.lse + (int64_t)(b * f.H + h) * f.Sq;
   const float* delta_base = a.delta + (int64_t)(b * f.H + h) * f.Sq;
@@ -470,101 +589,120 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
   const float* stat_base = threadIdx.x < 64 ? lse_base : delta_base;
   const int stat_row = threadIdx.x & 63;
 
-  f32x4 dk[C::DT], dv[C::DT];
-#pragma unroll
-  for (int d = 0; d < C::DT; ++d) { dk[d] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-
   const int ntiles = (f.Sq + 63) / 64;
   u32x4 rq[C::NLD], rd[C::NLD];
   float sreg = 0.f;
   tile_gload<DH>(Q, f.q_ts, 0, f.Sq, rq);
   tile_gload<DH>(dO, a.do_ts, 0, f.Sq, rd);
   if (threadIdx.x < 128) sreg = stat_base[min(stat_row, f.Sq - 1)];
-  float kstate = key_raw(km, kr, f.Sk) ? 0.f : 1.f;   // this lane's key: excluded by key_mask?
+  bool key_masked[QT];
 #pragma unroll
-  for (int ks = 0; ks < C::KS; ++ks) { settle(kf[ks]); settle(vf[ks]); }
-  settle(kstate);
-  const bool key_masked = kstate != 0.f;
+  for (int t = 0; t < QT; ++t) {
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) { settle(kf[t][ks]); settle(vf[t][ks]); }
+    settle(kstate[t]);
+    key_masked[t] = kstate[t] != 0.f;
+  }
   tile_lstore<DH>(smem, rq);
   tile_lstore<DH>(smem + C::TILE, rd);
   if (threadIdx.x < 128) side[threadIdx.x] = sreg;
   __syncthreads();
   int cur = 0;
-  for (int t = 0; t < ntiles; ++t) {
-    const bool more = t + 1 < ntiles;
+  for (int tl = 0; tl < ntiles; ++tl) {
+    const bool more = tl + 1 < ntiles;
     if (more) {
-      tile_gload<DH>(Q, f.q_ts, (t + 1) * 64, f.Sq, rq);
-      tile_gload<DH>(dO, a.do_ts, (t + 1) * 64, f.Sq, rd);
-      if (threadIdx.x < 128) sreg = stat_base[min((t + 1) * 64 + stat_row, f.Sq - 1)];
+      tile_gload<DH>(Q, f.q_ts, (tl + 1) * 64, f.Sq, rq);
+      tile_gload<DH>(dO, a.do_ts, (tl + 1) * 64, f.Sq, rd);
+      if (threadIdx.x < 128) sreg = stat_base[min((tl + 1) * 64 + stat_row, f.Sq - 1)];
     }
     const bf16* ql = smem + cur * 2 * C::TILE;
     const bf16* dl = ql + C::TILE;
     const float* stl = side + cur * 128;
-    const int qbase = t * 64;
-    if (wave_live) {
-      f32x4 pd[4], ds[4];
+    const int qbase = tl * 64;
+    auto tile_body = [&](auto tail_c) {                  // TAIL = false: PLAIN tile pair without padding rows / keys
+      constexpr bool TAIL = decltype(tail_c)::value;
+      f32x4 pd[QT][4], ds[QT][4];
 #pragma unroll
       for (int qt = 0; qt < 4; ++qt) {
-        if (qbase + qt * 16 < f.Sq) {
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        if (!TAIL || qbase + qt * 16 < f.Sq) {
+          f32x4 acc[QT], dp[QT];
+#pragma unroll
+          for (int t = 0; t < QT; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
           for (int ks = 0; ks < C::KS; ++ks) {
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(ql, qt * 16, ks, lane), kf[ks], acc, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(dl, qt * 16, ks, lane), vf[ks], dp, 0, 0, 0);
+            const bf16x8 qfr = frag_rows<DH>(ql, qt * 16, ks, lane);
+            const bf16x8 dfr = frag_rows<DH>(dl, qt * 16, ks, lane);
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+              acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[t][ks], acc[t], 0, 0, 0);
+              dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr, vf[t][ks], dp[t], 0, 0, 0);
+            }
           }
           const f32x4 l4 = *reinterpret_cast<const f32x4*>(stl + qt * 16 + g * 4);
           const f32x4 d4 = *reinterpret_cast<const f32x4*>(stl + 64 + qt * 16 + g * 4);
           if constexpr (PLAIN) {
             const float c2 = f.scale * LOG2E;
-            const bool tail = (qbase + 64 > f.Sq) || (k0 + 16 > f.Sk);     // (wave-uniform) this tile pair touches padding rows / keys
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float p = fast_exp2(fmaf(acc[r], c2, -l4[r] * LOG2E));
-              if (tail) p = (qbase + qt * 16 + g * 4 + r < f.Sq && ki < f.Sk) ? p : 0.f;
-              pd[qt][r] = p;
-              ds[qt][r] = p * (dp[r] - d4[r]);
-            }
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float p = fast_exp2(fmaf(acc[t][r], c2, -l4[r] * LOG2E));
+                if (TAIL) p = (qbase + qt * 16 + g * 4 + r < f.Sq && ki[t] < f.Sk) ? p : 0.f;
+                pd[t][qt][r] = p;
+                ds[t][qt][r] = p * (dp[t][r] - d4[r]);
+              }
           } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            int qi = qbase + qt * 16 + g * 4 + r;         // C layout here: row = query, col (lane & 15) = key
-            float p = 0.f, dpe = dp[r];
-            if (qi < f.Sq && ki < f.Sk) {
-              float sc = (key_masked || (f.causal && ki > qi)) ? NEG_MASK : acc[r] * f.scale;
-              p = __expf(sc - l4[r]);
-              float pdrop = p;
-              if (drop) {
-                uint32_t rowid = (uint32_t)((b * f.H + h) * f.Sq + qi);
-                u32x4 rnd = philox4x32((uint32_t)(ki >> 2), rowid, dc.stream, 0xa77eu, dc.k0, dc.k1);
-                uint32_t rr = rnd[ki & 3];
-                pdrop = drop_apply(dc, rr, p);
-                dpe = drop_apply(dc, rr, dp[r]);
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                int qi = qbase + qt * 16 + g * 4 + r;         // C layout here: row = query, col (lane & 15) = key
+                float p = 0.f, dpe = dp[t][r];
+                if (qi < f.Sq && ki[t] < f.Sk) {
+                  float sc = (key_masked[t] || (f.causal && ki[t] > qi)) ? NEG_MASK : acc[t][r] * f.scale;
+                  p = __expf(sc - l4[r]);
+                  float pdrop = p;
+                  if (drop) {
+                    uint32_t rowid = (uint32_t)((b * f.H + h) * f.Sq + qi);
+                    u32x4 rnd = philox4x32((uint32_t)(ki[t] >> 2), rowid, dc.stream, 0xa77eu, dc.k0, dc.k1);
+                    uint32_t rr = rnd[ki[t] & 3];
+                    pdrop = drop_apply(dc, rr, p);
+                    dpe = drop_apply(dc, rr, dp[t][r]);
+                  }
+                  pd[t][qt][r] = pdrop;
+                  ds[t][qt][r] = p * (dpe - d4[r]);
+                } else {
+                  pd[t][qt][r] = 0.f;
+                  ds[t][qt][r] = 0.f;
+                }
               }
-              pd[qt][r] = pdrop;
-              ds[qt][r] = p * (dpe - d4[r]);
-            } else {
-              pd[qt][r] = 0.f;
-              ds[qt][r] = 0.f;
-            }
-          }
           }
         } else {
-          pd[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-          ds[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < QT; ++t) { pd[t][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; ds[t][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         }
       }
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
-        if (qbase + k2 * 32 < f.Sq) {
-          bf16x8 pf = pack2(pd[2 * k2], pd[2 * k2 + 1]);
-          bf16x8 dsf = pack2(ds[2 * k2], ds[2 * k2 + 1]);
+        if (!TAIL || qbase + k2 * 32 < f.Sq) {
+          bf16x8 pf[QT], dsf[QT];
+#pragma unroll
+          for (int t = 0; t < QT; ++t) { pf[t] = pack2(pd[t][2 * k2], pd[t][2 * k2 + 1]); dsf[t] = pack2(ds[t][2 * k2], ds[t][2 * k2 + 1]); }
 #pragma unroll
           for (int d = 0; d < C::DT; ++d) {
-            dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(dl, k2 * 32, d * 16, lane), pf, dv[d], 0, 0, 0);
-            dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr<DH>(ql, k2 * 32, d * 16, lane), dsf, dk[d], 0, 0, 0);
+            const bf16x8 dfr = frag_tr<DH>(dl, k2 * 32, d * 16, lane);
+            const bf16x8 qfr = frag_tr<DH>(ql, k2 * 32, d * 16, lane);
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+              dv[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr, pf[t], dv[t][d], 0, 0, 0);
+              dk[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, dsf[t], dk[t][d], 0, 0, 0);
+            }
           }
         }
       }
+    };
+    if (wave_live) {
+      if (!PLAIN || (qbase + 64 > f.Sq) || (k0 + 16 * QT > f.Sk)) tile_body(std::true_type{}); else tile_body(std::false_type{});
     }
     if (more) {
       tile_lstore<DH>(smem + (cur ^ 1) * 2 * C::TILE, rq);
@@ -574,15 +712,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
     __syncthreads();
     cur ^= 1;
   }
-  if (ki < f.Sk) {
-    bf16* dK = reinterpret_cast<bf16*>(a.dk) + b * a.dk_bs + (int64_t)ki * a.dk_ts + (int64_t)h * DH;
-    bf16* dV = reinterpret_cast<bf16*>(a.dv) + b * a.dv_bs + (int64_t)ki * a.dv_ts + (int64_t)h * DH;
 #pragma unroll
-    for (int d = 0; d < C::DT; ++d) {
-      bf16x4 tk = {f2bf(dk[d][0] * f.scale), f2bf(dk[d][1] * f.scale), f2bf(dk[d][2] * f.scale), f2bf(dk[d][3] * f.scale)};
-      bf16x4 tv = {f2bf(dv[d][0]), f2bf(dv[d][1]), f2bf(dv[d][2]), f2bf(dv[d][3])};
-      *reinterpret_cast<bf16x4*>(dK + d * 16 + g * 4) = tk;
-      *reinterpret_cast<bf16x4*>(dV + d * 16 + g * 4) = tv;
+  for (int t = 0; t < QT; ++t) {
+    if (ki[t] < f.Sk) {
+      bf16* dK = reinterpret_cast<bf16*>(a.dk) + b * a.dk_bs + (int64_t)ki[t] * a.dk_ts + (int64_t)h * DH;
+      bf16* dV = reinterpret_cast<bf16*>(a.dv) + b * a.dv_bs + (int64_t)ki[t] * a.dv_ts + (int64_t)h * DH;
+#pragma unroll
+      for (int d = 0; d < C::DT; ++d) {
+        bf16x4 tk = {f2bf(dk[t][d][0] * f.scale), f2bf(dk[t][d][1] * f.scale), f2bf(dk[t][d][2] * f.scale), f2bf(dk[t][d][3] * f.scale)};
+        bf16x4 tv = {f2bf(dv[t][d][0]), f2bf(dv[t][d][1]), f2bf(dv[t][d][2]), f2bf(dv[t][d][3])};
+        *reinterpret_cast<bf16x4*>(dK + d * 16 + g * 4) = tk;
+        *reinterpret_cast<bf16x4*>(dV + d * 16 + g * 4) = tv;
+      }
     }
   }
 }
@@ -591,6 +732,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
 bool attn_plain_ok(const ph_attn_fwd_args* f) {
   static const bool on = [] { const char* e = getenv("PH_ATTN_PLAIN"); return !e || atoi(e) != 0; }();
   return on && !f->causal && !f->key_mask && !(f->drop_p > 0.f);
+}
+
+// 32 queries (keys, in the dK/dV kernel) per wave for long enough sequences
+int attn_qt2_ok() {          // PH_ATTN_QT2: 0 = never, 1 = by sequence length (default), 2 = wherever eligible
+  static const int mode = [] { const char* e = getenv("PH_ATTN_QT2"); return e ? atoi(e) : 1; }();
+  return mode;
 }
 
 template <typename KernelT>
@@ -615,19 +762,23 @@ extern "C" int ph_attention_fwd(const ph_attn_fwd_args* a, hipStream_t stream) {
   int rc = check_fwd(a, "ph_attention_fwd");
   if (rc) return rc;
   ProfScope prof__(PH_FAM_ATTN_FWD, 4.0 * a->B * (double)a->H * a->Sq * (double)a->Sk * a->dh, 0.0, stream);
-  dim3 grid(ceil_div(a->Sq, 64), a->B * a->H);
   const bool plain = attn_plain_ok(a);
+  // 32 queries per wave (QT = 2): measured slower than 16 in the forward at every shape once the blocks of a head share an XCD
+  // (ViT 26.8 vs 32.6 us, LARGE 58 vs 66 us); PH_ATTN_QT2=2 forces it for experiments
+  const bool qt2 = plain && attn_qt2_ok() == 2 && a->dh <= 64 && a->Sq >= 128;
+  dim3 grid(ceil_div(a->Sq, qt2 ? 128 : 64) * a->B * a->H);                          // 1-D: block_xy() re-maps it XCD-aware
+#define PH_FWD_LAUNCH(DHV, PL, QTV)                                                               \
+  {                                                                                               \
+    int smem = set_smem(attn_fwd_kernel<DHV, PL, QTV>, 4 * Cfg<DHV>::TILE * 2 + 1024);            \
+    hipLaunchKernelGGL((attn_fwd_kernel<DHV, PL, QTV>), grid, dim3(256), smem, stream, *a);       \
+  }
 #define PH_FWD(DHV)                                                                               \
   case DHV: {                                                                                     \
-    if (plain) {                                                                                  \
-      int smem = set_smem(attn_fwd_kernel<DHV, true>, 4 * Cfg<DHV>::TILE * 2 + 1024);             \
-      hipLaunchKernelGGL((attn_fwd_kernel<DHV, true>), grid, dim3(256), smem, stream, *a);        \
-    } else {                                                                                      \
-      int smem = set_smem(attn_fwd_kernel<DHV, false>, 4 * Cfg<DHV>::TILE * 2 + 1024);            \
-      hipLaunchKernelGGL((attn_fwd_kernel<DHV, false>), grid, dim3(256), smem, stream, *a);       \
-    }                                                                                             \
+    if constexpr (DHV <= 64) { if (qt2) { PH_FWD_LAUNCH(DHV, true, 2) break; } }                  \
+    if (plain) PH_FWD_LAUNCH(DHV, true, 1) else PH_FWD_LAUNCH(DHV, false, 1)                      \
   } break;
   switch (a->dh) { PH_FWD(32) PH_FWD(64) PH_FWD(96) PH_FWD(128) }
+#undef PH_FWD_LAUNCH
 #undef PH_FWD
   PH_LAUNCH_CHECK("attn_fwd_kernel");
   return PH_OK;
@@ -641,23 +792,37 @@ extern "C" int ph_attention_bwd(const ph_attn_bwd_args* a, hipStream_t stream) {
   PH_CHECK_ARG(a->d_o && a->dq && a->dk && a->dv && a->delta && a->f.lse, "ph_attention_bwd: null pointer");
   PH_CHECK_ARG(((a->do_ts | a->dq_ts | a->dk_ts | a->dv_ts | a->do_bs | a->dq_bs | a->dk_bs | a->dv_bs) % 8) == 0, "ph_attention_bwd: strides must be multiples of 8");
   const ph_attn_fwd_args& f = a->f;
-  dim3 gq(ceil_div(f.Sq, 64), f.B * f.H), gk(ceil_div(f.Sk, 64), f.B * f.H);
   const bool plain = attn_plain_ok(&f);
+  // backward: 32 queries / keys per wave pay from ~512 tokens on (LARGE, S = 1220: 184 vs 189 us; ViT S = 260: 91 vs 84 us)
+  const int qt_mode = attn_qt2_ok();
+  const bool q2 = plain && qt_mode && f.dh <= 64 && f.Sq >= (qt_mode == 2 ? 128 : 512);
+  const bool k2 = plain && qt_mode && f.dh <= 64 && f.Sk >= (qt_mode == 2 ? 128 : 512);
+  dim3 gq(ceil_div(f.Sq, q2 ? 128 : 64) * f.B * f.H), gk(ceil_div(f.Sk, k2 ? 128 : 64) * f.B * f.H);      // 1-D, see block_xy()
+#define PH_DQ_LAUNCH(DHV, PL, QTV)                                                                        \
+  {                                                                                                       \
+    int smem = set_smem(attn_bwd_dq_kernel<DHV, PL, QTV>, 4 * Cfg<DHV>::TILE * 2 + 1024);                 \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<DHV, PL, QTV>), gq, dim3(256), smem, stream, *a);              \
+  }
+#define PH_DKV_LAUNCH(DHV, PL, QTV)                                                                       \
+  {                                                                                                       \
+    int smem = set_smem(attn_bwd_dkv_kernel<DHV, PL, QTV>, 4 * Cfg<DHV>::TILE * 2 + 1024);                \
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DHV, PL, QTV>), gk, dim3(256), smem, stream, *a);             \
+  }
 #define PH_BWD(DHV)                                                                                       \
   case DHV: {                                                                                             \
-    if (plain) {                                                                                          \
-      int smem = set_smem(attn_bwd_dq_kernel<DHV, true>, 4 * Cfg<DHV>::TILE * 2 + 1024);                  \
-      set_smem(attn_bwd_dkv_kernel<DHV, true>, smem);                                                     \
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<DHV, true>), gq, dim3(256), smem, stream, *a);               \
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<DHV, true>), gk, dim3(256), smem, stream, *a);              \
-    } else {                                                                                              \
-      int smem = set_smem(attn_bwd_dq_kernel<DHV, false>, 4 * Cfg<DHV>::TILE * 2 + 1024);                 \
-      set_smem(attn_bwd_dkv_kernel<DHV, false>, smem);                                                    \
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<DHV, false>), gq, dim3(256), smem, stream, *a);              \
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<DHV, false>), gk, dim3(256), smem, stream, *a);             \
+    bool dq_done = false, dkv_done = false;                                                               \
+    if constexpr (DHV <= 64) {                                                                            \
+      if (q2) { PH_DQ_LAUNCH(DHV, true, 2) dq_done = true; }                                              \
     }                                                                                                     \
+    if (!dq_done) { if (plain) PH_DQ_LAUNCH(DHV, true, 1) else PH_DQ_LAUNCH(DHV, false, 1) }              \
+    if constexpr (DHV <= 64) {                                                                            \
+      if (k2) { PH_DKV_LAUNCH(DHV, true, 2) dkv_done = true; }                                            \
+    }                                                                                                     \
+    if (!dkv_done) { if (plain) PH_DKV_LAUNCH(DHV, true, 1) else PH_DKV_LAUNCH(DHV, false, 1) }           \
   } break;
   switch (f.dh) { PH_BWD(32) PH_BWD(64) PH_BWD(96) PH_BWD(128) }
+#undef PH_DQ_LAUNCH
+#undef PH_DKV_LAUNCH
 #undef PH_BWD
   PH_LAUNCH_CHECK("attn_bwd kernels");
   return PH_OK;
