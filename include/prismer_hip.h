@@ -340,6 +340,15 @@ int ph_conv_dgrad_shadow_grouped(const ph_conv_dgrad_item* items, int n, hipStre
 /* launches per GEMM kernel class since the last reset (128x128, 64x64, intra-block k split, 256x128 single, 256x128 grouped,
  * grouped 128/64, split-K reduce): out[0..n-1]; returns the number of classes.  Lets a test assert which kernels a program ran. */
 int ph_gemm_dispatch_counts(int64_t* out, int n, int reset);
+/* Scratch sizing for hosts that own their buffers (`ph_query_workspace(op, dims) -> size_t`): bytes of the scratch /
+ * workspace argument of entry point `op` for the given dimensions (the largest amount the entry point can make use of; every
+ * workspace is optional or has this exact size).  Returns -1 for an unknown op or a wrong number of dims.
+ *   PH_WS_GEMM_SPLITK     dims = {M, N, K}: ph_gemm_args.workspace (split-K partial tiles, up to 256 splits of [M][N rounded to 4] fp32)
+ *   PH_WS_LAYERNORM_BWD   dims = {M, D}:    ph_layernorm_bwd_args.partial_ws ([ph_layernorm_bwd_blocks(M)][2][D] fp32)
+ *   PH_WS_ATTENTION_BWD   dims = {B, H, Sq}: ph_attn_bwd_args.delta ([B*H*Sq] fp32)
+ *   PH_WS_CONV_COLSTATS   dims = {N}:       ph_gemm_args.col_stats ([PH_COLSTAT_SLABS][2][N] fp64, zeroed by the caller) */
+enum { PH_WS_GEMM_SPLITK = 0, PH_WS_LAYERNORM_BWD = 1, PH_WS_ATTENTION_BWD = 2, PH_WS_CONV_COLSTATS = 3 };
+int64_t ph_query_workspace(int op, const int64_t* dims, int ndims);
 /* advance the dropout seed (device-side, graph-replay safe): seed[0] = splitmix(seed[0]) */
 int ph_advance_seed(uint64_t* seed, hipStream_t stream);
 

@@ -169,6 +169,7 @@ _SIGS = {
     'ph_gemm_grouped_capped_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p]),
     'ph_gemm_tuning': (c_int, [c_int, c_int]),
     'ph_gemm_dispatch_counts': (c_int, [c_void_p, c_int, c_int]),
+    'ph_query_workspace': (c_i64, [c_int, c_void_p, c_int]),
     'ph_conv_dgrad_shadow_grouped': (c_int, [c_void_p, c_int, c_void_p]),
     'ph_add_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     'ph_act_bwd_bf16': (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),

@@ -19,6 +19,29 @@ int ph_fail(int code, const char* fmt, ...) {
 }
 
 extern "C" int ph_version(void) { return PH_VERSION; }
+
+extern "C" int ph_layernorm_bwd_blocks(int M);
+extern "C" int64_t ph_query_workspace(int op, const int64_t* dims, int ndims) {
+  if (!dims) return -1;
+  switch (op) {
+    case PH_WS_GEMM_SPLITK: {
+      if (ndims != 3 || dims[0] <= 0 || dims[1] <= 0 || dims[2] <= 0) return -1;
+      const int64_t kt = (dims[2] + 63) / 64, splits = kt / 2 < 256 ? (kt / 2 < 1 ? 1 : kt / 2) : 256;     // a split holds >= 2 k-tiles
+      return splits <= 1 ? 0 : splits * dims[0] * ((dims[1] + 3) / 4 * 4) * 4;
+    }
+    case PH_WS_LAYERNORM_BWD:
+      if (ndims != 2 || dims[0] <= 0 || dims[1] <= 0) return -1;
+      return (int64_t)ph_layernorm_bwd_blocks((int)dims[0]) * 2 * dims[1] * 4;
+    case PH_WS_ATTENTION_BWD:
+      if (ndims != 3 || dims[0] <= 0 || dims[1] <= 0 || dims[2] <= 0) return -1;
+      return dims[0] * dims[1] * dims[2] * 4;
+    case PH_WS_CONV_COLSTATS:
+      if (ndims != 1 || dims[0] <= 0) return -1;
+      return (int64_t)PH_COLSTAT_SLABS * 2 * dims[0] * 8;
+    default:
+      return -1;
+  }
+}
 extern "C" const char* ph_last_error(void) { return g_last_error.c_str(); }
 
 // ---- kernel-family timing -----------------------------------------------------------------------------------------

@@ -255,19 +255,34 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupParams g) {
 
 
 
-// folds the split-K partials and applies the fused epilogue (bias / activation / dropout / residual / accumulate / dtype)
+// folds the split-K partials and applies the fused epilogue (bias / activation / dropout / residual / accumulate / dtype).
+// LANES threads share one output vector: lane l sums the splits l, l + LANES, ... and the group is folded with shuffles -- with up to
+// 256 splits of a tiny output (the stems' first-layer weight gradients: 768 output vectors) one thread per vector walked 256
+// dependent loads (62 us for 3 blocks); 16 lanes per vector make it 16 loads and 48 blocks.
+template <int LANES>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int splits) {
   const int n4 = (p.N + 3) / 4;
   int64_t total = (int64_t)p.M * n4;
   DropCtx dc;
   const bool drop = p.drop_p > 0.0f;
   if (drop) dc = make_drop(p.drop_seed, p.drop_stream, p.drop_p);
-  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+  const int sub = threadIdx.x % LANES;
+  // (the LANES lanes of a group share `id`, hence their control flow: the shuffles below always see the whole group)
+  for (int64_t id = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LANES; id < total; id += (int64_t)gridDim.x * (256 / LANES)) {
     int m = (int)(id / n4), n = (int)(id % n4) * 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < splits; ++s) acc += *reinterpret_cast<const f32x4*>(p.ws + ((size_t)s * p.M + m) * p.ldws + n);
-    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-    epilogue_store(p, m, n, v, false, drop, dc);
+    for (int s = sub; s < splits; s += LANES) acc += *reinterpret_cast<const f32x4*>(p.ws + ((size_t)s * p.M + m) * p.ldws + n);
+    if constexpr (LANES > 1) {
+#pragma unroll
+      for (int o = LANES / 2; o > 0; o >>= 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+      }
+    }
+    if (sub == 0) {
+      float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+      epilogue_store(p, m, n, v, false, drop, dc);
+    }
   }
 }
 
@@ -573,7 +588,8 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
     // two waves of a SIMD alternate read and MFMA phases; default), 6 = ping-pong + s_setprio around the MFMA phase
     const int big_mode = big_mode_now(), big_min_tiles = big_min_tiles_now();
     const int64_t tb = (int64_t)ceil_div(a->M, big::BM) * ceil_div(a->N, big::BN);
-    static const int wide = env_int("PH_GEMM_BIG_WIDE", 0);    // 1: also the wide-N, short-K launches (in the step they do not gain, see below)
+    static const int wide = env_int("PH_GEMM_BIG_WIDE", 1);    // 1 (default since the tail split: c_fc / c_proj-dgrad become exactly 3 rounds of 256
+                                                               // tiles; step -0.17 ms in two A/B pairs): also the wide-N, short-K launches
     const bool wide_ok = wide != 0;
     static const int tb_ok = env_int("PH_GEMM_BIG_TB", 1);     // 0: keep the [K][N]-B (dgrad-shaped) problems on the 128x128 kernel
     // block rounds of either kernel (constants from the per-shape fits, us): a 256x128 block alone on its CU, a pair of co-resident
@@ -679,9 +695,15 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
            : BN == 64 ? dispatch_layout<128, 64>(p, a->trans_a, a->trans_b, splits, stream)
                       : dispatch_layout<128, 128>(p, a->trans_a, a->trans_b, splits, stream);
   if (rc != PH_OK || !p.ws) return rc;
-  int grid = (int)min((int64_t)2048, ceil_div64((int64_t)a->M * ((a->N + 3) / 4), 256));
+  const int64_t vecs = (int64_t)a->M * ((a->N + 3) / 4);
   count_launch(PH_GEMM_CLS_SPLITK_REDUCE);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, p, splits);
+  if (splits >= 32 && vecs <= 16384) {                    // many splits of a small output: 16 lanes per output vector
+    int grid = (int)min((int64_t)2048, ceil_div64(vecs * 16, 256));
+    hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3(grid), dim3(256), 0, stream, p, splits);
+  } else {
+    int grid = (int)min((int64_t)2048, ceil_div64(vecs, 256));
+    hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(grid), dim3(256), 0, stream, p, splits);
+  }
   PH_LAUNCH_CHECK("splitk_reduce_kernel");
   return PH_OK;
 }

@@ -41,6 +41,20 @@ def test_argument_validation_without_gpu():
     f.dh = 48
     rc = _lib.lib.ph_attention_fwd(C.byref(f), None)
     assert rc == -1 and b'head dim 48' in _lib.lib.ph_last_error()
+    # scratch sizing for hosts that own their buffers (ph_query_workspace)
+    q = lambda op, *d: _lib.lib.ph_query_workspace(op, (C.c_int64 * len(d))(*d), len(d))
+    assert q(0, 960, 768, 768) == 6 * 960 * 768 * 4            # GEMM split-K: 12 k-tiles -> at most 6 splits of [M][N] fp32
+    assert q(0, 96, 32, 401408) == 256 * 96 * 32 * 4           # capped at 256 splits
+    assert q(0, 128, 128, 64) == 0
+    assert q(1, 8320, 768) == _lib.lib.ph_layernorm_bwd_blocks(8320) * 2 * 768 * 4
+    assert q(2, 32, 12, 260) == 32 * 12 * 260 * 4
+    assert q(3, 192) == 8 * 2 * 192 * 8
+    assert q(9, 1) == -1 and q(0, 1, 2) == -1
+    # output row map / generalised conv window: validated before any launch
+    g = _lib.GemmArgs(); g.A = g.B = g.C = 16; g.M = g.N = g.K = 64; g.lda = g.ldb = g.ldc = 64; g.rowmap_wo = 7; g.accumulate = 1
+    assert _lib.lib.ph_gemm_bf16(C.byref(g), None) == -1 and b'row map' in _lib.lib.ph_last_error()
+    cnt = (C.c_int64 * 8)()
+    assert _lib.lib.ph_gemm_dispatch_counts(cnt, 8, 1) == 7
 
 
 def test_struct_sizes_match_header():
@@ -56,8 +70,8 @@ def test_struct_sizes_match_header():
 int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ph_gemm_args), sizeof(ph_layernorm_fwd_args), sizeof(ph_layernorm_bwd_args),
          sizeof(ph_attn_fwd_args), sizeof(ph_attn_bwd_args), sizeof(ph_embed_fwd_args), sizeof(ph_embed_bwd_args), sizeof(ph_rowmap));
-  printf("%zu %zu %zu %zu\n", offsetof(ph_gemm_args, split_k), offsetof(ph_layernorm_bwd_args, D), offsetof(ph_attn_bwd_args, delta),
-         offsetof(ph_embed_bwd_args, dbeta));
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", offsetof(ph_gemm_args, split_k), offsetof(ph_layernorm_bwd_args, D), offsetof(ph_attn_bwd_args, delta),
+         offsetof(ph_embed_bwd_args, dbeta), offsetof(ph_gemm_args, rowmap_add), sizeof(ph_conv_gather), sizeof(ph_conv_dgrad_item));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as td:
@@ -70,7 +84,7 @@ int main(void) {
     assert sizes == [C.sizeof(_lib.GemmArgs), C.sizeof(_lib.LayerNormFwdArgs), C.sizeof(_lib.LayerNormBwdArgs), C.sizeof(_lib.AttnFwdArgs),
                      C.sizeof(_lib.AttnBwdArgs), C.sizeof(_lib.EmbedFwdArgs), C.sizeof(_lib.EmbedBwdArgs), C.sizeof(_lib.RowMap)]
     assert offs == [_lib.GemmArgs.split_k.offset, _lib.LayerNormBwdArgs.D.offset, _lib.AttnBwdArgs.delta.offset,
-                    _lib.EmbedBwdArgs.dbeta.offset]
+                    _lib.EmbedBwdArgs.dbeta.offset, _lib.GemmArgs.rowmap_add.offset, C.sizeof(_lib.ConvGather), C.sizeof(_lib.ConvDgradItem)]
 
 
 def test_comm_library_exports_header_symbols():

@@ -254,6 +254,14 @@ def test_gemm_f32_accumulate_splitk(ops):
     cb0 = cb.clone()
     ops.gemm(dy, x, out=cb, trans_a=True, trans_b=True, accumulate=True, alpha=0.5)
     assert rel_fro(cb, cb0.float() + 0.5 * ref) < 6e-3
+    # tiny output, very long reduction (the stems' first-layer weight gradients: 96 x 32 over 401 408 rows): up to 256 splits, folded by
+    # the 16-lanes-per-vector reduce (round 3)
+    M2, N2, K2 = 96, 32, 100352
+    dy2, x2 = rnd(K2, M2, scale=0.3, seed=13), rnd(K2, N2, scale=0.3, seed=14)
+    ref2 = dy2.float().t() @ x2.float()
+    for split in (0, 64, 256):
+        c2 = ops.gemm(dy2, x2, trans_a=True, trans_b=True, out_f32=True, split_k=split)
+        assert rel_fro(c2, ref2) < 3e-4, (split, rel_fro(c2, ref2))
 
 
 @pytest.mark.parametrize('shapes', [
