@@ -534,7 +534,9 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
                         : launch_grouped<64, true, true, 1, 2>(g, total, max_blocks, stream);
   }
   if (BMsel == 128) {
-    if (kfull && PH_RING128 > 1 && !ta) return launch_grouped_layout<128, PH_RING128>(g, total, max_blocks, ta, tb, stream);
+    static const int tt_ring = env_int("PH_GEMM_TT_RING", 1);        // prefetch ring for the [K,M] x [K,N] weight-gradient groups too (round 3:
+                                                                     // step -0.07 / -0.17 ms in two same-box pairs; round 1 measured -4 % on single launches)
+    if (kfull && PH_RING128 > 1 && (!ta || tt_ring)) return launch_grouped_layout<128, PH_RING128>(g, total, max_blocks, ta, tb, stream);
     return launch_grouped_layout<128, 1>(g, total, max_blocks, ta, tb, stream);
   }
   if (kfull && PH_RING64 > 1) return launch_grouped_layout<64, PH_RING64>(g, total, max_blocks, ta, tb, stream);
