@@ -37,18 +37,37 @@ struct Cfg {
 // ---- tile staging: 64 rows x DH of a strided [token][head*dh] tensor -> registers -> LDS.
 // Rows beyond n_rows re-read the last valid row (finite data; every consumer masks them by index): the loads carry no
 // predicate, so the prefetch is straight-line code and the compiler's vmcnt bookkeeping stays exact around the tile loop.
+// Tile loads (round 3) go through a buffer descriptor: address = descriptor base (the (batch, head) slice, SGPRs) + tile offset
+// (SGPR soffset) + per-lane chunk offset (one 32-bit VGPR per chunk, computed once per kernel) -- zero address arithmetic in the
+// tile loop, and rows beyond the end of the sequence read as zeros by the hardware bounds check instead of being clamped in
+// software.  The 64-bit form this replaces cost 31-45 VALU instructions per tile, 8-12 of them quarter-rate v_mul_lo_u32, in
+// kernels that are VALU-issue-bound (ISA count: ~900 VALU cycles against 256 MFMA cycles per wave and 64-key forward tile).
+// The launcher checks that a slice spans < 2 GiB.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t tile_rsrc(const bf16* base, int64_t ts, int n_rows, int dh) {
+  // readfirstlane makes the wave-uniformity of the descriptor provable (no waterfall loop around every load)
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  const uint32_t bytes = __builtin_amdgcn_readfirstlane((uint32_t)(((int64_t)(n_rows - 1) * ts + dh) * 2));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, bytes, 0x00020000);
+}
 template <int DH>
-__device__ __forceinline__ void tile_gload(const bf16* __restrict__ base, int64_t ts, int row0, int n_rows,
-                                           u32x4 (&regs)[Cfg<DH>::NLD]) {
+__device__ __forceinline__ void tile_offsets(int64_t ts, uint32_t (&off)[Cfg<DH>::NLD]) {
   constexpr int CPR = Cfg<DH>::CPR;
-  static_assert(64 * CPR % 256 == 0, "tile chunks must divide over 256 threads");
 #pragma unroll
   for (int i = 0; i < Cfg<DH>::NLD; ++i) {
     int id = threadIdx.x + 256 * i;
     int r = id / CPR, c = id % CPR;
-    int row = min(row0 + r, n_rows - 1);
-    regs[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)row * ts + c * 8);
+    off[i] = (uint32_t)((r * ts + c * 8) * 2);
   }
+}
+template <int DH>
+__device__ __forceinline__ void tile_gload(rsrc_t rs, int64_t ts, int row0, const uint32_t (&off)[Cfg<DH>::NLD],
+                                           u32x4 (&regs)[Cfg<DH>::NLD]) {
+  const uint32_t soff = __builtin_amdgcn_readfirstlane((uint32_t)(row0 * ts * 2));
+#pragma unroll
+  for (int i = 0; i < Cfg<DH>::NLD; ++i)
+    regs[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off[i], soff, 0));
 }
 template <int DH>
 __device__ __forceinline__ void tile_lstore(bf16* lds, const u32x4 (&regs)[Cfg<DH>::NLD]) {
@@ -197,25 +216,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
   u32x4 rk[C::NLD], rv[C::NLD];
   uint32_t kraw = 1u;
   int kraw_i = threadIdx.x;
-  tile_gload<DH>(K, a.k_ts, 0, a.Sk, rk);
-  tile_gload<DH>(V, a.v_ts, 0, a.Sk, rv);
-  if (threadIdx.x < 64) kraw = key_raw(km, kraw_i, a.Sk);
+  uint32_t koff[C::NLD], voff[C::NLD];
+  tile_offsets<DH>(a.k_ts, koff);
+  tile_offsets<DH>(a.v_ts, voff);
+  const rsrc_t krs = tile_rsrc(K, a.k_ts, a.Sk, DH), vrs = tile_rsrc(V, a.v_ts, a.Sk, DH);
+  tile_gload<DH>(krs, a.k_ts, 0, koff, rk);
+  tile_gload<DH>(vrs, a.v_ts, 0, voff, rv);
+  if (!PLAIN && threadIdx.x < 64) kraw = key_raw(km, kraw_i, a.Sk);
 #pragma unroll
   for (int t = 0; t < QT; ++t)
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) settle(qf[t][ks]);
   tile_lstore<DH>(smem, rk);
   tile_lstore<DH>(smem + C::TILE, rv);
-  if (threadIdx.x < 64) side[threadIdx.x] = key_state(kraw, kraw_i, a.Sk);
+  if (!PLAIN && threadIdx.x < 64) side[threadIdx.x] = key_state(kraw, kraw_i, a.Sk);
   __syncthreads();
   int cur = 0;
   for (int tl = 0; tl < ntiles; ++tl) {
     const bool more = tl + 1 < ntiles;
     if (more) {
-      tile_gload<DH>(K, a.k_ts, (tl + 1) * 64, a.Sk, rk);
-      tile_gload<DH>(V, a.v_ts, (tl + 1) * 64, a.Sk, rv);
+      tile_gload<DH>(krs, a.k_ts, (tl + 1) * 64, koff, rk);
+      tile_gload<DH>(vrs, a.v_ts, (tl + 1) * 64, voff, rv);
       kraw_i = (tl + 1) * 64 + threadIdx.x;
-      if (threadIdx.x < 64) kraw = key_raw(km, kraw_i, a.Sk);
+      if (!PLAIN && threadIdx.x < 64) kraw = key_raw(km, kraw_i, a.Sk);
     }
     const bf16* kl = smem + cur * 2 * C::TILE;
     const bf16* vl = kl + C::TILE;
@@ -256,13 +279,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
 #pragma unroll
             for (int t = 0; t < QT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[t][ks], acc[t], 0, 0, 0);
           }
-          if constexpr (PLAIN) {                      // base-2 scores: s * scale * log2(e)
-            const float c2 = a.scale * LOG2E;
+          if constexpr (PLAIN) {                      // raw scores; the scale (> 0) is applied inside the exponent's fma below
 #pragma unroll
             for (int t = 0; t < QT; ++t)
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                acc[t][r] *= c2;
                 if (TAIL) acc[t][r] = (kbase + nt * 16 + g * 4 + r < a.Sk) ? acc[t][r] : -INFINITY;
                 mx[t] = fmaxf(mx[t], acc[t][r]);
               }
@@ -286,18 +307,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
       }
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
-        const float mxt = xor_max(mx[t]);
+        // PLAIN: m is kept in base-2 units of the scaled score, p = exp2(fma(s_raw, scale * log2(e), -m)); the arithmetic is written on
+        // float pairs so that it issues as v_pk_fma_f32 / v_pk_add_f32 (the kernel is VALU-issue-bound, not MFMA- or LDS-bound)
+        const float c2 = a.scale * LOG2E;
+        const float mxt = PLAIN ? xor_max(mx[t]) * c2 : xor_max(mx[t]);
         const float m_new = fmaxf(m[t], mxt);
         const float alpha = PLAIN ? fast_exp2(m[t] - m_new) : __expf(m[t] - m_new);
         float rs = 0.f;
+        if constexpr (PLAIN) {
+          const f32x2 c2v = {c2, c2}, nm = {-m_new, -m_new};
+          f32x2 rs2 = {0.f, 0.f};
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+          for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float p = PLAIN ? fast_exp2(s[t][nt][r] - m_new) : __expf(s[t][nt][r] - m_new);
-            rs += p;
-            s[t][nt][r] = p;
-          }
+            for (int r = 0; r < 4; r += 2) {
+              f32x2 x = {s[t][nt][r], s[t][nt][r + 1]};
+              x = __builtin_elementwise_fma(x, c2v, nm);
+              f32x2 p2 = {fast_exp2(x[0]), fast_exp2(x[1])};
+              rs2 += p2;
+              s[t][nt][r] = p2[0];
+              s[t][nt][r + 1] = p2[1];
+            }
+          rs = rs2[0] + rs2[1];
+        } else {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float p = __expf(s[t][nt][r] - m_new);
+              rs += p;
+              s[t][nt][r] = p;
+            }
+        }
         rs = xor_sum(rs);
         lsum[t] = lsum[t] * alpha + rs;
         m[t] = m_new;
@@ -335,7 +376,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
     if (more) {
       tile_lstore<DH>(smem + (cur ^ 1) * 2 * C::TILE, rk);
       tile_lstore<DH>(smem + (cur ^ 1) * 2 * C::TILE + C::TILE, rv);
-      if (threadIdx.x < 64) side[(cur ^ 1) * 128 + threadIdx.x] = key_state(kraw, kraw_i, a.Sk);
+      if (!PLAIN && threadIdx.x < 64) side[(cur ^ 1) * 128 + threadIdx.x] = key_state(kraw, kraw_i, a.Sk);
     }
     __syncthreads();
     cur ^= 1;
@@ -411,9 +452,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
   u32x4 rk[C::NLD], rv[C::NLD];
   uint32_t kraw = 1u;
   int kraw_i = threadIdx.x;
-  tile_gload<DH>(K, f.k_ts, 0, f.Sk, rk);
-  tile_gload<DH>(V, f.v_ts, 0, f.Sk, rv);
-  if (threadIdx.x < 64) kraw = key_raw(km, kraw_i, f.Sk);
+  uint32_t koff[C::NLD], voff[C::NLD];
+  tile_offsets<DH>(f.k_ts, koff);
+  tile_offsets<DH>(f.v_ts, voff);
+  const rsrc_t krs = tile_rsrc(K, f.k_ts, f.Sk, DH), vrs = tile_rsrc(V, f.v_ts, f.Sk, DH);
+  tile_gload<DH>(krs, f.k_ts, 0, koff, rk);
+  tile_gload<DH>(vrs, f.v_ts, 0, voff, rv);
+  if (!PLAIN && threadIdx.x < 64) kraw = key_raw(km, kraw_i, f.Sk);
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
 #pragma unroll
@@ -422,7 +467,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
   }
   tile_lstore<DH>(smem, rk);
   tile_lstore<DH>(smem + C::TILE, rv);
-  if (threadIdx.x < 64) side[threadIdx.x] = key_state(kraw, kraw_i, f.Sk);
+  if (!PLAIN && threadIdx.x < 64) side[threadIdx.x] = key_state(kraw, kraw_i, f.Sk);
   __syncthreads();
   int cur = 0;
   for (int u = 0; u < nsteps; ++u) {
@@ -431,10 +476,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
     const bool more = u + 1 < nsteps;
     if (more) {
       const int tn = (tl + 1 == ntiles) ? 0 : tl + 1;
-      tile_gload<DH>(K, f.k_ts, tn * 64, f.Sk, rk);
-      tile_gload<DH>(V, f.v_ts, tn * 64, f.Sk, rv);
+      tile_gload<DH>(krs, f.k_ts, tn * 64, koff, rk);
+      tile_gload<DH>(vrs, f.v_ts, tn * 64, voff, rv);
       kraw_i = tn * 64 + threadIdx.x;
-      if (threadIdx.x < 64) kraw = key_raw(km, kraw_i, f.Sk);
+      if (!PLAIN && threadIdx.x < 64) kraw = key_raw(km, kraw_i, f.Sk);
     }
     const bf16* kl = smem + cur * 2 * C::TILE;
     const bf16* vl = kl + C::TILE;
@@ -464,13 +509,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
               const float l2 = lse[t] * LOG2E;
+              const f32x2 c2v = {c2, c2}, nl = {-l2, -l2}, dl2 = {delta[t], delta[t]};
+              f32x2 part = {0.f, 0.f};
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                float p = fast_exp2(fmaf(acc[t][r], c2, -l2));
-                if (TAIL) p = (kbase + nt * 16 + g * 4 + r < f.Sk) ? p : 0.f;
-                dsum[t] += p * dp[t][r];
-                ds[t][nt][r] = p * (dp[t][r] - delta[t]);
+              for (int r = 0; r < 4; r += 2) {                // float pairs: v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32
+                f32x2 x = {acc[t][r], acc[t][r + 1]};
+                x = __builtin_elementwise_fma(x, c2v, nl);
+                f32x2 p2 = {fast_exp2(x[0]), fast_exp2(x[1])};
+                if (TAIL) {
+                  p2[0] = (kbase + nt * 16 + g * 4 + r < f.Sk) ? p2[0] : 0.f;
+                  p2[1] = (kbase + nt * 16 + g * 4 + r + 1 < f.Sk) ? p2[1] : 0.f;
+                }
+                const f32x2 dd = {dp[t][r], dp[t][r + 1]};
+                part = __builtin_elementwise_fma(p2, dd, part);
+                const f32x2 dv2 = p2 * (dd - dl2);
+                ds[t][nt][r] = dv2[0];
+                ds[t][nt][r + 1] = dv2[1];
               }
+              dsum[t] += part[0] + part[1];
             }
           } else {
             const f32x4 st = *reinterpret_cast<const f32x4*>(kst + nt * 16 + g * 4);
@@ -523,7 +579,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
     if (more) {
       tile_lstore<DH>(smem + (cur ^ 1) * 2 * C::TILE, rk);
       tile_lstore<DH>(smem + (cur ^ 1) * 2 * C::TILE + C::TILE, rv);
-      if (threadIdx.x < 64) side[(cur ^ 1) * 128 + threadIdx.x] = key_state(kraw, kraw_i, f.Sk);
+      if (!PLAIN && threadIdx.x < 64) side[(cur ^ 1) * 128 + threadIdx.x] = key_state(kraw, kraw_i, f.Sk);
     }
     __syncthreads();
     cur ^= 1;
@@ -592,8 +648,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
   const int ntiles = (f.Sq + 63) / 64;
   u32x4 rq[C::NLD], rd[C::NLD];
   float sreg = 0.f;
-  tile_gload<DH>(Q, f.q_ts, 0, f.Sq, rq);
-  tile_gload<DH>(dO, a.do_ts, 0, f.Sq, rd);
+  uint32_t qoff[C::NLD], dooff[C::NLD];
+  tile_offsets<DH>(f.q_ts, qoff);
+  tile_offsets<DH>(a.do_ts, dooff);
+  const rsrc_t qrs = tile_rsrc(Q, f.q_ts, f.Sq, DH), dors = tile_rsrc(dO, a.do_ts, f.Sq, DH);
+  tile_gload<DH>(qrs, f.q_ts, 0, qoff, rq);
+  tile_gload<DH>(dors, a.do_ts, 0, dooff, rd);
   if (threadIdx.x < 128) sreg = stat_base[min(stat_row, f.Sq - 1)];
   bool key_masked[QT];
 #pragma unroll
@@ -605,14 +665,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
   }
   tile_lstore<DH>(smem, rq);
   tile_lstore<DH>(smem + C::TILE, rd);
-  if (threadIdx.x < 128) side[threadIdx.x] = sreg;
+  // PLAIN: the lse half of the side data is staged as -lse * log2(e), the addend of the exponent's fma (one multiply per row and
+  // tile instead of one per score element in every wave)
+  const float stat_mul = (PLAIN && threadIdx.x < 64) ? -LOG2E : 1.f;
+  if (threadIdx.x < 128) side[threadIdx.x] = sreg * stat_mul;
   __syncthreads();
   int cur = 0;
   for (int tl = 0; tl < ntiles; ++tl) {
     const bool more = tl + 1 < ntiles;
     if (more) {
-      tile_gload<DH>(Q, f.q_ts, (tl + 1) * 64, f.Sq, rq);
-      tile_gload<DH>(dO, a.do_ts, (tl + 1) * 64, f.Sq, rd);
+      tile_gload<DH>(qrs, f.q_ts, (tl + 1) * 64, qoff, rq);
+      tile_gload<DH>(dors, a.do_ts, (tl + 1) * 64, dooff, rd);
       if (threadIdx.x < 128) sreg = stat_base[min((tl + 1) * 64 + stat_row, f.Sq - 1)];
     }
     const bf16* ql = smem + cur * 2 * C::TILE;
@@ -642,14 +705,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
           const f32x4 d4 = *reinterpret_cast<const f32x4*>(stl + 64 + qt * 16 + g * 4);
           if constexpr (PLAIN) {
             const float c2 = f.scale * LOG2E;
+            const f32x2 c2v = {c2, c2};
 #pragma unroll
             for (int t = 0; t < QT; ++t)
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                float p = fast_exp2(fmaf(acc[t][r], c2, -l4[r] * LOG2E));
-                if (TAIL) p = (qbase + qt * 16 + g * 4 + r < f.Sq && ki[t] < f.Sk) ? p : 0.f;
-                pd[t][qt][r] = p;
-                ds[t][qt][r] = p * (dp[t][r] - d4[r]);
+              for (int r = 0; r < 4; r += 2) {                // float pairs: v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32
+                const f32x2 nl = {l4[r], l4[r + 1]}, dl2 = {d4[r], d4[r + 1]};
+                f32x2 x = {acc[t][r], acc[t][r + 1]};
+                x = __builtin_elementwise_fma(x, c2v, nl);
+                f32x2 p2 = {fast_exp2(x[0]), fast_exp2(x[1])};
+                if (TAIL) {
+                  p2[0] = (qbase + qt * 16 + g * 4 + r < f.Sq && ki[t] < f.Sk) ? p2[0] : 0.f;
+                  p2[1] = (qbase + qt * 16 + g * 4 + r + 1 < f.Sq && ki[t] < f.Sk) ? p2[1] : 0.f;
+                }
+                f32x2 dd = {dp[t][r], dp[t][r + 1]};
+                dd = p2 * (dd - dl2);
+                pd[t][qt][r] = p2[0];
+                pd[t][qt][r + 1] = p2[1];
+                ds[t][qt][r] = dd[0];
+                ds[t][qt][r + 1] = dd[1];
               }
           } else {
 #pragma unroll
@@ -707,7 +781,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
     if (more) {
       tile_lstore<DH>(smem + (cur ^ 1) * 2 * C::TILE, rq);
       tile_lstore<DH>(smem + (cur ^ 1) * 2 * C::TILE + C::TILE, rd);
-      if (threadIdx.x < 128) side[(cur ^ 1) * 128 + threadIdx.x] = sreg;
+      if (threadIdx.x < 128) side[(cur ^ 1) * 128 + threadIdx.x] = sreg * stat_mul;
     }
     __syncthreads();
     cur ^= 1;
@@ -752,6 +826,8 @@ int check_fwd(const ph_attn_fwd_args* f, const char* who) {
   PH_CHECK_ARG(f->dh == 32 || f->dh == 64 || f->dh == 96 || f->dh == 128, "%s: head dim %d unsupported (32/64/96/128)", who, f->dh);
   PH_CHECK_ARG(((f->q_ts | f->k_ts | f->v_ts | f->o_ts | f->q_bs | f->k_bs | f->v_bs | f->o_bs) % 8) == 0, "%s: strides must be multiples of 8 elements", who);
   PH_CHECK_ARG((((uintptr_t)f->q | (uintptr_t)f->k | (uintptr_t)f->v | (uintptr_t)f->o) & 15) == 0, "%s: pointers must be 16-B aligned", who);
+  PH_CHECK_ARG(((int64_t)f->Sq * f->q_ts | (int64_t)f->Sk * f->k_ts | (int64_t)f->Sk * f->v_ts) < (1ll << 30),
+               "%s: a (batch, head) slice must span < 2 GiB (tiles are fetched through 32-bit buffer offsets)", who);
   PH_CHECK_ARG(!(f->drop_p > 0.f) || f->drop_seed, "%s: dropout needs a seed", who);
   return PH_OK;
 }
@@ -791,6 +867,7 @@ extern "C" int ph_attention_bwd(const ph_attn_bwd_args* a, hipStream_t stream) {
   if (rc) return rc;
   PH_CHECK_ARG(a->d_o && a->dq && a->dk && a->dv && a->delta && a->f.lse, "ph_attention_bwd: null pointer");
   PH_CHECK_ARG(((a->do_ts | a->dq_ts | a->dk_ts | a->dv_ts | a->do_bs | a->dq_bs | a->dk_bs | a->dv_bs) % 8) == 0, "ph_attention_bwd: strides must be multiples of 8");
+  PH_CHECK_ARG((int64_t)a->f.Sq * a->do_ts < (1ll << 30), "ph_attention_bwd: a (batch, head) slice of dO must span < 2 GiB");
   const ph_attn_fwd_args& f = a->f;
   const bool plain = attn_plain_ok(&f);
   // backward: 32 queries / keys per wave pay from ~512 tokens on (LARGE, S = 1220: 184 vs 189 us; ViT S = 260: 91 vs 84 us)
