@@ -161,6 +161,8 @@ int ph_ln_param_reduce_grouped(const ph_ln_reduce_item* items, int n, hipStream_
  * Token (b, t), head h, channel c of q lives at  q + b*q_bs + t*q_ts + h*dh + c   (elements).
  * key_mask[b*Sk + j] == 0 or (causal && j > i)  =>  score = finfo.min (finite, as roberta.py:113-115).
  * lse[(b*H+h)*Sq + i] = log-sum-exp of the scaled, masked scores (saved for backward).
+ * One (batch, head) slice of q / k / v / dO must span < 2 GiB (Sq*q_ts, Sk*k_ts, Sk*v_ts < 2^30 elements): tiles are fetched
+ * through buffer descriptors with 32-bit offsets; larger slices are rejected with PH_ERR.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
   const void* q; const void* k; const void* v; void* o;

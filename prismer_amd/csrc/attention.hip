@@ -805,7 +805,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
 // no causal cut, no key mask, no probability dropout -> the PLAIN kernels (PH_ATTN_PLAIN=0: A/B against the generic ones)
 bool attn_plain_ok(const ph_attn_fwd_args* f) {
   static const bool on = [] { const char* e = getenv("PH_ATTN_PLAIN"); return !e || atoi(e) != 0; }();
-  return on && !f->causal && !f->key_mask && !(f->drop_p > 0.f);
+  return on && !f->causal && !f->key_mask && !(f->drop_p > 0.f) && f->scale > 0.f;     // (the row max is taken on raw scores: needs scale > 0)
 }
 
 // 32 queries (keys, in the dK/dV kernel) per wave for long enough sequences

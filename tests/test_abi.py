@@ -41,6 +41,9 @@ def test_argument_validation_without_gpu():
     f.dh = 48
     rc = _lib.lib.ph_attention_fwd(C.byref(f), None)
     assert rc == -1 and b'head dim 48' in _lib.lib.ph_last_error()
+    f.dh = 64; f.Sk = 1 << 20; f.k_ts = 1 << 12; f.q_ts = f.v_ts = f.o_ts = 64                # K slice of 8 GiB: beyond the 32-bit tile offsets
+    rc = _lib.lib.ph_attention_fwd(C.byref(f), None)
+    assert rc == -1 and b'2 GiB' in _lib.lib.ph_last_error()
     # scratch sizing for hosts that own their buffers (ph_query_workspace)
     q = lambda op, *d: _lib.lib.ph_query_workspace(op, (C.c_int64 * len(d))(*d), len(d))
     assert q(0, 960, 768, 768) == 6 * 960 * 768 * 4            # GEMM split-K: 12 k-tiles -> at most 6 splits of [M][N] fp32
