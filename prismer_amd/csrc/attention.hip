@@ -24,11 +24,14 @@ namespace {
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
+#ifndef PH_ATTN_PAD
+#define PH_ATTN_PAD 8
+#endif
 template <int DH>
 struct Cfg {
   static constexpr int KS = DH / 32;       // MFMA k-steps over the head dimension
   static constexpr int DT = DH / 16;       // 16-wide tiles over the head dimension
-  static constexpr int RS = DH + 8;        // LDS row stride in elements (16-B pad)
+  static constexpr int RS = DH + PH_ATTN_PAD;   // LDS row stride in elements
   static constexpr int TILE = 64 * RS;     // elements per 64-row tile
   static constexpr int CPR = DH / 8;       // 16-B chunks per row
   static constexpr int NLD = 64 * CPR / 256 > 0 ? 64 * CPR / 256 : 1;   // chunks per thread per tile

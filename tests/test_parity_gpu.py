@@ -473,8 +473,20 @@ def _check_grads_against_golden(g, named_grads, tag):
 PROJ_SLACK = 1.8
 
 
-@pytest.mark.parametrize('name', ['base_b8', 'zbase_b4', 'large_vqa_b1', 'base_b32'])
+@pytest.mark.parametrize('name', ['base_b8', 'zbase_b4', 'large_vqa_b1', 'large_vqa_b1+big', 'base_b32'])
 def test_trainer_hipgraph_step_matches_reference_golden(name):
+    force_big = name.endswith('+big')           # LARGE shapes (H = 1024, 24 + 24 layers, S = 1220) through the 256x128 ping-pong kernel:
+    name = name.split('+')[0]                   # at B = 1 the cost model never picks it, config 5's bs16 does
+    from prismer_amd import _lib as _l
+    if force_big:
+        _l.lib.ph_gemm_tuning(5, 1)
+    try:
+        _hipgraph_step_vs_golden(name, force_big)
+    finally:
+        _l.lib.ph_gemm_tuning(5, 128)
+
+
+def _hipgraph_step_vs_golden(name, force_big=False):
     """Prismer-BASE B=8 (BASELINE config 3 geometry), PrismerZ-BASE B=4 (config 2), Prismer-LARGE VQA 480^2 B=1 (config 5): full
     depth.  First replayed step: loss, every trainable gradient (norm + sampled entries, autocast yardstick), BatchNorm
     running statistics after exactly ONE update, and the fused AdamW result."""
@@ -494,6 +506,8 @@ def test_trainer_hipgraph_step_matches_reference_golden(name):
     ncls = _lib.lib.ph_gemm_dispatch_counts(counts, 16, 0)
     by_class = dict(zip(('128x128', '64x64', 'ks2', 'big', 'big_grouped', 'grouped', 'splitk_reduce'), list(counts)[:ncls]))
     print(name, 'GEMM launches by kernel class during warm-up + capture:', by_class)
+    if force_big:
+        assert by_class['big'] > 0, by_class
     if name == 'base_b32':
         # the benchmark configuration itself: the 256x128 ping-pong kernel (M = 8320: N = 768 launches and long reductions) and its
         # grouped persistent form (long-reduction weight gradients) must be ON the path this fixture pins, not just unit-tested
