@@ -549,8 +549,10 @@ def _hipgraph_step_vs_golden(name, force_big=False):
     assert np.isfinite(loss2.item()) and tr.it == 2
 
 
-def test_trainer_graph_equals_eager_first_step():
-    """capture warm-up must not leak into the training state: the first replayed step and the first eager step produce the same
+@pytest.mark.parametrize('keep_grads', [True, False])
+def test_trainer_graph_equals_eager_first_step(keep_grads):
+    """(keep_grads=False is the bench's setting: the fused AdamW zeroes the gradients and the captured forward carries no fill.)
+    capture warm-up must not leak into the training state: the first replayed step and the first eager step produce the same
     loss, gradients, parameters, Adam moments, BatchNorm buffers and iteration counter (tiny geometry, dropout ON: the
     dropout seed is part of the state)."""
     case = C.Case('tiny_caption')
@@ -562,10 +564,12 @@ def test_trainer_graph_equals_eager_first_step():
         dec._seed = torch.tensor([1234567], dtype=torch.int64, device='cuda')
         m = _Holder(); m.expert_encoder, m.text_decoder = enc, dec
         x, ids, mask, labels, _ = case.inputs()
-        tr = Trainer(m, lr=1e-3, total_steps=10, use_graph=use_graph, keep_grads=True)
+        tr = Trainer(m, lr=1e-3, total_steps=10, use_graph=use_graph, keep_grads=keep_grads)
         tr.set_batch(to_dev(x), ids, mask, labels)
         random.seed(99)
         losses = [tr.step().item() for _ in range(2)]
+        if not keep_grads:
+            assert all(float(st.grad.abs().max()) == 0.0 for st in tr.stores)       # left clean for the next step
         torch.cuda.synchronize()
         res.append(dict(losses=losses, it=tr.it, seed=int(tr.seed.item()), p=[st.master.clone() for st in tr.stores],
                         m=[t.clone() for t in tr.m], bufs=[b.clone().float() for b in enc.buffers()]))
