@@ -27,6 +27,12 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 #ifndef PH_ATTN_PAD
 #define PH_ATTN_PAD 8
 #endif
+#ifndef PH_DQ_WAVES            // waves per SIMD the register allocation of the 16-row backward kernels aims at (dh <= 64)
+#define PH_DQ_WAVES 3
+#endif
+#ifndef PH_DKV_WAVES
+#define PH_DKV_WAVES 3
+#endif
 template <int DH>
 struct Cfg {
   static constexpr int KS = DH / 32;       // MFMA k-steps over the head dimension
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
 // backward: dQ  (same streaming structure as forward)
 // =====================================================================================================
 template <int DH, bool PLAIN, int QT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? (QT == 1 ? 3 : 2) : 2))) void attn_bwd_dq_kernel(ph_attn_bwd_args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? (QT == 1 ? PH_DQ_WAVES : 2) : 2))) void attn_bwd_dq_kernel(ph_attn_bwd_args a) {
   using C = Cfg<DH>;
   const ph_attn_fwd_args& f = a.f;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -604,7 +610,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
 // backward: dK, dV  (one key per lane and sub-tile; Q / dO streamed in 64-query tiles)
 // =====================================================================================================
 template <int DH, bool PLAIN, int QT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? (QT == 1 ? 3 : 2) : 2))) void attn_bwd_dkv_kernel(ph_attn_bwd_args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? (QT == 1 ? PH_DKV_WAVES : 2) : 2))) void attn_bwd_dkv_kernel(ph_attn_bwd_args a) {
   using C = Cfg<DH>;
   const ph_attn_fwd_args& f = a.f;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
