@@ -299,6 +299,12 @@ int ph_adamw(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, co
              float beta2, float eps, float weight_decay, float grad_scale, int zero_grad, hipStream_t stream);
 /* zero_grad != 0: g is overwritten with zeros after it has been read (the next step's optimizer.zero_grad(), without a
  * separate pass over the 1 GB gradient buffers) */
+/* same with a keep bitmap (bit c of word c/32 set: the 1024 gradients [1024 c, 1024 c + 1024) are NOT zeroed): ranges whose
+ * producer overwrites them in the next step -- the single-writer weight gradients of the native training step -- skip the
+ * zero store here and the read-modify-write in the producing GEMM.  keep_bitmap == NULL: identical to ph_adamw. */
+int ph_adamw_keep(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, const float* hyper, float beta1,
+                  float beta2, float eps, float weight_decay, float grad_scale, int zero_grad, const uint32_t* keep_bitmap,
+                  hipStream_t stream);
 int ph_cast_f32_to_bf16(const float* x, void* y, int64_t n, hipStream_t stream);
 int ph_cast_bf16_to_f32(const void* x, float* y, int64_t n, hipStream_t stream);
 /* y = bf16(x * scale): the gradient pack of the bf16 exchange payload, pre-scaled by 1/world BEFORE the rounding (round 3) */

@@ -156,6 +156,8 @@ _SIGS = {
     'ph_ce_bwd': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     'ph_adamw': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_float, c_float, c_float,
                          c_float, c_float, c_int, c_void_p]),
+    'ph_adamw_keep': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_float, c_float, c_float,
+                              c_float, c_float, c_int, c_void_p, c_void_p]),
     'ph_cast_f32_to_bf16': (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     'ph_cast_bf16_to_f32': (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     'ph_scale_cast_f32_to_bf16': (c_int, [c_void_p, c_void_p, c_i64, c_float, c_void_p]),

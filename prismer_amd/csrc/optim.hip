@@ -12,7 +12,8 @@ namespace {
 // HBM-bound: 16 B read + 14 B written per parameter.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16* __restrict__ pb, int64_t n, const float* __restrict__ hyper,
-                                                    float b1, float b2, float eps, float wd, float gscale, int zero_g, int mode) {
+                                                    float b1, float b2, float eps, float wd, float gscale, int zero_g, int mode,
+                                                    const uint32_t* __restrict__ keep) {
   const float lr = hyper[0], bc1 = hyper[1], bc2 = hyper[2];
   const float step = lr / bc1, rbc2 = rsqrtf(bc2), decay = 1.f - lr * wd;
   int64_t n4 = n >> 2;
@@ -26,6 +27,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
 #define LD4(ptr, i) (reinterpret_cast<f32x4*>(ptr)[i])
 #define ST4(ptr, i, val) (reinterpret_cast<f32x4*>(ptr)[i] = (val))
 #endif
+  // keep (optional): bit c set = the 1024 gradients of chunk c are NOT zeroed -- ranges whose producer overwrites them in the next
+  // step (single-writer weight gradients, Trainer): saves their 4 B/parameter of zero stores here and the C read of the producing GEMM
+  auto zero_vec = [&](int64_t i) -> bool {            // i: float4 index
+    if (!zero_g) return false;
+    if (!keep) return true;
+    const int64_t c = i >> 8;
+    return !((keep[c >> 5] >> (c & 31)) & 1u);
+  };
   auto update = [&](f32x4& tp, const f32x4& tg, f32x4& tm, f32x4& tv, bf16x4& ob) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -52,12 +61,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
       update(tp0, tg0, tm0, tv0, ob0);
       ST4(p, i, tp0); ST4(m, i, tm0); ST4(v, i, tv0);
       if (pb) reinterpret_cast<bf16x4*>(pb)[i] = ob0;
-      if (zero_g) ST4(g, i, (f32x4{0.f, 0.f, 0.f, 0.f}));
+      if (zero_vec(i)) ST4(g, i, (f32x4{0.f, 0.f, 0.f, 0.f}));
       if (two) {
         update(tp1, tg1, tm1, tv1, ob1);
         ST4(p, j, tp1); ST4(m, j, tm1); ST4(v, j, tv1);
         if (pb) reinterpret_cast<bf16x4*>(pb)[j] = ob1;
-        if (zero_g) ST4(g, j, (f32x4{0.f, 0.f, 0.f, 0.f}));
+        if (zero_vec(j)) ST4(g, j, (f32x4{0.f, 0.f, 0.f, 0.f}));
       }
     }
   } else {
@@ -70,7 +79,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
       ST4(m, i, tm);
       ST4(v, i, tv);
       if (pb) reinterpret_cast<bf16x4*>(pb)[i] = ob;
-      if (zero_g) ST4(g, i, (f32x4{0.f, 0.f, 0.f, 0.f}));      // optimizer.zero_grad() of the NEXT step
+      if (zero_vec(i)) ST4(g, i, (f32x4{0.f, 0.f, 0.f, 0.f}));      // optimizer.zero_grad() of the NEXT step
     }
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
@@ -339,8 +348,9 @@ inline int grid_for(int64_t work_items) { return (int)std::min<int64_t>(ceil_div
 
 }  // namespace
 
-extern "C" int ph_adamw(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, const float* hyper, float beta1,
-                        float beta2, float eps, float weight_decay, float grad_scale, int zero_grad, hipStream_t stream) {
+extern "C" int ph_adamw_keep(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, const float* hyper, float beta1,
+                             float beta2, float eps, float weight_decay, float grad_scale, int zero_grad, const uint32_t* keep_bitmap,
+                             hipStream_t stream) {
   PH_CHECK_ARG(p && g && m && v && hyper && n > 0, "ph_adamw: bad args");
   ProfScope prof__(PH_FAM_OPTIM, 0.0, 30.0 * (double)n, stream);
   PH_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && (((uintptr_t)p_bf16) & 7) == 0, "ph_adamw: misaligned");
@@ -349,9 +359,13 @@ extern "C" int ph_adamw(float* p, float* g, float* m, float* v, void* p_bf16, in
   int grid = grid_for(n / 4 + 1);
   if (blocks_cap > 0 && grid > blocks_cap) grid = blocks_cap;
   hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, stream, p, g, m, v, (bf16*)p_bf16, n, hyper, beta1, beta2, eps,
-                     weight_decay, grad_scale, zero_grad, mode);
+                     weight_decay, grad_scale, zero_grad, mode, keep_bitmap);
   PH_LAUNCH_CHECK("adamw_kernel");
   return PH_OK;
+}
+extern "C" int ph_adamw(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, const float* hyper, float beta1,
+                        float beta2, float eps, float weight_decay, float grad_scale, int zero_grad, hipStream_t stream) {
+  return ph_adamw_keep(p, g, m, v, p_bf16, n, hyper, beta1, beta2, eps, weight_decay, grad_scale, zero_grad, nullptr, stream);
 }
 extern "C" int ph_cast_f32_to_bf16(const float* x, void* y, int64_t n, hipStream_t stream) {
   PH_CHECK_ARG(x && y && n > 0 && (((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 7) == 0, "ph_cast_f32_to_bf16: bad args");

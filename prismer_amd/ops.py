@@ -2,6 +2,7 @@
 HIP stream; every arithmetic step runs in libprismer_hip.so.  No fallbacks: a missing library fails at import.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -145,9 +146,17 @@ class WgradQueue:
         self.ln_arena = None     # fp32 scratch the deferred LayerNorm backwards write their per-block partials into
         self.ln_off = 0
         self.ln_stream = None
+        # first-writer bookkeeping of a native training step (Trainer._wq_scope): `counts` (while not None) tallies the writes per
+        # output address of one whole step; `exclusive` = addresses written exactly once per step -> their GEMM overwrites
+        self.counts = None
+        self.exclusive = None
 
     def add_gemm(self, dy, x, gw, M, N, K):
         """gw[M, N] (fp32) += dy[K, M]^T . x[K, N]"""
+        if self.counts is not None:
+            key = gw.data_ptr()
+            c = self.counts.get(key, (0, 0, True))
+            self.counts[key] = (c[0] + 1, M * N, c[2] and gw.is_contiguous() and self.enabled)
         if not self.enabled:
             gemm(dy, x, out=gw, trans_a=True, trans_b=True, out_f32=True, accumulate=True, M=M, N=N, K=K)
             return
@@ -209,6 +218,8 @@ class WgradQueue:
         if not allq:
             return
 
+        excl = self.exclusive
+
         def work():
             i0 = 0
             while i0 < len(allq):                    # <= 16 problems per launch, no output twice in one launch
@@ -220,7 +231,10 @@ class WgradQueue:
                     g.A, g.B, g.C = dy.data_ptr(), x.data_ptr(), gw.data_ptr()
                     g.M, g.N, g.K = M, N, Kk
                     g.lda, g.ldb, g.ldc = dy.stride(0), x.stride(0), gw.stride(0)
-                    g.trans_a, g.trans_b, g.out_f32, g.accumulate, g.alpha = 1, 1, 1, 1, 1.0
+                    # single-writer outputs of the native step are OVERWRITTEN (no read of the zeroed buffer, and AdamW does not
+                    # have to zero it): self.exclusive is set by the Trainer for the duration of its own step only
+                    acc = 0 if (excl is not None and gw.data_ptr() in excl) else 1
+                    g.trans_a, g.trans_b, g.out_f32, g.accumulate, g.alpha = 1, 1, 1, acc, 1.0
                 check(lib.ph_gemm_grouped_capped_bf16(arr, len(q), max_blocks, _stream()), 'ph_gemm_grouped_capped_bf16')
         off_critical_path(work, *[t for e in allq for t in e[:3]])
 
@@ -623,9 +637,11 @@ def ce_bwd(logits, labels, B, T, V, eps, row_lse, dloss):
 
 # ---------------------------------------------------------------------------------------------- utilities
 
-def adamw(p, g, m, v, p_bf16, n, hyper, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.05, grad_scale=1.0, zero_grad=False):
-    check(lib.ph_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), ptr(p_bf16), n, hyper.data_ptr(), beta1, beta2, eps,
-                       weight_decay, grad_scale, int(zero_grad), _stream()), 'ph_adamw')
+def adamw(p, g, m, v, p_bf16, n, hyper, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.05, grad_scale=1.0, zero_grad=False, keep=None):
+    """keep: optional int32 tensor, bit c = gradients [1024 c, 1024 c + 1024) keep their values (see ph_adamw_keep)"""
+    assert keep is None or keep.numel() * 32 * 1024 >= n
+    check(lib.ph_adamw_keep(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), ptr(p_bf16), n, hyper.data_ptr(), beta1, beta2, eps,
+                            weight_decay, grad_scale, int(zero_grad), ptr(keep), _stream()), 'ph_adamw')
 
 
 def cast_to_bf16(x, out=None, scale=1.0):
