@@ -420,7 +420,8 @@ def _pinned_trainer(case, use_graph, lr=1e-3, **kw):
     m = _Holder(); m.expert_encoder, m.text_decoder = enc, dec
     x, ids, mask, labels, weights = case.inputs()
     tab = case.instance_table(x)
-    tr = Trainer(m, lr=lr, weight_decay=0.05, total_steps=10, use_graph=use_graph, keep_grads=True, **kw)
+    kw.setdefault('keep_grads', True)
+    tr = Trainer(m, lr=lr, weight_decay=0.05, total_steps=10, use_graph=use_graph, **kw)
     tr.set_batch(to_dev(x), ids, mask, labels, None if weights is None else weights.cuda())
     if tab is not None:
         orig = tr._host_prologue
@@ -547,6 +548,28 @@ def _hipgraph_step_vs_golden(name, force_big=False):
     loss2 = tr.step()
     torch.cuda.synchronize()
     assert np.isfinite(loss2.item()) and tr.it == 2
+
+
+def test_bench_gradient_handling_equals_the_pinned_one():
+    """bench.py runs keep_grads=False (AdamW zeroes the gradients except the single-writer ones, which their GEMM overwrites); the
+    reference-pinned tests above read gradients, i.e. run keep_grads=True (everything accumulates into a buffer filled at the start
+    of the step).  Same batch, same weights, three steps under hipGraph replay at Prismer-BASE B = 8: the two must walk the same
+    trajectory -- losses and parameters to the atomics noise of two runs."""
+    case = C.Case('base_b8')
+    res = []
+    for keep in (True, True, False):                            # the repeated run measures the run-to-run noise (fp32 atomics order, +-lr moves)
+        tr, m = _pinned_trainer(case, use_graph=True, lr=1e-4, keep_grads=keep)
+        losses = [tr.step().item() for _ in range(3)]
+        torch.cuda.synchronize()
+        assert (tr._exclusive is not None and len(tr._exclusive) > 50) or os.environ.get('PRISMER_WGRAD_OVERWRITE') == '0'
+        res.append((losses, [st.master[:st.n_train].clone() for st in tr.stores], [t.clone() for t in tr.m]))
+        del tr, m
+    (la, pa, ma), (ln, pn, mn), (lb, pb, mb) = res
+    assert math_close(la[0], lb[0], 1e-5), (la, lb)
+    assert math_close(la[1], lb[1], 1e-3) and math_close(la[2], lb[2], 2e-3), (la, lb)
+    for ta, tn, tb in zip(pa + ma, pn + mn, pb + mb):
+        noise = rel_fro(tn, ta)
+        assert rel_fro(tb, ta) < max(2.0 * noise, 1e-3), (rel_fro(tb, ta), noise)
 
 
 @pytest.mark.parametrize('keep_grads', [True, False])
