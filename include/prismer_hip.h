@@ -92,8 +92,17 @@ typedef struct {
    * rowmap_add  (the other row-indexed operands keep row m).  The data gradient of a stride-2 convolution is computed per parity
    * class of the input pixel: row m = (b, a, c) of class (py, px) is pixel (2a + py, 2c + px) = row 4m - 2(m % Wo) + py * W + px. */
   int rowmap_wo, rowmap_mul, rowmap_sub, rowmap_add;
+  /* round 3 -- defer_reduce != 0: when the call is split over K, the pass that folds the partial sums (and applies the epilogue) is
+   * not launched; it is queued and issued by ph_gemm_flush_deferred() together with those of the following deferred calls, <=
+   * PH_GEMM_GROUP_MAX per launch (the stems' 24 conv weight gradients of a step: 24 fold launches -> 4).  The partials of
+   * consecutive deferred calls are placed one after the other in `workspace` (pass the SAME workspace to all of them and to nothing
+   * else until the flush; a call that does not fit flushes first).  C is only valid after the flush.  One queue per process:
+   * deferred calls and their flush must come from one thread and one stream. */
+  int defer_reduce;
 } ph_gemm_args;
 int ph_gemm_bf16(const ph_gemm_args* args, hipStream_t stream);
+/* launches the queued fold passes of the deferred split-K GEMMs (no-op when nothing is queued) */
+int ph_gemm_flush_deferred(hipStream_t stream);
 
 /* Grouped GEMM: n <= PH_GEMM_GROUP_MAX independent problems with the SAME trans_a / trans_b in one launch (no split-K;
  * split_k / workspace fields are ignored).  Used for the weight gradients, which the reference's autograd emits as one

@@ -43,7 +43,7 @@ class GemmArgs(C.Structure):
                 ('out_f32', c_int), ('accumulate', c_int), ('alpha', c_float), ('split_k', c_int),
                 ('residual_f32', c_int), ('workspace', c_void_p), ('workspace_bytes', c_i64), ('pre_grad', c_int),
                 ('conv', C.POINTER(ConvGather)), ('col_stats', c_void_p),
-                ('rowmap_wo', c_int), ('rowmap_mul', c_int), ('rowmap_sub', c_int), ('rowmap_add', c_int)]
+                ('rowmap_wo', c_int), ('rowmap_mul', c_int), ('rowmap_sub', c_int), ('rowmap_add', c_int), ('defer_reduce', c_int)]
 
 
 class ConvDgradItem(C.Structure):
@@ -170,6 +170,7 @@ _SIGS = {
     'ph_gemm_grouped_bf16': (c_int, [c_void_p, c_int, c_void_p]),
     'ph_gemm_grouped_capped_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p]),
     'ph_gemm_tuning': (c_int, [c_int, c_int]),
+    'ph_gemm_flush_deferred': (c_int, [c_void_p]),
     'ph_gemm_dispatch_counts': (c_int, [c_void_p, c_int, c_int]),
     'ph_query_workspace': (c_i64, [c_int, c_void_p, c_int]),
     'ph_conv_dgrad_shadow_grouped': (c_int, [c_void_p, c_int, c_void_p]),

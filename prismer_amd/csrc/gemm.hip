@@ -21,6 +21,7 @@
 //   * split-K (grid.z): partial tiles to an fp32 workspace + splitk_reduce_kernel (which runs the same epilogue).
 //   * XCD-aware, grouped tile rasterisation (each XCD walks 8-row-panel groups, rows fastest).
 #include "gemm_common.h"
+#include <vector>
 
 using namespace phg;
 
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupParams g) {
 // 256 splits of a tiny output (the stems' first-layer weight gradients: 768 output vectors) one thread per vector walked 256
 // dependent loads (62 us for 3 blocks); 16 lanes per vector make it 16 loads and 48 blocks.
 template <int LANES>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int splits) {
+__device__ __forceinline__ void splitk_reduce_body(const GemmParams& p, const int splits, const int block, const int nblocks) {
   const int n4 = (p.N + 3) / 4;
   int64_t total = (int64_t)p.M * n4;
   DropCtx dc;
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
   if (drop) dc = make_drop(p.drop_seed, p.drop_stream, p.drop_p);
   const int sub = threadIdx.x % LANES;
   // (the LANES lanes of a group share `id`, hence their control flow: the shuffles below always see the whole group)
-  for (int64_t id = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LANES; id < total; id += (int64_t)gridDim.x * (256 / LANES)) {
+  for (int64_t id = ((int64_t)block * 256 + threadIdx.x) / LANES; id < total; id += (int64_t)nblocks * (256 / LANES)) {
     int m = (int)(id / n4), n = (int)(id % n4) * 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int s = sub; s < splits; s += LANES) acc += *reinterpret_cast<const f32x4*>(p.ws + ((size_t)s * p.M + m) * p.ldws + n);
@@ -284,6 +285,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int sp
       epilogue_store(p, m, n, v, false, drop, dc);
     }
   }
+}
+template <int LANES>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p, int splits) {
+  splitk_reduce_body<LANES>(p, splits, blockIdx.x, gridDim.x);
+}
+// the fold passes of several deferred split-K GEMMs in one grid (ph_gemm_args.defer_reduce / ph_gemm_flush_deferred)
+struct ReduceGroup {
+  int n;
+  int blk_start[PH_GEMM_GROUP_MAX + 1];
+  int splits[PH_GEMM_GROUP_MAX];
+  GemmParams p[PH_GEMM_GROUP_MAX];
+};
+template <int LANES>
+__global__ __launch_bounds__(256) void splitk_reduce_grouped_kernel(ReduceGroup g) {
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.blk_start[i + 1]) ++i;
+  splitk_reduce_body<LANES>(g.p[i], g.splits[i], (int)blockIdx.x - g.blk_start[i], g.blk_start[i + 1] - g.blk_start[i]);
 }
 
 // prefetch depth per tile size (VGPR budget: 128x128 tiles hold 32 staging VGPRs per slot, 64x64 tiles 16)
@@ -361,6 +379,50 @@ static int big_min_tiles_now() {
   int m = g_big_min_tiles.load(std::memory_order_relaxed);
   if (m < 0) { static const int dflt = env_int("PH_GEMM_BIG_MIN_TILES", 128); m = dflt; }
   return m;
+}
+
+// ---- deferred fold passes (ph_gemm_args.defer_reduce): one queue per process, see the header for the calling contract
+namespace {
+struct DeferredReduce { GemmParams p; int splits; bool wide; };    // wide: the 16-lanes-per-vector form
+std::mutex g_defer_mu;
+std::vector<DeferredReduce> g_defer;
+size_t g_defer_cursor = 0;              // bytes of the caller's workspace taken by the queued partial sums
+const void* g_defer_ws = nullptr;
+
+int reduce_blocks(const GemmParams& p, bool wide) {
+  const int64_t vecs = (int64_t)p.M * ((p.N + 3) / 4);
+  return (int)std::min<int64_t>(2048, ceil_div64(wide ? vecs * 16 : vecs, 256));
+}
+int flush_deferred_locked(hipStream_t stream) {
+  for (int wide = 0; wide < 2; ++wide) {
+    size_t i = 0;
+    while (true) {
+      ReduceGroup g;
+      g.n = 0; g.blk_start[0] = 0;
+      for (; i < g_defer.size() && g.n < PH_GEMM_GROUP_MAX; ++i) {
+        if ((int)g_defer[i].wide != wide) continue;
+        g.p[g.n] = g_defer[i].p; g.splits[g.n] = g_defer[i].splits;
+        g.blk_start[g.n + 1] = g.blk_start[g.n] + reduce_blocks(g_defer[i].p, wide != 0);
+        ++g.n;
+      }
+      if (g.n == 0) break;
+      count_launch(PH_GEMM_CLS_SPLITK_REDUCE);
+      if (wide) hipLaunchKernelGGL(splitk_reduce_grouped_kernel<16>, dim3(g.blk_start[g.n]), dim3(256), 0, stream, g);
+      else hipLaunchKernelGGL(splitk_reduce_grouped_kernel<1>, dim3(g.blk_start[g.n]), dim3(256), 0, stream, g);
+      PH_LAUNCH_CHECK("splitk_reduce_grouped_kernel");
+    }
+  }
+  g_defer.clear();
+  g_defer_cursor = 0;
+  g_defer_ws = nullptr;
+  return PH_OK;
+}
+}  // namespace
+
+extern "C" int ph_gemm_flush_deferred(hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_defer_mu);
+  if (g_defer.empty()) return PH_OK;
+  return flush_deferred_locked(stream);
 }
 
 extern "C" int ph_gemm_tuning(int big_mode, int big_min_tiles) {
@@ -677,9 +739,24 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
   p.k_tiles_per_split = ceil_div(kt, splits);
   splits = ceil_div(kt, p.k_tiles_per_split);
   p.ws = nullptr; p.ldws = ldws;
+  bool deferred = false;
   if (splits > 1) {
-    if (ws_fits(splits)) p.ws = (float*)a->workspace;
-    else PH_CHECK_ARG(plain_acc, "ph_gemm_bf16: split_k > 1 without workspace needs out_f32 + accumulate and no fused epilogue");
+    if (ws_fits(splits)) {
+      p.ws = (float*)a->workspace;
+      if (a->defer_reduce) {              // partial sums of consecutive deferred calls sit one after the other in the caller's workspace
+        std::lock_guard<std::mutex> lock(g_defer_mu);
+        const size_t need = ((size_t)splits * a->M * ldws * 4 + 255) / 256 * 256;
+        if (g_defer.empty()) g_defer_cursor = 0;
+        if (!g_defer.empty() && (g_defer_ws != a->workspace || g_defer_cursor + need > (size_t)a->workspace_bytes)) {
+          int rcf = flush_deferred_locked(stream);
+          if (rcf != PH_OK) return rcf;
+        }
+        p.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(a->workspace) + g_defer_cursor);
+        g_defer_cursor += need;
+        g_defer_ws = a->workspace;
+        deferred = true;
+      }
+    } else PH_CHECK_ARG(plain_acc, "ph_gemm_bf16: split_k > 1 without workspace needs out_f32 + accumulate and no fused epilogue");
   }
   {
     // 64x64-tile launches that leave CUs with a single block (the decoder's M = 960 rows): split the k loop inside the block instead
@@ -698,6 +775,11 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
                       : dispatch_layout<128, 128>(p, a->trans_a, a->trans_b, splits, stream);
   if (rc != PH_OK || !p.ws) return rc;
   const int64_t vecs = (int64_t)a->M * ((a->N + 3) / 4);
+  if (deferred) {                                         // the fold pass joins the queue (the partials stay where they are until the flush)
+    std::lock_guard<std::mutex> lock(g_defer_mu);
+    g_defer.push_back(DeferredReduce{p, splits, splits >= 32 && vecs <= 16384});
+    return PH_OK;
+  }
   count_launch(PH_GEMM_CLS_SPLITK_REDUCE);
   if (splits >= 32 && vecs <= 16384) {                    // many splits of a small output: 16 lanes per output vector
     int grid = (int)min((int64_t)2048, ceil_div64(vecs * 16, 256));

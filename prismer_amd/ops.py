@@ -31,10 +31,11 @@ _WS = {}
 WS_BYTES = 256 << 20
 
 
-def _workspace(device):
+def _workspace(device, which=0):
     """per-(device, stream) fp32 scratch for split-K partial tiles / LayerNorm partials: kernels on one stream are
-    serialised, so one buffer per stream is race-free (allocated once, reused by every launch on that stream)"""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    serialised, so one buffer per stream is race-free (allocated once, reused by every launch on that stream).
+    which = 1: the separate buffer that holds the partial sums of DEFERRED fold passes until gemm_flush_deferred()"""
+    key = (device, torch.cuda.current_stream(device).cuda_stream, which)
     ws = _WS.get(key)
     if ws is None:
         ws = torch.empty(WS_BYTES // 4, dtype=F32, device=device)
@@ -279,7 +280,7 @@ def wait_side():
 
 def gemm(a, b, out=None, *, trans_a=False, trans_b=False, bias=None, act=ACT_NONE, pre_out=None, act_in=None,
          residual=None, drop=None, out_f32=False, accumulate=False, alpha=1.0, split_k=0, M=None, N=None, K=None, pre_grad=False,
-         conv=None, col_stats=None):
+         conv=None, col_stats=None, defer_reduce=False):
     """out[M,N] = epi(alpha * opA . opB^T).  a: [M,K] (or [K,M] if trans_a), b: [N,K] (or [K,N] if trans_b)."""
     if M is None:
         M = a.shape[1] if trans_a else a.shape[0]
@@ -317,10 +318,16 @@ def gemm(a, b, out=None, *, trans_a=False, trans_b=False, bias=None, act=ACT_NON
     else:
         g.drop_p, g.drop_seed, g.drop_stream = 0.0, None, 0
     g.out_f32, g.accumulate, g.alpha, g.split_k = int(out_f32), int(accumulate), float(alpha), int(split_k)
-    ws = _workspace(a.device)
-    g.workspace, g.workspace_bytes = ws.data_ptr(), WS_BYTES
+    # defer_reduce: a split-K call leaves its fold pass to gemm_flush_deferred() (one grouped launch for up to 16 of them); the partial
+    # sums of the queued calls live in their own workspace, which nothing else uses
+    ws = _workspace(a.device, 1 if defer_reduce else 0)
+    g.workspace, g.workspace_bytes, g.defer_reduce = ws.data_ptr(), WS_BYTES, int(defer_reduce)
     check(lib.ph_gemm_bf16(C.byref(g), _stream()), 'ph_gemm_bf16')
     return out
+
+
+def gemm_flush_deferred():
+    check(lib.ph_gemm_flush_deferred(_stream()), 'ph_gemm_flush_deferred')
 
 
 def layernorm_fwd(x, gamma, beta, eps=1e-5, out=None, out_map=IDENT, out2=None, out2_map=IDENT, save_stats=True, out_f32=None):

@@ -22,6 +22,7 @@ from ..config import LABEL_DOMAINS
 # data gradients of the stems' 3x3 convolutions: implicit GEMMs gathered from dY (round 3) instead of dcol = dY . W + col2im
 # (PRISMER_IMPLICIT_DGRAD=0: the round-2 path, kept as the A/B reference)
 IMPLICIT_DGRAD = os.environ.get('PRISMER_IMPLICIT_DGRAD', '1') != '0'
+DEFER_REDUCE = os.environ.get('PRISMER_DEFER_REDUCE', '1') != '0'       # stems: the conv weight gradients' split-K fold passes, grouped per layer
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -366,9 +367,10 @@ class EncoderProgram:
                 if g is not None:
                     if C % 8 == 0:                                 # implicit-GEMM weight gradient: the im2col view sits on the reduction side
                         ds = ops.gemm(dy, s['a_in'][i].view(-1, C), trans_a=True, trans_b=True, out_f32=True, M=Co, N=Kp, K=dy.shape[0],
-                                      conv=(s['B'], H, H, C, 3, stride))
+                                      conv=(s['B'], H, H, C, 3, stride), defer_reduce=DEFER_REDUCE)
                     else:
-                        ds = ops.gemm(dy, s['col0'], trans_a=True, trans_b=True, out_f32=True, M=Co, N=Kp, K=dy.shape[0])
+                        ds = ops.gemm(dy, s['col0'], trans_a=True, trans_b=True, out_f32=True, M=Co, N=Kp, K=dy.shape[0],
+                                      defer_reduce=DEFER_REDUCE)
                     ops.WQ.add_conv_fold(ds, g, Co, C, 3, Kp)
                 if i > 0:
                     if IMPLICIT_DGRAD:
@@ -380,6 +382,8 @@ class EncoderProgram:
                         dcol = torch.empty(dy.shape[0], Kp, dtype=BF16, device=dev)
                         dcol_probs.append((dy, shadow, dcol, dy.shape[0], Kp, Co))
                         dcols.append(dcol)
+            if DEFER_REDUCE:
+                ops.gemm_flush_deferred()                        # the split-K fold passes of this layer's weight gradients: one grouped launch
             if i > 0 and IMPLICIT_DGRAD:
                 ops.conv_dgrad_grouped(dcol_probs)               # data gradients gathered from dY (no dcol matrix, no col2im pass)
                 das = dcols

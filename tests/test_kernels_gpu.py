@@ -264,6 +264,32 @@ def test_gemm_f32_accumulate_splitk(ops):
         assert rel_fro(c2, ref2) < 3e-4, (split, rel_fro(c2, ref2))
 
 
+def test_gemm_deferred_fold_passes_match_immediate(ops):
+    """defer_reduce: the fold passes of several split-K GEMMs are queued and run as ONE grouped launch per flush (both fold forms:
+    one thread per output vector, 16 lanes per vector for many splits of a small output); results bit-identical to the immediate
+    path (same partial sums, same summation order), the queue survives a workspace wrap-around, an unsplit call is unaffected."""
+    cases = [(768, 768, 4160, 7), (96, 32, 100352, 64), (192, 864, 25088, 0), (96, 32, 100352, 256), (384, 1728, 6272, 0)]
+    ops_in = [(rnd(K, M, scale=0.3, seed=20 + i), rnd(K, N, scale=0.3, seed=40 + i)) for i, (M, N, K, _) in enumerate(cases)]
+    want = [ops.gemm(dy, x, trans_a=True, trans_b=True, out_f32=True, split_k=sp) for (dy, x), (_, _, _, sp) in zip(ops_in, cases)]
+    got = [ops.gemm(dy, x, trans_a=True, trans_b=True, out_f32=True, split_k=sp, defer_reduce=True) for (dy, x), (_, _, _, sp) in zip(ops_in, cases)]
+    small = ops.gemm(rnd(64, 64, seed=1), rnd(64, 64, seed=2), defer_reduce=True)          # no split: nothing queued for it
+    ops.gemm_flush_deferred()
+    ops.gemm_flush_deferred()                                                              # empty queue: no-op
+    torch.cuda.synchronize()
+    for w, g in zip(want, got):
+        assert torch.equal(w, g)
+    assert rel_fro(small, rnd(64, 64, seed=1).float() @ rnd(64, 64, seed=2).float().t()) < 6e-3
+    # more partial sums than the workspace holds: the queue flushes itself in between
+    M, N, K = 768, 3456, 6272
+    dy, x = rnd(K, M, scale=0.3, seed=77), rnd(K, N, scale=0.3, seed=78)
+    ref = ops.gemm(dy, x, trans_a=True, trans_b=True, out_f32=True, split_k=12)
+    outs = [ops.gemm(dy, x, trans_a=True, trans_b=True, out_f32=True, split_k=12, defer_reduce=True) for _ in range(4)]   # 4 x 127 MB > 256 MB
+    ops.gemm_flush_deferred()
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, ref)
+
+
 @pytest.mark.parametrize('shapes', [
     [(768, 768, 960), (2304, 768, 960), (384, 768, 960), (768, 3072, 960), (3072, 768, 960)],      # one decoder layer: 128x128 tiles
     [(384, 768, 1984), (768, 384, 1984), (100, 200, 1984)],                                        # few tiles: 64x64 path, ragged edge
