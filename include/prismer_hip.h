@@ -104,8 +104,10 @@ int ph_gemm_bf16(const ph_gemm_args* args, hipStream_t stream);
 /* launches the queued fold passes of the deferred split-K GEMMs (no-op when nothing is queued) */
 int ph_gemm_flush_deferred(hipStream_t stream);
 
-/* Grouped GEMM: n <= PH_GEMM_GROUP_MAX independent problems with the SAME trans_a / trans_b in one launch (no split-K;
- * split_k / workspace fields are ignored).  Used for the weight gradients, which the reference's autograd emits as one
+/* Grouped GEMM: n <= PH_GEMM_GROUP_MAX independent problems with the SAME trans_a / trans_b in one launch (split_k is ignored;
+ * round 3: a [K,M] x [K,N] group of plain fp32-output problems that all carry the same `workspace` and covers less than half of the
+ * chip's block slots is ALSO split over K -- partial sums in the workspace, one grouped fold pass right behind the launch;
+ * without a workspace there is no split).  Used for the weight gradients, which the reference's autograd emits as one
  * small GEMM per nn.Linear (dW = dY^T X, e.g. model/modules/roberta.py:79-183 has nine per decoder layer): their outputs
  * cover 18..144 tiles each, far fewer than the chip holds, so the host side defers them and issues each layer's set at once. */
 #define PH_GEMM_GROUP_MAX 16

@@ -30,13 +30,14 @@ namespace {
 
 // One output tile over the k-tiles [kt_begin, kt_end).  XCD_REMAP: block_id is a hardware block index of a one-tile-per-block launch
 // (re-mapped so that each XCD owns a contiguous run of tiles); otherwise block_id already is the tile index.  splitk: the tile has
-// other contributors (raw partial sums: workspace slice blockIdx.z, or fp32 atomics into C when there is no workspace).
+// other contributors (raw partial sums: workspace slice split_id, or fp32 atomics into C when there is no workspace).
 // KS = 2: intra-block split of the k loop (512 threads): thread group g = threadIdx.x >> 8 multiplies the k-tiles kt_begin + 2i + g
 // in its own pair of LDS stage buffers, the write-out sums the two partial tiles.  For the decoder's launches (M = B*T = 960 rows:
 // fewer tiles than CUs, so one block per CU and one wave per SIMD) the k loop is a latency chain -- LDS write, barrier, LDS read,
 // 4 MFMAs per wave -- and a second wave per SIMD working on the other half of K hides half of it.
 template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0, bool XCD_REMAP = true, int KS = 1>
-__device__ __forceinline__ void gemm_tile(const GemmParams& p, const int block_id, const int kt_begin, const int kt_end, const bool splitk) {
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, const int block_id, const int kt_begin, const int kt_end, const bool splitk,
+                                          const int split_id = 0) {
   static_assert(KS == 1 || (KS == 2 && CONV == 0 && PF > 1), "intra-block k split: plain ring kernels only");
   static_assert(CONV == 0 || (CONV == 1 && !TA && !TB) || (CONV == 2 && TA && TB), "conv gather: A of an NN problem or B of a TT problem");
   constexpr int WM = BM / 2, WN = BN / 2;   // wave tile
@@ -222,7 +223,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int block_i
     static_assert(2 * BM * BN * 4 <= 4 * STAGE, "two parked fp32 tiles must fit the four stage buffers");
     tile_writeout<BM, BN, 512>(p, reinterpret_cast<float*>(smem), m0, n0, splitk, drop, dc, reinterpret_cast<float*>(smem) + BM * BN);
   } else {
-    tile_writeout<BM, BN, 256>(p, cl, m0, n0, splitk, drop, dc);
+    tile_writeout<BM, BN, 256>(p, cl, m0, n0, splitk, drop, dc, nullptr, split_id);
     if (p.col_stats) tile_colstats<BM, BN, 256>(p, cl, m0, n0);
   }
 }
@@ -231,7 +232,7 @@ template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, const int block_id, const int split_id, const int nsplits) {
   const int kt_begin = split_id * p.k_tiles_per_split;
   const int kt_end = min(kt_begin + p.k_tiles_per_split, (p.K + BK - 1) / BK);
-  gemm_tile<BM, BN, TA, TB, PF, CONV, true>(p, block_id, kt_begin, kt_end, nsplits > 1);
+  gemm_tile<BM, BN, TA, TB, PF, CONV, true>(p, block_id, kt_begin, kt_end, nsplits > 1, split_id);
 }
 
 template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0>
@@ -249,7 +250,13 @@ __global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupParams g) {
   int i = 0;
   for (int t = blockIdx.x; t < total; t += gridDim.x) {
     while (i + 1 < g.n && t >= g.tile_start[i + 1]) ++i;
-    gemm_body<BM, BN, TA, TB, PF, CONV>(g.p[i], t - g.tile_start[i], 0, 1);
+    const int local = t - g.tile_start[i], ns = g.nsplit[i];
+    if (ns > 1) {                        // grouped AND split over K (long reductions with few output tiles): partial sums -> workspace
+      const int ntile = g.p[i].tiles_m * g.p[i].tiles_n;
+      gemm_body<BM, BN, TA, TB, PF, CONV>(g.p[i], local % ntile, local / ntile, ns);
+    } else {
+      gemm_body<BM, BN, TA, TB, PF, CONV>(g.p[i], local, 0, 1);
+    }
     __syncthreads();                     // the epilogue's LDS staging area is the next tile's stage buffer
   }
 }
@@ -547,9 +554,71 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
     g.p[i].tiles_m = ceil_div(args[i].M, BMsel); g.p[i].tiles_n = ceil_div(args[i].N, BMsel);
     g.p[i].k_tiles_per_split = ceil_div(args[i].K, BK);
     g.tile_start[i] = total;
+    g.nsplit[i] = 1;
     total += g.p[i].tiles_m * g.p[i].tiles_n;
   }
   g.tile_start[n] = total;
+  // ---- grouped AND split over K (round 3): weight-gradient groups with few output tiles and very long reductions -- the stems' conv
+  // weight gradients, 6 experts x (2..42 tiles over up to 6272 k-tiles).  As single launches each of them split K on its own (28-92 us
+  // per launch at 5-60 % fill, 28 launches per step); here every problem is cut into pieces of ~W/slots k-tiles so that the whole
+  // group fills the chip once, partial sums go to the caller's workspace and ONE grouped pass folds them (plain fp32 epilogues only).
+  {
+    static const int grp_split = env_int("PH_GEMM_GROUP_SPLIT", 1);
+    const ph_gemm_args& a0 = args[0];
+    bool ok = grp_split && max_blocks == 0 && a0.trans_a && a0.trans_b && a0.workspace && a0.workspace_bytes > 0;
+    double W = 0.0;
+    for (int i = 0; i < n && ok; ++i) {
+      const ph_gemm_args& a = args[i];
+      ok = a.out_f32 && !a.bias && a.act == PH_ACT_NONE && !a.pre_out && !a.act_in && !a.residual && !(a.drop_p > 0.f) && !a.col_stats &&
+           a.rowmap_wo == 0 && a.workspace == a0.workspace;
+      W += (double)g.p[i].tiles_m * g.p[i].tiles_n * ceil_div(a.K, BK);
+    }
+    const double slots = BMsel == 128 ? 512.0 : 1024.0;
+    if (ok && total * 2 <= slots) {
+      const int L = std::max(8, (int)ceil(W / slots));            // k-tiles per block
+      int blocks = 0, nsp[PH_GEMM_GROUP_MAX];
+      size_t off = 0, offs[PH_GEMM_GROUP_MAX];
+      bool any = false;
+      for (int i = 0; i < n; ++i) {
+        const int kti = ceil_div(args[i].K, BK);
+        int ns = std::min(ceil_div(kti, L), std::max(1, kti / 4));
+        const int per = ceil_div(kti, std::max(1, ns));
+        ns = ceil_div(kti, per);
+        nsp[i] = ns; offs[i] = off;
+        if (ns > 1) { any = true; off += ((size_t)ns * args[i].M * ((args[i].N + 3) / 4 * 4) * 4 + 255) / 256 * 256; }
+        blocks += g.p[i].tiles_m * g.p[i].tiles_n * ns;
+      }
+      if (any && off <= (size_t)a0.workspace_bytes) {
+        int tot = 0;
+        for (int i = 0; i < n; ++i) {
+          const int kti = ceil_div(args[i].K, BK);
+          g.nsplit[i] = nsp[i];
+          g.p[i].k_tiles_per_split = ceil_div(kti, nsp[i]);
+          g.p[i].ldws = (args[i].N + 3) / 4 * 4;
+          g.p[i].ws = nsp[i] > 1 ? reinterpret_cast<float*>(reinterpret_cast<char*>(a0.workspace) + offs[i]) : nullptr;
+          g.tile_start[i] = tot;
+          tot += g.p[i].tiles_m * g.p[i].tiles_n * nsp[i];
+        }
+        g.tile_start[n] = tot;
+        int rc;
+        if (conv) rc = BMsel == 128 ? launch_grouped<128, true, true, 1, 2>(g, tot, 0, stream) : launch_grouped<64, true, true, 1, 2>(g, tot, 0, stream);
+        else rc = BMsel == 128 ? launch_grouped_layout<128, 1>(g, tot, 0, 1, 1, stream) : launch_grouped_layout<64, 1>(g, tot, 0, 1, 1, stream);
+        if (rc != PH_OK) return rc;
+        ReduceGroup r;
+        r.n = 0; r.blk_start[0] = 0;
+        for (int i = 0; i < n; ++i) {
+          if (nsp[i] <= 1) continue;
+          r.p[r.n] = g.p[i]; r.splits[r.n] = nsp[i];
+          r.blk_start[r.n + 1] = r.blk_start[r.n] + reduce_blocks(g.p[i], false);
+          ++r.n;
+        }
+        count_launch(PH_GEMM_CLS_SPLITK_REDUCE);
+        hipLaunchKernelGGL(splitk_reduce_grouped_kernel<1>, dim3(r.blk_start[r.n]), dim3(256), 0, stream, r);
+        PH_LAUNCH_CHECK("splitk_reduce_grouped_kernel");
+        return PH_OK;
+      }
+    }
+  }
   // ---- weight-gradient groups with long reductions: the 256x128 ping-pong kernel, one persistent block per CU ----
   {
     static const int big_grp = env_int("PH_GEMM_BIG_GROUPED", 1);   // 0: keep every group on the 128x128 / 64x64 grouped kernel

@@ -248,10 +248,10 @@ __device__ __forceinline__ bf16x8 frag_ks_dma(const char* lds, int rbase, int kk
 
 // one lane's 4 consecutive outputs C[m][n..n+3]
 __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n, float (&v)[4], bool splitk, bool drop,
-                                               const DropCtx& dc) {
+                                               const DropCtx& dc, int split_id = 0) {
   const bool full = (n + 4 <= p.N);
   if (splitk && p.ws) {   // split-K with workspace: raw partial sums, the full epilogue runs in splitk_reduce_kernel
-    float* c = p.ws + ((size_t)blockIdx.z * p.M + m) * p.ldws + n;
+    float* c = p.ws + ((size_t)split_id * p.M + m) * p.ldws + n;
     f32x4 t = {v[0], v[1], v[2], v[3]};
     *reinterpret_cast<f32x4*>(c) = t;      // ldws % 4 == 0 and n % 4 == 0: always a full, aligned vector (pad columns are scratch)
     return;
@@ -413,7 +413,7 @@ __device__ __forceinline__ void epi_apply8(const GemmParams& p, int m, int n, fl
 // consecutive 16/32-B pieces of one output row for every load / store of the fused epilogue chain.
 template <int BM, int BN, int NTHR, int GCAP = 4>      // GCAP: cap on the prefetch group (register budget of the caller)
 __device__ __forceinline__ void tile_writeout(const GemmParams& p, const float* cl, int m0, int n0, bool splitk, bool drop,
-                                              const DropCtx& dc, const float* cl2 = nullptr) {   // cl2: second partial tile to add (KS = 2)
+                                              const DropCtx& dc, const float* cl2 = nullptr, int split_id = 0) {   // cl2: second partial tile to add (KS = 2); split_id: workspace slice of a split-K block
   constexpr int CH = BN / 4;                       // 16-B chunks per tile row
   // fast path: 8 outputs per thread per step (16-B loads/stores) when every leading dimension / pointer allows it
   const bool vec8 = !(splitk) && p.N >= 8 && (p.ldc % 8) == 0 && (!p.act_in || (p.ld_act % 8) == 0) && (!p.residual || (p.ldr % 8) == 0) &&
@@ -467,7 +467,7 @@ __device__ __forceinline__ void tile_writeout(const GemmParams& p, const float* 
       f32x4 t = *reinterpret_cast<const f32x4*>(cl + ml * BN + ((c ^ (ml & (CH - 1))) << 2));
       if (cl2) t += *reinterpret_cast<const f32x4*>(cl2 + ml * BN + ((c ^ (ml & (CH - 1))) << 2));
       float v[4] = {t[0], t[1], t[2], t[3]};
-      if (m < p.M && n < p.N) epilogue_store(p, m, n, v, splitk, drop, dc);
+      if (m < p.M && n < p.N) epilogue_store(p, m, n, v, splitk, drop, dc, split_id);
     }
   }
 }
@@ -502,7 +502,8 @@ __device__ __forceinline__ void tile_colstats(const GemmParams& p, const float* 
 // below the 512 block slots of the chip) are issued this way instead of one under-filled launch + split-K reduce apiece.
 struct GroupParams {
   int n;
-  int tile_start[PH_GEMM_GROUP_MAX + 1];
+  int tile_start[PH_GEMM_GROUP_MAX + 1];   // first block of problem i (blocks of a problem = tiles x nsplit)
+  int nsplit[PH_GEMM_GROUP_MAX];           // k splits of problem i (1 = none): block b of the problem is tile b % tiles, split b / tiles
   GemmParams p[PH_GEMM_GROUP_MAX];
 };
 

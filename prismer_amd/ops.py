@@ -485,6 +485,37 @@ def conv_fwd_grouped(items):
         check(lib.ph_gemm_grouped_bf16(arr, len(part), _stream()), 'ph_gemm_grouped_bf16 (conv)')
 
 
+def wgrad_split_grouped(items):
+    """Weight gradients with few output tiles and very long reductions -- the same conv layer of several expert stems -- in ONE grouped
+    launch that is also split over K, plus one grouped fold pass (include/prismer_hip.h: ph_gemm_grouped_bf16 with a workspace).
+    items: [(dy [K, M] bf16, x, M, N, K, conv)]: out[M, N] (fp32, returned) = dy^T . x with x = [K, N] bf16 (conv None) or the im2col
+    view of the NHWC activation x (conv = (B, H, W, C, ks, stride): the gathered operand sits on the reduction side).
+    Implicit and plain problems cannot share a launch, so they are grouped separately."""
+    outs = [None] * len(items)
+    for want_conv in (True, False):
+        idx = [i for i, it in enumerate(items) if (it[5] is not None) == want_conv]
+        for i0 in range(0, len(idx), _lib.GEMM_GROUP_MAX):
+            part = idx[i0:i0 + _lib.GEMM_GROUP_MAX]
+            arr = (_lib.GemmArgs * len(part))()
+            keep = []
+            ws = _workspace(items[part[0]][0].device, 1)
+            for g, i in zip(arr, part):
+                dy, x, M, N, K, conv = items[i]
+                out = torch.empty((M, N), dtype=F32, device=dy.device)
+                outs[i] = out
+                g.A, g.B, g.C = dy.data_ptr(), x.data_ptr(), out.data_ptr()
+                g.M, g.N, g.K = M, N, K
+                g.lda, g.ldb, g.ldc = dy.stride(0), (N if conv is not None else x.stride(0)), out.stride(0)
+                g.trans_a, g.trans_b, g.out_f32, g.alpha = 1, 1, 1, 1.0
+                if conv is not None:
+                    cg = _lib.ConvGather(*conv)
+                    g.conv = C.pointer(cg)
+                    keep.append(cg)
+                g.workspace, g.workspace_bytes = ws.data_ptr(), WS_BYTES
+            check(lib.ph_gemm_grouped_bf16(arr, len(part), _stream()), 'ph_gemm_grouped_bf16 (split wgrad)')
+    return outs
+
+
 def conv_out_size(H, ks, stride):
     pad = ks // 2
     return (H + 2 * pad - ks) // stride + 1

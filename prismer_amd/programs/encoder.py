@@ -22,6 +22,10 @@ from ..config import LABEL_DOMAINS
 # data gradients of the stems' 3x3 convolutions: implicit GEMMs gathered from dY (round 3) instead of dcol = dY . W + col2im
 # (PRISMER_IMPLICIT_DGRAD=0: the round-2 path, kept as the A/B reference)
 IMPLICIT_DGRAD = os.environ.get('PRISMER_IMPLICIT_DGRAD', '1') != '0'
+# stems: one grouped, K-split launch per layer for the conv weight gradients (ops.wgrad_split_grouped).  Built and measured in round 3: 43
+# launches fewer per step, step time +0.05 ms in two same-box pairs (25.53 / 25.60 -> 25.57 / 25.66 ms) -- every single launch already
+# split K far enough to fill the chip, so only their fixed cost was at stake.  Off by default.
+GROUP_WGRAD = os.environ.get('PRISMER_GROUP_WGRAD', '0') != '0'
 DEFER_REDUCE = os.environ.get('PRISMER_DEFER_REDUCE', '1') != '0'       # stems: the conv weight gradients' split-K fold passes, grouped per layer
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -359,10 +363,25 @@ class EncoderProgram:
                 dys.append(dy)
             ops.bn_relu_bwd_grouped(bn_items)
             dcol_probs, dcols = [], []
+            if GROUP_WGRAD:                                        # all experts' weight gradients of this layer: one grouped, K-split launch + one fold
+                witems, wmeta = [], []
+                for dom, s, dy in zip(doms, S, dys):
+                    H, C, stride, Kp = s['geo'][i]
+                    wname = f'conv1.{dom}.{1 + 3 * i}.weight'
+                    if P.g(wname) is None:
+                        continue
+                    Co = P.shape[wname][0]
+                    if C % 8 == 0:
+                        witems.append((dy, s['a_in'][i].view(-1, C), Co, Kp, dy.shape[0], (s['B'], H, H, C, 3, stride)))
+                    else:
+                        witems.append((dy, s['col0'], Co, Kp, dy.shape[0], None))
+                    wmeta.append((P.g(wname), Co, C, Kp))
+                for ds, (gw, Co, C, Kp) in zip(ops.wgrad_split_grouped(witems), wmeta):
+                    ops.WQ.add_conv_fold(ds, gw, Co, C, 3, Kp)
             for dom, s, dy in zip(doms, S, dys):
                 H, C, stride, Kp = s['geo'][i]
                 wname = f'conv1.{dom}.{1 + 3 * i}.weight'
-                g = P.g(wname)
+                g = P.g(wname) if not GROUP_WGRAD else None
                 Co = P.shape[wname][0]
                 if g is not None:
                     if C % 8 == 0:                                 # implicit-GEMM weight gradient: the im2col view sits on the reduction side

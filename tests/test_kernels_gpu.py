@@ -264,6 +264,35 @@ def test_gemm_f32_accumulate_splitk(ops):
         assert rel_fro(c2, ref2) < 3e-4, (split, rel_fro(c2, ref2))
 
 
+def test_wgrad_groups_split_over_k_match_single_launches(ops):
+    """ops.wgrad_split_grouped: conv (implicit, im2col view on the reduction side) and plain weight gradients with few output tiles and
+    long reductions, one grouped + K-split launch and one grouped fold per kind; against the single-launch path (which is pinned
+    against F.conv2d autograd above) and against fp32 torch for the plain ones."""
+    torch.manual_seed(5)
+    items, want = [], []
+    for (B, H, Cc, Co, stride) in ((8, 56, 96, 192, 2), (8, 28, 192, 384, 2), (8, 56, 96, 96, 1), (4, 28, 192, 192, 1)):
+        Ho = (H + 2 - 3) // stride + 1
+        x = rnd(B * H * H, Cc, scale=0.5, seed=H + Cc)
+        dy = rnd(B * Ho * Ho, Co, scale=0.3, seed=H + Co + 1)
+        Kp = 9 * Cc
+        items.append((dy, x, Co, Kp, dy.shape[0], (B, H, H, Cc, 3, stride)))
+        want.append(ops.gemm(dy, x, trans_a=True, trans_b=True, out_f32=True, M=Co, N=Kp, K=dy.shape[0], conv=(B, H, H, Cc, 3, stride)))
+    for (M, N, K) in ((96, 32, 50176), (96, 32, 25088), (48, 64, 12544)):
+        dy, x = rnd(K, M, scale=0.3, seed=K % 97), rnd(K, N, scale=0.3, seed=K % 89)
+        items.append((dy, x, M, N, K, None))
+        want.append(dy.float().t() @ x.float())
+    from prismer_amd import _lib
+    import ctypes
+    cnt = (ctypes.c_int64 * 16)()
+    _lib.lib.ph_gemm_dispatch_counts(cnt, 16, 1)
+    got = ops.wgrad_split_grouped(items)
+    torch.cuda.synchronize()
+    _lib.lib.ph_gemm_dispatch_counts(cnt, 16, 0)
+    assert cnt[5] == 2 and cnt[6] == 2, list(cnt)[:7]            # two grouped GEMM launches, two grouped fold passes
+    for w, g, it in zip(want, got, items):
+        assert rel_fro(g, w) < 3e-4, (it[2:5], rel_fro(g, w))
+
+
 def test_gemm_deferred_fold_passes_match_immediate(ops):
     """defer_reduce: the fold passes of several split-K GEMMs are queued and run as ONE grouped launch per flush (both fold forms:
     one thread per output vector, 16 lanes per vector for many splits of a small output); results bit-identical to the immediate
