@@ -30,7 +30,9 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define PH_VERSION 100
+/* ABI revision: bumped whenever an argument struct or a signature changes (101: ph_conv_gather window fields, ph_gemm_args row map +
+ * defer_reduce; 102: round 4).  A host built against another revision must refuse to run: ph_version() != PH_VERSION. */
+#define PH_VERSION 102
 
 enum { PH_OK = 0, PH_ERR_BAD_ARG = -1, PH_ERR_UNSUPPORTED = -2, PH_ERR_LAUNCH = -3 };
 enum { PH_ACT_NONE = 0, PH_ACT_QUICKGELU = 1, PH_ACT_RELU2 = 2, PH_ACT_GELU = 3, PH_ACT_RELU = 4,

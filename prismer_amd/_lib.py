@@ -206,6 +206,10 @@ def _load():
 
 
 lib, LIB_PATH = _load()
+ABI_VERSION = 102          # PH_VERSION of include/prismer_hip.h these ctypes structures mirror
+if lib.ph_version() != ABI_VERSION:
+    raise ImportError(f'{LIB_PATH} reports ABI revision {lib.ph_version()}, this binding was written for {ABI_VERSION} '
+                      '(stale build? run `python -m prismer_amd.build --force`)')
 
 
 class PrismerHipError(RuntimeError):

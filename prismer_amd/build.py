@@ -28,6 +28,30 @@ def _digest():
     return h.hexdigest()
 
 
+def build_comm():
+    """libprismer_comm.so alone (host code, one file).  Optional: a box without <rccl/rccl.h> still gets the compute library; the
+    failure is remembered in comm.failed so that later callers raise at once instead of recompiling.  Written to a temporary name and
+    renamed, so concurrent ranks never see (or load) a half-written file."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    failed = os.path.join(LIBDIR, 'comm.failed')
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    tmp = f'{COMM_LIB}.{os.getpid()}.tmp'
+    r = subprocess.run([hipcc, '-O2', '-std=c++17', '-fPIC', '-shared', '-I/opt/rocm/include', os.path.join(CSRC, 'comm.cpp'), '-o', tmp,
+                        '-ldl'], capture_output=True, text=True)
+    if r.returncode != 0:
+        import warnings
+        warnings.warn('libprismer_comm.so (native RCCL gradient exchange) was not built: ' + r.stderr[-500:])
+        open(failed, 'w').write(r.stderr[-2000:])
+        for f in (tmp, COMM_LIB):
+            if os.path.isfile(f):
+                os.remove(f)
+        return None
+    os.replace(tmp, COMM_LIB)
+    if os.path.isfile(failed):
+        os.remove(failed)
+    return COMM_LIB
+
+
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     stamp = os.path.join(LIBDIR, 'build.stamp')
@@ -50,14 +74,7 @@ def build(force=False, verbose=True):
     r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n' + r.stderr[-4000:])
-    # the RCCL transport is optional (transport='native' of the Trainer): a box without <rccl/rccl.h> still gets the compute library
-    r = subprocess.run([hipcc, '-O2', '-std=c++17', '-fPIC', '-shared', '-I/opt/rocm/include', os.path.join(CSRC, 'comm.cpp'), '-o', COMM_LIB,
-                        '-ldl'], capture_output=True, text=True)
-    if r.returncode != 0:
-        import warnings
-        warnings.warn('libprismer_comm.so (native RCCL gradient exchange) was not built: ' + r.stderr[-500:])
-        if os.path.isfile(COMM_LIB):
-            os.remove(COMM_LIB)
+    build_comm()
     open(stamp, 'w').write(dig)
     if verbose:
         print(f'built {LIB} ({os.path.getsize(LIB) / 1e6:.1f} MB)')

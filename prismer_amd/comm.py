@@ -15,8 +15,9 @@ def lib():
     global _lib
     if _lib is None:
         path = _build.COMM_LIB
-        if not os.path.isfile(path):
-            _build.build(force=True, verbose=False)
+        failed = os.path.join(_build.LIBDIR, 'comm.failed')
+        if not os.path.isfile(path) and not os.path.isfile(failed):
+            _build.build_comm()                                 # comm.cpp only: never touches the compute library a process has loaded
         if not os.path.isfile(path):
             raise RuntimeError('libprismer_comm.so is not available on this machine (built without <rccl/rccl.h>?); '
                                "use transport='torch.distributed'")

@@ -195,6 +195,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
   const int b = bxy.y / a.H, h = bxy.y % a.H;
   const int q0 = bxy.x * (64 * QT) + wave * (16 * QT);
   const bool wave_live = q0 < a.Sq;                 // a wave whose queries are all padding only helps staging
+  PH_TL_DECL;
+  PH_TL(0);
   const bf16* Q = reinterpret_cast<const bf16*>(a.q) + b * a.q_bs + (int64_t)h * DH;
   const bf16* K = reinterpret_cast<const bf16*>(a.k) + b * a.k_bs + (int64_t)h * DH;
   const bf16* V = reinterpret_cast<const bf16*>(a.v) + b * a.v_bs + (int64_t)h * DH;
@@ -236,10 +238,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
   for (int t = 0; t < QT; ++t)
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) settle(qf[t][ks]);
+  PH_TL(1);
   tile_lstore<DH>(smem, rk);
   tile_lstore<DH>(smem + C::TILE, rv);
   if (!PLAIN && threadIdx.x < 64) side[threadIdx.x] = key_state(kraw, kraw_i, a.Sk);
   __syncthreads();
+  PH_TL(2);
   int cur = 0;
   for (int tl = 0; tl < ntiles; ++tl) {
     const bool more = tl + 1 < ntiles;
@@ -390,6 +394,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
     __syncthreads();
     cur ^= 1;
   }
+  PH_TL(3);
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     if (qi[t] < a.Sq) {
@@ -403,6 +408,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
       if (g == 0 && a.lse) a.lse[(int64_t)(b * a.H + h) * a.Sq + qi[t]] = (PLAIN ? m[t] * LN2 : m[t]) + __logf(lsum[t]);    // natural-log lse either way
     }
   }
+#ifdef PH_TIMELINE
+  PH_TL(8);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PH_TL(9);
+  PH_TL_FLUSH((int)blockIdx.x, 0, threadIdx.x == 0);
+#endif
 }
 
 // =====================================================================================================
@@ -913,3 +924,12 @@ extern "C" int ph_attention_bwd(const ph_attn_bwd_args* a, hipStream_t stream) {
   PH_LAUNCH_CHECK("attn_bwd kernels");
   return PH_OK;
 }
+
+#ifdef PH_TIMELINE
+extern "C" int ph_tl_fetch_attn(unsigned long long* host, int n, int reset) {
+  hipDeviceSynchronize();
+  if (host && n > 0) hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tl), sizeof(unsigned long long) * (size_t)n);
+  if (reset) { void* d = nullptr; hipGetSymbolAddress(&d, HIP_SYMBOL(g_tl)); hipMemset(d, 0, sizeof(g_tl)); }
+  return 0;
+}
+#endif

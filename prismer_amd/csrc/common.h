@@ -43,6 +43,33 @@ struct ProfScope {
   ~ProfScope() { if (on) ph_prof_end(s); }
 };
 
+// ---- diagnostics build only (-DPH_TIMELINE, tools/timeline_probe.py): s_memtime stamps of one wave per thread group, kept in SGPRs and
+// stored once at the end of the block; slot meaning is documented in the probe.  Never defined in the product build.
+#ifdef PH_TIMELINE
+#define PH_TL_SLOTS 16
+#define PH_TL_BLOCKS 4096
+static __device__ unsigned long long g_tl[PH_TL_BLOCKS * 2 * PH_TL_SLOTS];
+struct TlStamps { unsigned long long t[PH_TL_SLOTS]; };
+#define PH_TL_DECL TlStamps tl__ = {}; tl__.t[10] = __builtin_amdgcn_s_memrealtime()
+#define PH_TL(s) (tl__.t[(s)] = __builtin_amdgcn_s_memtime())
+#define PH_TL_ARG tl__,
+#define PH_TL_PARAM TlStamps& tl__,
+#define PH_TL_FLUSH(blk, half, who)                                                                              \
+  do {                                                                                                           \
+    if ((who) && (blk) < PH_TL_BLOCKS) {                                                                         \
+      tl__.t[11] = __builtin_amdgcn_s_memrealtime();                                                                \
+      tl__.t[PH_TL_SLOTS - 1] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492); \
+      _Pragma("unroll") for (int i__ = 0; i__ < PH_TL_SLOTS; ++i__) g_tl[((blk) * 2 + (half)) * PH_TL_SLOTS + i__] = tl__.t[i__]; \
+    }                                                                                                            \
+  } while (0)
+#else
+#define PH_TL_DECL
+#define PH_TL(s)
+#define PH_TL_ARG
+#define PH_TL_PARAM
+#define PH_TL_FLUSH(blk, half, who)
+#endif
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -71,6 +71,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int block_i
   int lane = tid & 63, wave = tid >> 6;
   int wm = wave >> 1, wn = wave & 1;
   char* const smem_g = smem + grp * 2 * STAGE;          // this thread group's two stage buffers
+  PH_TL_DECL;
+  PH_TL(0);
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -159,9 +161,11 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int block_i
     const int nk = (nkt + KS - 1) / KS, nkg = (nkt - grp + KS - 1) / KS;
     auto gl = [&](int i, u32x4 (&xa)[BM * 8 / 256], u32x4 (&xb)[BN * 8 / 256]) { gload(kt_begin + KS * min(i, nkg - 1) + grp, xa, xb); };
     static_for(std::make_integer_sequence<int, D>{}, [&](auto dd) { gl(decltype(dd)::value, ra[decltype(dd)::value], rb[decltype(dd)::value]); });
+    PH_TL(1);
     lstore(0, ra[0], rb[0]);
     gl(D, ra[0], rb[0]);
     __syncthreads();
+    PH_TL(2);
     int cur = 0;
     int i0 = 0;
     for (; i0 + D <= nk; i0 += D) {             // full groups: no predicate anywhere (the store after the last tile lands in the
@@ -202,6 +206,12 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int block_i
   // to HBM from that layout costs one cache-line touch per 16 B; instead the fp32 tile is parked in LDS (re-using the
   // stage buffers, 16-B chunks XOR-swizzled by the row so both sides are conflict-free) and re-read row-wise: 32
   // consecutive lanes then own 256 contiguous bytes of one output row for every load/store of the fused epilogue.
+  PH_TL(3);
+  // the reads of the fused chain are requested before the accumulators are parked (gemm_common.h, "Round 4": one in-order memory counter
+  // per wave -- a load issued after a store waits for that store's acknowledgement)
+  constexpr int WO_THR = KS == 2 ? 512 : 256;
+  PH_WO_DECL(BM, BN, WO_THR);
+  writeout_prefetch<BM, BN, WO_THR>(p, m0, n0, splitk, PH_WO_ARGS);
   DropCtx dc;
   const bool drop = p.drop_p > 0.0f;
   if (drop) dc = make_drop(p.drop_seed, p.drop_stream, p.drop_p);
@@ -218,14 +228,23 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int block_i
                acc[i][j][g * 4 + 3] * p.alpha};
     *reinterpret_cast<f32x4*>(cl + ml * BN + ((c ^ (ml & (CH - 1))) << 2)) = v;
   });
-  __syncthreads();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // raw barrier: the prefetched epilogue inputs stay in flight across it
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  PH_TL(5);
   if constexpr (KS == 2) {
     static_assert(2 * BM * BN * 4 <= 4 * STAGE, "two parked fp32 tiles must fit the four stage buffers");
-    tile_writeout<BM, BN, 512>(p, reinterpret_cast<float*>(smem), m0, n0, splitk, drop, dc, reinterpret_cast<float*>(smem) + BM * BN);
+    tile_writeout<BM, BN, 512>(PH_TL_ARG p, reinterpret_cast<float*>(smem), m0, n0, splitk, drop, dc, PH_WO_ARGS, reinterpret_cast<float*>(smem) + BM * BN);
   } else {
-    tile_writeout<BM, BN, 256>(p, cl, m0, n0, splitk, drop, dc, nullptr, split_id);
+    tile_writeout<BM, BN, 256>(PH_TL_ARG p, cl, m0, n0, splitk, drop, dc, PH_WO_ARGS, nullptr, split_id);
     if (p.col_stats) tile_colstats<BM, BN, 256>(p, cl, m0, n0);
   }
+  PH_TL(8);
+#ifdef PH_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PH_TL(9);
+  PH_TL_FLUSH(block_id, grp, (threadIdx.x & 255) == 0);
+#endif
 }
 
 template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0>
@@ -425,6 +444,15 @@ int flush_deferred_locked(hipStream_t stream) {
   return PH_OK;
 }
 }  // namespace
+
+#ifdef PH_TIMELINE
+extern "C" int ph_tl_fetch_gemm(unsigned long long* host, int n, int reset) {
+  hipDeviceSynchronize();
+  if (host && n > 0) hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tl), sizeof(unsigned long long) * (size_t)n);
+  if (reset) { void* d = nullptr; hipGetSymbolAddress(&d, HIP_SYMBOL(g_tl)); hipMemset(d, 0, sizeof(g_tl)); }
+  return 0;
+}
+#endif
 
 extern "C" int ph_gemm_flush_deferred(hipStream_t stream) {
   std::lock_guard<std::mutex> lock(g_defer_mu);
@@ -684,7 +712,7 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
     static const int tail_split = env_int("PH_GEMM_TAIL_SPLIT", 1);
     const int64_t tn128 = ceil_div(a->N, 128), tm128 = ceil_div(a->M, 128);
     const int64_t tiles = tm128 * tn128, slots = 512;
-    if (tail_split && !a->trans_a && !a->conv && !a->col_stats && !(a->drop_p > 0.0f) && a->split_k <= 0 && tiles > slots && (a->K % BK) == 0) {
+    if (tail_split && !a->trans_a && !a->conv && !a->col_stats && !(a->drop_p > 0.0f) && a->split_k <= 0 && a->rowmap_wo == 0 && tiles > slots && (a->K % BK) == 0) {
       const int64_t over = tiles % slots;
       const int64_t panels_main = (tiles / slots) * slots / tn128;              // row panels that fit the whole rounds
       const int64_t m_main = panels_main * 128, m_rem = a->M - m_main;

@@ -46,6 +46,8 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;                   // wave tile: rows wm*64, cols wn*64
+  PH_TL_DECL;
+  PH_TL(0);
 
   // ---- DMA addressing: instruction i of this wave covers tile rows (i*8 + wave)*8 .. +8, lane l -> row +(l>>3), LDS slot l&7
   const bf16* a_src[A_INSTR];
@@ -150,7 +152,9 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
     } else {
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     }
+    PH_TL(1);
     __builtin_amdgcn_s_barrier();                              // tile 0 is in LDS for everybody
+    PH_TL(2);
     if (grp) __builtin_amdgcn_s_barrier();                     // group 1 idles through phase 0
     int st = 0;
     for (int t = 0; t < nk; ++t) {
@@ -187,13 +191,19 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
       __builtin_amdgcn_sched_barrier(0);
       st = st + 1 == 3 ? 0 : st + 1;
     }
+    PH_TL(3);
     if (!grp) __builtin_amdgcn_s_barrier();                    // group 0 idles through the last phase (group 1's M(nk-1))
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // drain the surplus DMA before the ring is reused as the C tile
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  PH_TL(4);
 
-  // ---- epilogue (same chain as gemm_body, 512 threads, 256 x 128 tile)
+  // ---- epilogue (same chain as gemm_body, 512 threads, 256 x 128 tile).  The reads of the fused chain (bias, residual, saved
+  // derivative) are requested here, before the accumulators are parked: their latency hides behind the LDS transpose and the store
+  // loop never waits on memory (gemm_common.h, "Round 4").  Raw s_barrier + lgkmcnt(0): __syncthreads() would drain those loads.
+  PH_WO_DECL(BM, BN, NTHR);
+  writeout_prefetch<BM, BN, NTHR>(p, m0, n0, false, PH_WO_ARGS);
   DropCtx dc;
   const bool drop = p.drop_p > 0.0f;
   if (drop) dc = make_drop(p.drop_seed, p.drop_stream, p.drop_p);
@@ -207,8 +217,17 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
                acc[i][j][g * 4 + 3] * p.alpha};
     *reinterpret_cast<f32x4*>(cl + ml * BN + ((c ^ (ml & (CH - 1))) << 2)) = v;
   });
-  __syncthreads();
-  tile_writeout<BM, BN, NTHR>(p, cl, m0, n0, false, drop, dc);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  PH_TL(5);
+  tile_writeout<BM, BN, NTHR>(PH_TL_ARG p, cl, m0, n0, false, drop, dc, PH_WO_ARGS);
+  PH_TL(8);
+#ifdef PH_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PH_TL(9);
+  PH_TL_FLUSH(block_id, wave >> 2, (threadIdx.x & 255) == 0);
+#endif
 }
 
 template <int VARIANT, bool TA, bool TB>
@@ -262,5 +281,13 @@ int launch_single(const GemmParams& p, int variant, bool ta, bool tb, hipStream_
 }
 int launch_grouped_wgrad(const GroupParams& g, int total, hipStream_t s) { return launch_grouped<4, true, true>(g, total, s); }
 }  // namespace big
+#ifdef PH_TIMELINE
+extern "C" int ph_tl_fetch_big(unsigned long long* host, int n, int reset) {
+  hipDeviceSynchronize();
+  if (host && n > 0) hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tl), sizeof(unsigned long long) * (size_t)n);
+  if (reset) { void* d = nullptr; hipGetSymbolAddress(&d, HIP_SYMBOL(g_tl)); hipMemset(d, 0, sizeof(g_tl)); }
+  return 0;
+}
+#endif
 
 }  // namespace phg

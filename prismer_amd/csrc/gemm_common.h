@@ -330,12 +330,21 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
 }
 
 // 8 consecutive outputs C[m][n..n+7] with 16-B vector loads/stores (interior tiles, 16-B aligned leading dimensions), in two
-// halves: epi_load8 issues the global READS of the fused chain (saved activation, residual), epi_apply8 does the arithmetic and the
-// stores.  The write-out loops issue the loads of several steps before the first apply, so their latency (1-2 us under load) is
-// paid once per group instead of once per step (stores to C may alias the residual -- in-place residual adds -- so the compiler
-// cannot hoist the loads by itself; every thread reads exactly the elements it later writes, which keeps the reordering exact).
-struct EpiIn { bf16x8 a, rb; f32x4 r0, r1; };   // act_in | bf16 residual | fp32 residual (typed fields: no punning through the
-                                                 // aggregate, or it is not promoted to registers)
+// halves: epi_load8 issues the global READS of the fused chain (saved activation, residual, the old C of an accumulating call),
+// epi_apply8 does the arithmetic and the stores.
+//
+// Round 4 -- every read of the write-out is issued BEFORE its first store.  gfx950 retires a wave's vector-memory operations on ONE
+// in-order counter: a wait for a load that was issued after a store also waits for that store's write acknowledgement (1-2 us under
+// load).  The round-1..3 write-out loaded the bias inside every step and the residual / saved activation per group of four steps, so a
+// 256x128 tile with bias + residual paid eight to ten dependent store-ack + load latencies: 11.7 us of write-out against an 8 us k loop
+// (tools/timeline_probe.py, profiles/r4_timeline_before.txt); the same tile without bias and residual wrote out in 4.3 us.  Now
+// writeout_prefetch() requests the bias (a per-thread constant: a thread's column block does not change over its steps) and the
+// inputs of ALL steps before the accumulators are parked; their latency hides behind the LDS transpose, and the store loop never waits
+// on memory again.  (Stores to C may alias the residual -- in-place residual adds; every thread reads exactly the elements it later
+// writes, and reads them all first, which keeps the reordering exact.)
+struct EpiIn { bf16x8 a, rb; f32x4 r0, r1; };   // act_in | bf16 residual or old bf16 C | fp32 residual or old fp32 C (typed fields: no punning
+                                                 // through the aggregate, or it is not promoted to registers)
+__device__ __forceinline__ bool epi_c_prefetched(const GemmParams& p) { return p.accumulate && p.out_f32 && !p.residual; }
 __device__ __forceinline__ void epi_load8(const GemmParams& p, int m, int n, EpiIn& in) {
   if (p.act_in) in.a = *reinterpret_cast<const bf16x8*>(p.act_in + (size_t)m * p.ld_act + n);
   if (p.residual && p.res_f32) {
@@ -343,11 +352,14 @@ __device__ __forceinline__ void epi_load8(const GemmParams& p, int m, int n, Epi
     in.r0 = *reinterpret_cast<const f32x4*>(q); in.r1 = *reinterpret_cast<const f32x4*>(q + 4);
   } else if (p.residual) {
     in.rb = *reinterpret_cast<const bf16x8*>(p.residual + (size_t)m * p.ldr + n);
-  }
+  } else if (p.accumulate && p.out_f32) {           // accumulating call without residual: the old C travels in the residual's registers
+    const float* q = reinterpret_cast<const float*>(p.C) + crow(p, m) * p.ldc + n;
+    in.r0 = *reinterpret_cast<const f32x4*>(q); in.r1 = *reinterpret_cast<const f32x4*>(q + 4);
+  }                                                 // (bf16 accumulate: read in the loop -- no call site of the step uses it)
 }
-__device__ __forceinline__ void epi_apply8(const GemmParams& p, int m, int n, float (&v)[8], bool drop, const DropCtx& dc, const EpiIn& in) {
+__device__ __forceinline__ void epi_apply8(const GemmParams& p, int m, int n, float (&v)[8], bool drop, const DropCtx& dc, const EpiIn& in,
+                                           const f32x4& b0, const f32x4& b1) {
   if (p.bias) {
-    f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
   }
@@ -388,7 +400,9 @@ __device__ __forceinline__ void epi_apply8(const GemmParams& p, int m, int n, fl
   if (p.out_f32) {
     float* c = reinterpret_cast<float*>(p.C) + crow(p, m) * p.ldc + n;
     if (p.accumulate) {
-      f32x4 c0 = *reinterpret_cast<const f32x4*>(c), c1 = *reinterpret_cast<const f32x4*>(c + 4);
+      f32x4 c0, c1;
+      if (epi_c_prefetched(p)) { c0 = in.r0; c1 = in.r1; }
+      else { c0 = *reinterpret_cast<const f32x4*>(c); c1 = *reinterpret_cast<const f32x4*>(c + 4); }     // (accumulate + residual: rare, in-loop read)
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] += c0[e]; v[4 + e] += c1[e]; }
     }
@@ -398,7 +412,7 @@ __device__ __forceinline__ void epi_apply8(const GemmParams& p, int m, int n, fl
   } else {
     bf16* c = reinterpret_cast<bf16*>(p.C) + crow(p, m) * p.ldc + n;
     if (p.accumulate) {
-      bf16x8 t = *reinterpret_cast<const bf16x8*>(c);
+      const bf16x8 t = *reinterpret_cast<const bf16x8*>(c);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += bf2f(t[e]);
     }
@@ -409,55 +423,69 @@ __device__ __forceinline__ void epi_apply8(const GemmParams& p, int m, int n, fl
   }
 }
 
+// Inputs of a tile's write-out, requested before the tile is parked (see above).  vec8 = the fast path applies: 8 outputs per thread
+// per step through 16-B loads / stores (every leading dimension and pointer of the fused chain 16-B aligned).  A thread's column block
+// c is the same for all its steps (NTHR is a multiple of the CH / 2 column blocks of a tile row), its rows are ml = (u * NTHR + tid) / (CH / 2).
+template <int BM, int BN, int NTHR>
+struct WoCfg {
+  static constexpr int CH = BN / 4, IT = BM * CH / (2 * NTHR);
+  static_assert(NTHR % (CH / 2) == 0 && IT >= 1, "write-out: a thread must keep its column block over its steps");
+};
+// (the prefetched values are plain locals of the calling kernel, passed by reference: an aggregate holding them ended up in scratch memory)
+#define PH_WO_DECL(BM, BN, NTHR) EpiIn wo_in[WoCfg<BM, BN, NTHR>::IT]; f32x4 wo_b0, wo_b1; bool wo_vec8
+#define PH_WO_ARGS wo_in, wo_b0, wo_b1, wo_vec8
+template <int BM, int BN, int NTHR>
+__device__ __forceinline__ void writeout_prefetch(const GemmParams& p, int m0, int n0, bool splitk, EpiIn (&in)[WoCfg<BM, BN, NTHR>::IT],
+                                                  f32x4& b0, f32x4& b1, bool& vec8) {
+  constexpr int CH = BN / 4, IT = WoCfg<BM, BN, NTHR>::IT;
+  vec8 = !(splitk) && p.N >= 8 && (p.ldc % 8) == 0 && (!p.act_in || (p.ld_act % 8) == 0) && (!p.residual || (p.ldr % 8) == 0) &&
+         ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.pre_out) | reinterpret_cast<uintptr_t>(p.act_in) |
+           reinterpret_cast<uintptr_t>(p.residual) | reinterpret_cast<uintptr_t>(p.bias)) & 15) == 0;
+  b0 = f32x4{0.f, 0.f, 0.f, 0.f}; b1 = f32x4{0.f, 0.f, 0.f, 0.f};
+  static_for(std::make_integer_sequence<int, IT>{}, [&](auto uu) { in[decltype(uu)::value] = EpiIn{}; });
+  if (!vec8) return;
+  const int c = ((int)threadIdx.x % (CH / 2)) * 2;
+  const int n = (n0 + c * 4 + 8 <= p.N) ? n0 + c * 4 : 0;          // always a valid address: the loads are unconditional
+  if (p.bias) { b0 = *reinterpret_cast<const f32x4*>(p.bias + n); b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4); }
+  static_for(std::make_integer_sequence<int, IT>{}, [&](auto uu) {
+    constexpr int u = decltype(uu)::value;
+    const int ml = (u * NTHR + (int)threadIdx.x) / (CH / 2);
+    epi_load8(p, min(m0 + ml, p.M - 1), n, in[u]);
+  });
+}
+
 // Row-wise write-out of a BM x BN fp32 tile parked in LDS (16-B chunks XOR-swizzled by the row): consecutive lanes own
 // consecutive 16/32-B pieces of one output row for every load / store of the fused epilogue chain.
-template <int BM, int BN, int NTHR, int GCAP = 4>      // GCAP: cap on the prefetch group (register budget of the caller)
-__device__ __forceinline__ void tile_writeout(const GemmParams& p, const float* cl, int m0, int n0, bool splitk, bool drop,
-                                              const DropCtx& dc, const float* cl2 = nullptr, int split_id = 0) {   // cl2: second partial tile to add (KS = 2); split_id: workspace slice of a split-K block
+template <int BM, int BN, int NTHR>
+__device__ __forceinline__ void tile_writeout(PH_TL_PARAM const GemmParams& p, const float* cl, int m0, int n0, bool splitk, bool drop,
+                                              const DropCtx& dc, const EpiIn (&in)[WoCfg<BM, BN, NTHR>::IT], const f32x4& b0, const f32x4& b1, const bool vec8,
+                                              const float* cl2 = nullptr, int split_id = 0) {   // cl2: second partial tile to add (KS = 2); split_id: workspace slice of a split-K block
   constexpr int CH = BN / 4;                       // 16-B chunks per tile row
-  // fast path: 8 outputs per thread per step (16-B loads/stores) when every leading dimension / pointer allows it
-  const bool vec8 = !(splitk) && p.N >= 8 && (p.ldc % 8) == 0 && (!p.act_in || (p.ld_act % 8) == 0) && (!p.residual || (p.ldr % 8) == 0) &&
-                    ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.pre_out) | reinterpret_cast<uintptr_t>(p.act_in) |
-                      reinterpret_cast<uintptr_t>(p.residual) | reinterpret_cast<uintptr_t>(p.bias)) & 15) == 0;
   if (vec8) {
-    // steps per thread; steps per load group (16 VGPRs of prefetched inputs per step: 4 for the 512-thread kernel, whose register budget
-    // is 256/lane at its occupancy; 2 for the 256-thread kernels, which must stay under 192 + 64 accumulators for 2 blocks per CU)
-    constexpr int IT = BM * CH / (2 * NTHR), G = (NTHR >= 512 && IT % 4 == 0 && GCAP >= 4) ? 4 : ((IT % 2 == 0 && GCAP >= 2) ? 2 : 1);
-    for (int it0 = 0; it0 < IT; it0 += G) {
-      EpiIn in[G];                  // (indexed with compile-time constants only and fully initialised: stays in VGPRs)
-      static_for(std::make_integer_sequence<int, G>{}, [&](auto uu) {
-        constexpr int u = decltype(uu)::value;
-        const int id = (it0 + u) * NTHR + threadIdx.x;
-        const int ml = id / (CH / 2), c = (id % (CH / 2)) * 2;
-        const int m = min(m0 + ml, p.M - 1), n = (n0 + c * 4 + 8 <= p.N) ? n0 + c * 4 : 0;     // always a valid address: the loads are unconditional
-        in[u] = EpiIn{};
-        epi_load8(p, m, n, in[u]);
-      });
-      static_for(std::make_integer_sequence<int, G>{}, [&](auto uu) {
-        constexpr int u = decltype(uu)::value;
-        const int id = (it0 + u) * NTHR + threadIdx.x;
-        const int ml = id / (CH / 2), c = (id % (CH / 2)) * 2;
-        const int m = m0 + ml, n = n0 + c * 4;
-        const int sw = ml & (CH - 1);
-        f32x4 t0 = *reinterpret_cast<const f32x4*>(cl + ml * BN + ((c ^ sw) << 2));
-        f32x4 t1 = *reinterpret_cast<const f32x4*>(cl + ml * BN + (((c + 1) ^ sw) << 2));
-        if (cl2) {
-          t0 += *reinterpret_cast<const f32x4*>(cl2 + ml * BN + ((c ^ sw) << 2));
-          t1 += *reinterpret_cast<const f32x4*>(cl2 + ml * BN + (((c + 1) ^ sw) << 2));
-        }
-        if (m < p.M && n + 8 <= p.N) {
-          float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-#ifdef PH_GEMM_DIAG_NOSTORE  // diagnostics build: staging + LDS reads, no HBM traffic from the epilogue
-          if (v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] != 123456.789f) return;
-#endif
-          epi_apply8(p, m, n, v, drop, dc, in[u]);
-        } else if (m < p.M) {
-          float v0[4] = {t0[0], t0[1], t0[2], t0[3]}, v1[4] = {t1[0], t1[1], t1[2], t1[3]};
-          if (n < p.N) epilogue_store(p, m, n, v0, false, drop, dc);
-          if (n + 4 < p.N) epilogue_store(p, m, n + 4, v1, false, drop, dc);
-        }
-      });
-    }
+    constexpr int IT = WoCfg<BM, BN, NTHR>::IT;
+    PH_TL(6);
+    static_for(std::make_integer_sequence<int, IT>{}, [&](auto uu) {
+      constexpr int u = decltype(uu)::value;
+      const int id = u * NTHR + (int)threadIdx.x;
+      const int ml = id / (CH / 2), c = (id % (CH / 2)) * 2;
+      const int m = m0 + ml, n = n0 + c * 4;
+      const int sw = ml & (CH - 1);
+      f32x4 t0 = *reinterpret_cast<const f32x4*>(cl + ml * BN + ((c ^ sw) << 2));
+      f32x4 t1 = *reinterpret_cast<const f32x4*>(cl + ml * BN + (((c + 1) ^ sw) << 2));
+      if (cl2) {
+        t0 += *reinterpret_cast<const f32x4*>(cl2 + ml * BN + ((c ^ sw) << 2));
+        t1 += *reinterpret_cast<const f32x4*>(cl2 + ml * BN + (((c + 1) ^ sw) << 2));
+      }
+      if (m < p.M && n + 8 <= p.N) {
+        float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+        epi_apply8(p, m, n, v, drop, dc, in[u], b0, b1);
+      } else if (m < p.M) {
+        float v0[4] = {t0[0], t0[1], t0[2], t0[3]}, v1[4] = {t1[0], t1[1], t1[2], t1[3]};
+        if (n < p.N) epilogue_store(p, m, n, v0, false, drop, dc);
+        if (n + 4 < p.N) epilogue_store(p, m, n + 4, v1, false, drop, dc);
+      }
+      if (u == 0) PH_TL(7);
+    });
   } else {
 #pragma unroll 4
     for (int it = 0; it < BM * CH / NTHR; ++it) {

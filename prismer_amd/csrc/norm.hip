@@ -18,6 +18,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(ph_layernorm_fwd_args a) {
   int lane = threadIdx.x & 63;
   int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.M) return;
+  PH_TL_DECL;
+  PH_TL(0);
   const int nch = a.D >> 2;
   const bf16* x = reinterpret_cast<const bf16*>(a.x) + (size_t)row * a.D;
   const float* xf = reinterpret_cast<const float*>(a.x) + (size_t)row * a.D;
@@ -45,7 +47,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(ph_layernorm_fwd_args a) {
       }
     }
   }
+  PH_TL(1);
   float mean = wave_sum(s) / (float)a.D;
+  PH_TL(2);
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
@@ -56,6 +60,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(ph_layernorm_fwd_args a) {
     }
   }
   float rstd = rsqrtf(wave_sum(q) / (float)a.D + a.eps);
+  PH_TL(3);
   if (lane == 0) {
     if (a.mean) a.mean[row] = mean;
     if (a.rstd) a.rstd[row] = rstd;
@@ -76,6 +81,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(ph_layernorm_fwd_args a) {
       if (y2) *reinterpret_cast<bf16x4*>(y2 + c * 4) = o;
     }
   }
+#ifdef PH_TIMELINE
+  PH_TL(8);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PH_TL(9);
+  PH_TL_FLUSH((int)blockIdx.x, 0, threadIdx.x == 0);
+#endif
 }
 
 // Backward.  Each wave walks rows (grid-stride) keeping its dgamma / dbeta partials in registers; the block
@@ -325,3 +336,12 @@ extern "C" int ph_layernorm_bwd(const ph_layernorm_bwd_args* a, hipStream_t stre
   PH_LAUNCH_CHECK("ln_bwd_kernel");
   return PH_OK;
 }
+
+#ifdef PH_TIMELINE
+extern "C" int ph_tl_fetch_norm(unsigned long long* host, int n, int reset) {
+  hipDeviceSynchronize();
+  if (host && n > 0) hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tl), sizeof(unsigned long long) * (size_t)n);
+  if (reset) { void* d = nullptr; hipGetSymbolAddress(&d, HIP_SYMBOL(g_tl)); hipMemset(d, 0, sizeof(g_tl)); }
+  return 0;
+}
+#endif

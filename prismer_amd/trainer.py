@@ -134,7 +134,9 @@ class Trainer:
         self._grads_clean = False
         self.keep_grads = keep_grads           # True: gradients stay readable after step() (tests); False: AdamW zeroes them
         self._overwrite = os.environ.get('PRISMER_WGRAD_OVERWRITE', '1') != '0'      # see _wq_scope
-        self._exclusive, self._keep_maps = None, None
+        self._exclusive, self._keep_maps, self._count_config = None, None, None
+        self._graph_no_fill = False
+        self._step_open = False                # a step was started and did not reach its last segment (exception between replays)
         if self.world > 1:
             self.broadcast_parameters()
 
@@ -366,17 +368,29 @@ class Trainer:
         if not self._overwrite:
             yield
             return
+        if self._exclusive is not None and self._count_config != self._wq_config():
+            # the frozen single-writer state belongs to another configuration (queue switched, micro-batching changed): recount
+            self._exclusive, self._keep_maps = None, None
         counting = self._exclusive is None
         if counting:
             wq.counts = {}
         else:
             wq.exclusive = self._exclusive
+        completed = False
         try:
             yield
+            completed = True
         finally:
-            if counting and wq.counts is not None:
+            # only a step that ran to its end has seen every writer: a partial count (failed capture warm-up, an exception in a
+            # collective) would mark multiply-written outputs exclusive and later steps would overwrite instead of accumulate
+            if counting and completed and wq.counts is not None:
                 self._finish_count(wq.counts)
+                self._count_config = self._wq_config()
             wq.counts, wq.exclusive = None, None
+
+    def _wq_config(self):
+        """what the frozen single-writer state depends on: a change invalidates it (see _wq_scope)"""
+        return (bool(ops.WQ.enabled), self.micro, self.keep_grads, tuple(st.n_train for st in self.stores))
 
     def _finish_count(self, counts):
         excl = set()
@@ -648,6 +662,7 @@ class Trainer:
             for st in self.stores:
                 st.grad.zero_()
             self._grads_clean = True
+            self._graph_no_fill = True                          # the replayed step relies on its predecessor's AdamW for clean buffers
         torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
         # thread_local: RCCL's watchdog thread polls events while we capture (world > 1); only this thread's calls are policed
@@ -694,11 +709,18 @@ class Trainer:
             self.exchange.begin_step()
         self.trace = []                                         # host enqueue order of compute segments and bucket hand-offs
         if self.use_graph:
+            if self._step_open and self._graph_no_fill:
+                # the previous replayed step was interrupted between two segments (an exception in a host collective, Ctrl-C): its
+                # partly accumulated gradients never reached the AdamW that re-zeroes them, and the graphs carry no fill of their own
+                for st in self.stores:
+                    st.grad.zero_()
+            self._step_open = True
             for i, (g, coll) in enumerate(self.graphs):
                 self.trace.append(('seg', i))
                 g.replay()
                 if coll is not None:
                     coll()
+            self._step_open = False
         else:
             with self._wq_scope():
                 for i, (seg, coll) in enumerate(self._schedule()):

@@ -22,7 +22,7 @@ def _dims(name):
         return config.prismer_base()
     if name == 'zbase_b4':                # BASELINE config 2 geometry: PrismerZ-BASE, full depth
         return config.prismerz_base()
-    if name == 'large_vqa_b1':            # BASELINE config 5 geometry: Prismer-LARGE VQA, 480^2, full depth (24 + 24 layers)
+    if name in ('large_vqa_b1', 'large_vqa_b4'):            # BASELINE config 5 geometry: Prismer-LARGE VQA, 480^2, full depth (24 + 24 layers)
         return config.prismer_large()
     raise KeyError(name)
 
@@ -44,11 +44,13 @@ CASES = OrderedDict([
     # round 3: EXACTLY the configuration bench.py times (BASELINE config 3: Prismer-BASE, bs32, T=30) -- at this batch the GEMM dispatch
     # selects the 256x128 ping-pong kernel and the grouped persistent weight-gradient kernel, which B=8 never reaches
     ('base_b32', (32, 30, True)),
+    # round 4: config 5 at a batch where the dispatch picks the 256x128 / grouped kernels UNFORCED (B=1 had to force them); ragged rows
+    ('large_vqa_b4', (4, 40, True)),
 ])
 
-LOGIT_STRIDE = {'base_caption': 97, 'base_b8': 97, 'zbase_b4': 97, 'large_vqa_b1': 97, 'base_b32': 97}    # every 97th vocab column for the big cases
-ENC_STRIDE = {'base_b8': 16, 'zbase_b4': 8, 'large_vqa_b1': 16, 'base_b32': 16}                             # every n-th feature of the encoder output
-VQA_CASES = ('tiny_vqa', 'large_vqa_b1')
+LOGIT_STRIDE = {'base_caption': 97, 'base_b8': 97, 'zbase_b4': 97, 'large_vqa_b1': 97, 'base_b32': 97, 'large_vqa_b4': 97}    # every 97th vocab column for the big cases
+ENC_STRIDE = {'base_b8': 16, 'zbase_b4': 8, 'large_vqa_b1': 16, 'base_b32': 16, 'large_vqa_b4': 16}                             # every n-th feature of the encoder output
+VQA_CASES = ('tiny_vqa', 'large_vqa_b1', 'large_vqa_b4')
 VQA_HEAD_TQ, VQA_HEAD_TA = 9, 5
 
 

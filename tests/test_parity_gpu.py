@@ -390,7 +390,6 @@ def test_rank_inference_matches_oracle(name, head):
     print(name, head, 'best', best.tolist(), want_best.tolist(), 'topk', topk.tolist(), want_topk.tolist())
     agree = 0
     for b in range(B):
-        assert sorted(topk[b].tolist()) == sorted(want_topk[b].tolist()) or True       # (the k-th / k+1-th candidates may be a near-tie)
         score = {int(i): float(s) for i, s in zip(topk[b], lp[b])}
         wscore = {int(i): float(s) for i, s in zip(want_topk[b], want_lp[b])}
         common = sorted(set(score) & set(wscore))
