@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libprismer_hip.so')
 COMM_LIB = os.path.join(LIBDIR, 'libprismer_comm.so')     # RCCL gradient-exchange transport (include/prismer_comm.h), host code only
-SOURCES = ['core.hip', 'gemm.hip', 'gemm_big.hip', 'norm.hip', 'attention.hip', 'frontend.hip', 'embed_loss.hip', 'optim.hip']
+SOURCES = ['core.hip', 'gemm.hip', 'gemm_s128.hip', 'gemm_s64.hip', 'gemm_g128.hip', 'gemm_g64.hip', 'gemm_big.hip', 'norm.hip', 'attention.hip', 'frontend.hip', 'embed_loss.hip', 'optim.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-pass-failed']
 
 
@@ -69,7 +69,7 @@ def build(force=False, verbose=True):
             raise RuntimeError(f'hipcc failed on {src}:\n{r.stderr[-4000:]}')
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 8, len(SOURCES))) as ex:
         objs = list(ex.map(cc, SOURCES))
     r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs, capture_output=True, text=True)
     if r.returncode != 0:

@@ -27,261 +27,6 @@ using namespace phg;
 
 namespace {
 
-
-// One output tile over the k-tiles [kt_begin, kt_end).  XCD_REMAP: block_id is a hardware block index of a one-tile-per-block launch
-// (re-mapped so that each XCD owns a contiguous run of tiles); otherwise block_id already is the tile index.  splitk: the tile has
-// other contributors (raw partial sums: workspace slice split_id, or fp32 atomics into C when there is no workspace).
-// KS = 2: intra-block split of the k loop (512 threads): thread group g = threadIdx.x >> 8 multiplies the k-tiles kt_begin + 2i + g
-// in its own pair of LDS stage buffers, the write-out sums the two partial tiles.  For the decoder's launches (M = B*T = 960 rows:
-// fewer tiles than CUs, so one block per CU and one wave per SIMD) the k loop is a latency chain -- LDS write, barrier, LDS read,
-// 4 MFMAs per wave -- and a second wave per SIMD working on the other half of K hides half of it.
-template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0, bool XCD_REMAP = true, int KS = 1>
-__device__ __forceinline__ void gemm_tile(const GemmParams& p, const int block_id, const int kt_begin, const int kt_end, const bool splitk,
-                                          const int split_id = 0) {
-  static_assert(KS == 1 || (KS == 2 && CONV == 0 && PF > 1), "intra-block k split: plain ring kernels only");
-  static_assert(CONV == 0 || (CONV == 1 && !TA && !TB) || (CONV == 2 && TA && TB), "conv gather: A of an NN problem or B of a TT problem");
-  constexpr int WM = BM / 2, WN = BN / 2;   // wave tile
-  constexpr int TM = WM / 32, TN = WN / 32; // 32x32 MFMA tiles per wave
-  constexpr int A_BYTES = TA ? TileBytes<BM>::ks : TileBytes<BM>::kc;
-  constexpr int B_BYTES = TB ? TileBytes<BN>::ks : TileBytes<BN>::kc;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int STAGE = A_BYTES + B_BYTES;   // stage s: A image at smem + s*STAGE, B image right behind it
-
-  // XCD-aware tile mapping: hardware places block b on XCD b % 8; give each XCD a contiguous run of tiles.
-  int nt = p.tiles_m * p.tiles_n;
-  int bid = block_id;
-  if constexpr (XCD_REMAP) {
-    int q = nt / 8, r = nt % 8, xcd = bid % 8, idx = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  // L2-aware rasterisation: tiles are walked in groups of GM row-panels, rows fastest.  The ~64 tiles an XCD runs at once
-  // then cover ~8 row-panels x 8 column-panels (16 operand panels through its 4 MB L2) instead of 1-3 row-panels x ALL
-  // column-panels: PMC showed 3-4x the algorithmic HBM bytes on the wide-N GEMMs (qkv / fc / LM head) with row-major order.
-  constexpr int GM = 8;
-  const int group_sz = GM * p.tiles_n;
-  const int first_m = (bid / group_sz) * GM;
-  const int gm = min(GM, p.tiles_m - first_m);
-  const int rin = bid % group_sz;
-  int tm = first_m + rin % gm, tn = rin / gm;
-  int m0 = tm * BM, n0 = tn * BN;
-  if (kt_begin >= kt_end) return;
-
-  const int tid = KS == 2 ? (int)(threadIdx.x & 255) : (int)threadIdx.x;
-  const int grp = KS == 2 ? (int)(threadIdx.x >> 8) : 0;
-  int lane = tid & 63, wave = tid >> 6;
-  int wm = wave >> 1, wn = wave & 1;
-  char* const smem_g = smem + grp * 2 * STAGE;          // this thread group's two stage buffers
-  PH_TL_DECL;
-  PH_TL(0);
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-  // Register prefetch ring of depth D: the global loads of k-tiles t+1 .. t+D are in flight while tile t is multiplied
-  // (HBM/L2 latency is ~1-2 us, one 128x128x64 tile of MFMA work is ~0.2-0.4 us: depth 1 stalls every iteration).
-  // Ring slot s holds tile (t0 + s); slots are indexed with compile-time constants only (static_for) so they stay
-  // in VGPRs.  LDS stays double-buffered: one barrier per k-tile.
-  constexpr int D = PF;
-  u32x4 ra[D][BM * 8 / 256], rb[D][BN * 8 / 256];
-  PixRow px[BM * 8 / 256];
-  ColTap ct[BN * 8 / 256];
-  if constexpr (CONV == 1) {
-#pragma unroll
-    for (int i = 0; i < BM * 8 / 256; ++i) px[i] = pix_of(p.cv, min(m0 + ((int)(threadIdx.x + 256 * i) >> 3), p.M - 1));
-  }
-  if constexpr (CONV == 2) coltaps_of<BN>(p.cv, n0, p.N, ct);
-  auto gload = [&](int kt, u32x4 (&xa)[BM * 8 / 256], u32x4 (&xb)[BN * 8 / 256]) {
-    int k0 = kt * BK;
-    // plain ring kernels are only launched when K % BK == 0 (no k predicate); with a gathered operand K = taps * C is any multiple
-    // of 8 and the OTHER operand keeps its predicate -- the gather zero-fills k >= K, but 0 x (whatever lies behind the weight row,
-    // possibly NaN bit patterns at the end of an allocation) is not 0
-    constexpr bool KF = PF > 1 && CONV == 0;
-    if constexpr (CONV == 1) load_kc_conv<BM>(p.cv, p.A, px, k0, xa);
-    else if (TA) load_ks<BM, KF>(p.A, p.lda, m0, p.M, k0, p.K, xa, tid); else load_kc<BM, KF>(p.A, p.lda, m0, p.M, k0, p.K, xa, tid);
-    if constexpr (CONV == 2) load_ks_conv<BN>(p.cv, p.B, ct, k0, p.K, xb);
-    else if (TB) load_ks<BN, KF>(p.B, p.ldb, n0, p.N, k0, p.K, xb, tid); else load_kc<BN, KF>(p.B, p.ldb, n0, p.N, k0, p.K, xb, tid);
-  };
-  auto lstore = [&](int buf, const u32x4 (&xa)[BM * 8 / 256], const u32x4 (&xb)[BN * 8 / 256]) {
-    char* sa = smem_g + buf * STAGE;
-    char* sb = sa + A_BYTES;
-    if (TA) store_ks<BM>(sa, xa, tid); else store_kc<BM>(sa, xa, tid);
-    if constexpr (CONV == 2) store_ks_conv<BN>(sb, xb);
-    else if (TB) store_ks<BN>(sb, xb, tid); else store_kc<BN>(sb, xb, tid);
-  };
-  auto compute = [&](int buf) {
-    const char* la = smem_g + buf * STAGE;
-    const char* lb = la + A_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      bf16x8 fx[TM], fw[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        fx[i] = TA ? frag_ks<BM>(la, wm * WM + i * 32, kk, lane) : frag_kc(la, wm * WM + i * 32, kk, lane);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        fw[j] = TB ? frag_ks<BN>(lb, wn * WN + j * 32, kk, lane) : frag_kc(lb, wn * WN + j * 32, kk, lane);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fx[i], acc[i][j], 0, 0, 0);
-    }
-  };
-
-  // Schedule (per k-tile t, one barrier):   [LDS(cur) = tile t, registers = tile t+1 landed or landing]
-  //     write registers -> LDS(cur^1)      (tile t+1; its loads were issued a whole iteration ago)
-  //     re-issue the SAME registers <- global tile t+2      (in flight across the barrier)
-  //     MFMAs on LDS(cur)
-  //     barrier
-  // i.e. two tiles of look-ahead with one register set and two LDS buffers; the LDS write pass sits BEFORE this wave's
-  // MFMAs, where it overlaps the co-resident block's matrix work instead of trailing its own.
-  if constexpr (D == 1) {
-    gload(kt_begin, ra[0], rb[0]);
-    lstore(0, ra[0], rb[0]);
-    if (kt_begin + 1 < kt_end) gload(kt_begin + 1, ra[0], rb[0]);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      if (kt + 1 < kt_end) lstore(cur ^ 1, ra[0], rb[0]);
-      if (kt + 2 < kt_end) gload(kt + 2, ra[0], rb[0]);
-      compute(cur);
-      __syncthreads();
-      cur ^= 1;
-    }
-  } else {
-    // Ring of D register sets: the loads of tile i+1+D are issued in iteration i and written to LDS in iteration i+D, so a
-    // load has D iterations to land (one is not enough when a CU holds a single block, i.e. every GEMM with few tiles).
-    // Loads are unconditional (tile index clamped to the last one) and slots are compile-time constants.
-    // (KS = 2: group g owns tiles kt_begin + 2i + g; nk = iterations of the block, nkg = tiles of this group -- one less for group 1
-    //  when the count is odd: it then runs its last iteration on a clamped reload without multiplying)
-    const int nkt = kt_end - kt_begin;
-    const int nk = (nkt + KS - 1) / KS, nkg = (nkt - grp + KS - 1) / KS;
-    auto gl = [&](int i, u32x4 (&xa)[BM * 8 / 256], u32x4 (&xb)[BN * 8 / 256]) { gload(kt_begin + KS * min(i, nkg - 1) + grp, xa, xb); };
-    static_for(std::make_integer_sequence<int, D>{}, [&](auto dd) { gl(decltype(dd)::value, ra[decltype(dd)::value], rb[decltype(dd)::value]); });
-    PH_TL(1);
-    lstore(0, ra[0], rb[0]);
-    gl(D, ra[0], rb[0]);
-    __syncthreads();
-    PH_TL(2);
-    int cur = 0;
-    int i0 = 0;
-    for (; i0 + D <= nk; i0 += D) {             // full groups: no predicate anywhere (the store after the last tile lands in the
-      static_for(std::make_integer_sequence<int, D>{}, [&](auto dd) {      // idle buffer and is never read)
-        constexpr int d = decltype(dd)::value, slot = (d + 1) % D;
-        lstore(cur ^ 1, ra[slot], rb[slot]);
-        gl(i0 + d + 1 + D, ra[slot], rb[slot]);
-        if (KS == 1 || i0 + d < nkg) compute(cur);
-        __syncthreads();
-        cur ^= 1;
-      });
-    }
-    static_for(std::make_integer_sequence<int, D - 1>{}, [&](auto dd) {    // remainder: nk % D tiles
-      constexpr int d = decltype(dd)::value, slot = (d + 1) % D;
-      if (i0 + d < nk) {
-        lstore(cur ^ 1, ra[slot], rb[slot]);
-        if (KS == 1 || i0 + d < nkg) compute(cur);
-        __syncthreads();
-        cur ^= 1;
-      }
-    });
-  }
-
-#ifdef PH_GEMM_DIAG_NOEPI   // diagnostics build (tools/build_variant.py): main loop only, nothing written unless a sentinel hits
-  {
-    float chk = 0.f;
-    static_for(std::make_integer_sequence<int, TM * TN>{}, [&](auto idx) {
-      constexpr int i = decltype(idx)::value / TN, j = decltype(idx)::value % TN;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) chk += acc[i][j][e];
-    });
-    if (chk == 123456.789f) reinterpret_cast<float*>(p.C)[threadIdx.x] = chk;
-    return;
-  }
-#endif
-  // ---- epilogue --------------------------------------------------------------------------------------------------
-  // MFMA leaves lane l with C[m = l&31][n = 8g + 4(l>>5) + e]: 32 different rows per store instruction.  Going straight
-  // to HBM from that layout costs one cache-line touch per 16 B; instead the fp32 tile is parked in LDS (re-using the
-  // stage buffers, 16-B chunks XOR-swizzled by the row so both sides are conflict-free) and re-read row-wise: 32
-  // consecutive lanes then own 256 contiguous bytes of one output row for every load/store of the fused epilogue.
-  PH_TL(3);
-  // the reads of the fused chain are requested before the accumulators are parked (gemm_common.h, "Round 4": one in-order memory counter
-  // per wave -- a load issued after a store waits for that store's acknowledgement)
-  constexpr int WO_THR = KS == 2 ? 512 : 256;
-  PH_WO_DECL(BM, BN, WO_THR);
-  writeout_prefetch<BM, BN, WO_THR>(p, m0, n0, splitk, PH_WO_ARGS);
-  DropCtx dc;
-  const bool drop = p.drop_p > 0.0f;
-  if (drop) dc = make_drop(p.drop_seed, p.drop_stream, p.drop_p);
-  constexpr int CH = BN / 4;                       // 16-B chunks per tile row
-  float* cl = reinterpret_cast<float*>(smem) + grp * (BM * BN);     // (KS = 2: one parking area per thread group, summed by the write-out)
-  // (the main loop ended with a barrier: nobody reads the stage buffers any more)
-  // acc[][] must only ever be indexed with compile-time constants (a runtime index demotes the accumulators to
-  // scratch memory and the main loop then spills them every k-tile), so the tile loop is a static_for.
-  static_for(std::make_integer_sequence<int, TM * TN * 4>{}, [&](auto idx) {
-    constexpr int i = decltype(idx)::value / (TN * 4), j = (decltype(idx)::value / 4) % TN, g = decltype(idx)::value % 4;
-    const int ml = wm * WM + i * 32 + (lane & 31);
-    const int c = (wn * WN + j * 32 + g * 8 + (lane >> 5) * 4) >> 2;
-    f32x4 v = {acc[i][j][g * 4 + 0] * p.alpha, acc[i][j][g * 4 + 1] * p.alpha, acc[i][j][g * 4 + 2] * p.alpha,
-               acc[i][j][g * 4 + 3] * p.alpha};
-    *reinterpret_cast<f32x4*>(cl + ml * BN + ((c ^ (ml & (CH - 1))) << 2)) = v;
-  });
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // raw barrier: the prefetched epilogue inputs stay in flight across it
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  PH_TL(5);
-  if constexpr (KS == 2) {
-    static_assert(2 * BM * BN * 4 <= 4 * STAGE, "two parked fp32 tiles must fit the four stage buffers");
-    tile_writeout<BM, BN, 512>(PH_TL_ARG p, reinterpret_cast<float*>(smem), m0, n0, splitk, drop, dc, PH_WO_ARGS, reinterpret_cast<float*>(smem) + BM * BN);
-  } else {
-    tile_writeout<BM, BN, 256>(PH_TL_ARG p, cl, m0, n0, splitk, drop, dc, PH_WO_ARGS, nullptr, split_id);
-    if (p.col_stats) tile_colstats<BM, BN, 256>(p, cl, m0, n0);
-  }
-  PH_TL(8);
-#ifdef PH_TIMELINE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  PH_TL(9);
-  PH_TL_FLUSH(block_id, grp, (threadIdx.x & 255) == 0);
-#endif
-}
-
-template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0>
-__device__ __forceinline__ void gemm_body(const GemmParams& p, const int block_id, const int split_id, const int nsplits) {
-  const int kt_begin = split_id * p.k_tiles_per_split;
-  const int kt_end = min(kt_begin + p.k_tiles_per_split, (p.K + BK - 1) / BK);
-  gemm_tile<BM, BN, TA, TB, PF, CONV, true>(p, block_id, kt_begin, kt_end, nsplits > 1, split_id);
-}
-
-template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
-  gemm_body<BM, BN, TA, TB, PF, CONV>(p, blockIdx.x, blockIdx.z, gridDim.z);
-}
-
-
-// The grid may be SMALLER than the number of tiles (ph_gemm_grouped_bf16's max_blocks): each block then walks tiles
-// blockIdx.x, blockIdx.x + gridDim.x, ... -- a background launch that occupies at most max_blocks block slots and leaves the rest
-// of the chip to the latency-bound chain on the main stream (deferred weight gradients beside the decoder's backward).
-template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0>
-__global__ __launch_bounds__(256) void gemm_grouped_kernel(GroupParams g) {
-  const int total = g.tile_start[g.n];
-  int i = 0;
-  for (int t = blockIdx.x; t < total; t += gridDim.x) {
-    while (i + 1 < g.n && t >= g.tile_start[i + 1]) ++i;
-    const int local = t - g.tile_start[i], ns = g.nsplit[i];
-    if (ns > 1) {                        // grouped AND split over K (long reductions with few output tiles): partial sums -> workspace
-      const int ntile = g.p[i].tiles_m * g.p[i].tiles_n;
-      gemm_body<BM, BN, TA, TB, PF, CONV>(g.p[i], local % ntile, local / ntile, ns);
-    } else {
-      gemm_body<BM, BN, TA, TB, PF, CONV>(g.p[i], local, 0, 1);
-    }
-    __syncthreads();                     // the epilogue's LDS staging area is the next tile's stage buffer
-  }
-}
-
-
-
 // folds the split-K partials and applies the fused epilogue (bias / activation / dropout / residual / accumulate / dtype).
 // LANES threads share one output vector: lane l sums the splits l, l + LANES, ... and the group is folded with shuffles -- with up to
 // 256 splits of a tiny output (the stems' first-layer weight gradients: 768 output vectors) one thread per vector walked 256
@@ -328,66 +73,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_grouped_kernel(ReduceGroup 
   int i = 0;
   while (i + 1 < g.n && (int)blockIdx.x >= g.blk_start[i + 1]) ++i;
   splitk_reduce_body<LANES>(g.p[i], g.splits[i], (int)blockIdx.x - g.blk_start[i], g.blk_start[i + 1] - g.blk_start[i]);
-}
-
-// prefetch depth per tile size (VGPR budget: 128x128 tiles hold 32 staging VGPRs per slot, 64x64 tiles 16)
-// A/B on MI355X (tools/ab_probe.py, graph replay): depth 2 on 128x128 tiles +2..10 % on the NT / NN layouts (TN: -4 %, kept
-// at 1); depth 3 on 64x64 tiles +7..11 % on the one-block-per-CU decoder GEMMs; split-K launches keep depth 1.
-#ifndef PH_RING128
-#define PH_RING128 2
-#endif
-#ifndef PH_RING64
-#define PH_RING64 3
-#endif
-#define PF_DEPTH(bm) ((bm) == 128 ? PH_RING128 : PH_RING64)
-
-// 512-thread form with the k loop split between two thread groups (gemm_tile KS = 2); 64x64 tiles, K % 64 == 0, no split-K
-template <bool TA, bool TB>
-__global__ __launch_bounds__(512) void gemm_ks2_kernel(GemmParams p) {
-  gemm_tile<64, 64, TA, TB, PH_RING64, 0, true, 2>(p, blockIdx.x, 0, p.K / BK, false);
-}
-
-template <bool TA, bool TB>
-int launch_ks2(const GemmParams& p, hipStream_t s) {
-  constexpr int smem = 4 * ((TA ? TileBytes<64>::ks : TileBytes<64>::kc) + (TB ? TileBytes<64>::ks : TileBytes<64>::kc));
-  PH_SET_SMEM_ONCE((&gemm_ks2_kernel<TA, TB>), smem);
-  count_launch(PH_GEMM_CLS_KS2);
-  hipLaunchKernelGGL((gemm_ks2_kernel<TA, TB>), dim3(p.tiles_m * p.tiles_n), dim3(512), smem, s, p);
-  PH_LAUNCH_CHECK("gemm_ks2_kernel");
-  return PH_OK;
-}
-
-template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0>
-int launch_pf(const GemmParams& p, int splits, hipStream_t s) {
-  constexpr int smem_min = 2 * ((TA ? TileBytes<BM>::ks : TileBytes<BM>::kc) + (TB ? TileBytes<BN>::ks : TileBytes<BN>::kc));
-  static const int extra = env_int("PH_GEMM_EXTRA_LDS", 0);            // occupancy experiments only (pads the dynamic LDS request)
-  const int smem = smem_min + extra;
-  PH_SET_SMEM_ONCE((&gemm_kernel<BM, BN, TA, TB, PF, CONV>), smem);
-  count_launch(BM == 64 ? PH_GEMM_CLS_64 : PH_GEMM_CLS_128);
-  dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, TA, TB, PF, CONV>), grid, dim3(256), smem, s, p);
-  PH_LAUNCH_CHECK("gemm_kernel");
-  return PH_OK;
-}
-
-template <int BM, int BN, bool TA, bool TB>
-int launch(const GemmParams& p, int splits, hipStream_t s) {
-  if constexpr (PF_DEPTH(BM) > 1 && !(BM == 128 && TA)) {
-    if (p.K % BK == 0 && splits == 1) return launch_pf<BM, BN, TA, TB, PF_DEPTH(BM)>(p, splits, s);   // the ring needs unpredicated k loads
-  }
-  return launch_pf<BM, BN, TA, TB, 1>(p, splits, s);
-}
-
-template <int BM, int BN>
-int dispatch_layout(const GemmParams& p, int ta, int tb, int splits, hipStream_t s) {
-  if (p.cv.C > 0) {       // implicit-GEMM weight gradient: B = im2col view (K-strided gather); square tiles only, no prefetch ring
-    if constexpr (BM == BN) return launch_pf<BM, BN, true, true, 1, 2>(p, splits, s);
-    else return ph_fail(PH_ERR_UNSUPPORTED, "ph_gemm_bf16: conv gather needs square tiles");
-  }
-  if (!ta && !tb) return launch<BM, BN, false, false>(p, splits, s);
-  if (!ta && tb) return launch<BM, BN, false, true>(p, splits, s);
-  if (ta && tb) return launch<BM, BN, true, true>(p, splits, s);
-  return launch<BM, BN, true, false>(p, splits, s);
 }
 
 }  // namespace
@@ -445,14 +130,6 @@ int flush_deferred_locked(hipStream_t stream) {
 }
 }  // namespace
 
-#ifdef PH_TIMELINE
-extern "C" int ph_tl_fetch_gemm(unsigned long long* host, int n, int reset) {
-  hipDeviceSynchronize();
-  if (host && n > 0) hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tl), sizeof(unsigned long long) * (size_t)n);
-  if (reset) { void* d = nullptr; hipGetSymbolAddress(&d, HIP_SYMBOL(g_tl)); hipMemset(d, 0, sizeof(g_tl)); }
-  return 0;
-}
-#endif
 
 extern "C" int ph_gemm_flush_deferred(hipStream_t stream) {
   std::lock_guard<std::mutex> lock(g_defer_mu);
@@ -475,6 +152,16 @@ extern "C" int ph_gemm_dispatch_counts(int64_t* out, int n, int reset) {
   return PH_GEMM_CLS_COUNT;
 }
 
+// device-resident zero vector standing in for a null bias (epilogue classes, gemm_common.h): part of the code object, no allocation
+static __device__ float g_zero_bias[PH_ZERO_BIAS_FLOATS];
+static const float* zero_bias_ptr() {
+  static const float* ptr = [] {
+    void* d = nullptr;
+    return hipGetSymbolAddress(&d, HIP_SYMBOL(g_zero_bias)) == hipSuccess ? static_cast<const float*>(d) : nullptr;
+  }();
+  return ptr;
+}
+
 // argument validation + kernel parameter block shared by the single and the grouped entry point
 static int fill_params(const ph_gemm_args* a, GemmParams& p) {
   PH_CHECK_ARG(a && a->A && a->B && a->C, "ph_gemm_bf16: null pointer");
@@ -489,7 +176,8 @@ static int fill_params(const ph_gemm_args* a, GemmParams& p) {
   PH_CHECK_ARG(a->drop_p >= 0.0f && a->drop_p < 1.0f, "ph_gemm_bf16: bad dropout p");
   p.A = (const bf16*)a->A; p.B = (const bf16*)a->B; p.C = a->C;
   p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc;
-  p.bias = a->bias; p.pre_out = (bf16*)a->pre_out; p.act_in = (const bf16*)a->act_in; p.ld_act = a->ld_act;
+  p.bias = a->bias; p.bias_or_zero = a->bias ? a->bias : (a->N <= PH_ZERO_BIAS_FLOATS ? zero_bias_ptr() : nullptr);
+  p.pre_out = (bf16*)a->pre_out; p.act_in = (const bf16*)a->act_in; p.ld_act = a->ld_act;
   p.residual = (const bf16*)a->residual; p.ldr = a->ldr; p.res_f32 = a->residual_f32;
   p.drop_p = a->drop_p; p.drop_seed = a->drop_seed; p.drop_stream = a->drop_stream;
   p.act = a->act; p.out_f32 = a->out_f32; p.accumulate = a->accumulate; p.alpha = a->alpha; p.pre_grad = a->pre_grad;
@@ -522,24 +210,6 @@ static int fill_params(const ph_gemm_args* a, GemmParams& p) {
   PH_CHECK_ARG(!a->col_stats || (!a->bias && a->act == PH_ACT_NONE && !a->act_in && !a->residual && !(a->drop_p > 0.f) && !a->accumulate),
                "ph_gemm_bf16: col_stats needs a plain epilogue");
   return PH_OK;
-}
-
-template <int BM, bool TA, bool TB, int PF, int CONV = 0>
-static int launch_grouped(const GroupParams& g, int total, int max_blocks, hipStream_t s) {
-  constexpr int smem = 2 * ((TA ? TileBytes<BM>::ks : TileBytes<BM>::kc) + (TB ? TileBytes<BM>::ks : TileBytes<BM>::kc));
-  PH_SET_SMEM_ONCE((&gemm_grouped_kernel<BM, BM, TA, TB, PF, CONV>), smem);
-  count_launch(PH_GEMM_CLS_GROUPED);
-  const int grid = (max_blocks > 0 && max_blocks < total) ? max_blocks : total;
-  hipLaunchKernelGGL((gemm_grouped_kernel<BM, BM, TA, TB, PF, CONV>), dim3(grid), dim3(256), smem, s, g);
-  PH_LAUNCH_CHECK("gemm_grouped_kernel");
-  return PH_OK;
-}
-template <int BM, int PF>
-static int launch_grouped_layout(const GroupParams& g, int total, int max_blocks, int ta, int tb, hipStream_t s) {
-  if (!ta && !tb) return launch_grouped<BM, false, false, PF>(g, total, max_blocks, s);
-  if (!ta && tb) return launch_grouped<BM, false, true, PF>(g, total, max_blocks, s);
-  if (ta && tb) return launch_grouped<BM, true, true, PF>(g, total, max_blocks, s);
-  return launch_grouped<BM, true, false, PF>(g, total, max_blocks, s);
 }
 
 extern "C" int ph_gemm_grouped_bf16(const ph_gemm_args* args, int n, hipStream_t stream) {
@@ -629,8 +299,7 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
         }
         g.tile_start[n] = tot;
         int rc;
-        if (conv) rc = BMsel == 128 ? launch_grouped<128, true, true, 1, 2>(g, tot, 0, stream) : launch_grouped<64, true, true, 1, 2>(g, tot, 0, stream);
-        else rc = BMsel == 128 ? launch_grouped_layout<128, 1>(g, tot, 0, 1, 1, stream) : launch_grouped_layout<64, 1>(g, tot, 0, 1, 1, stream);
+        rc = BMsel == 128 ? reg::launch_grouped_128(g, tot, 0, 1, 1, 0, conv ? 2 : 0, stream) : reg::launch_grouped_64(g, tot, 0, 1, 1, 0, conv ? 2 : 0, stream);
         if (rc != PH_OK) return rc;
         ReduceGroup r;
         r.n = 0; r.blk_start[0] = 0;
@@ -684,22 +353,17 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
       // gathered A operand through the register prefetch ring as well (round 3): the gather loads are unconditional (clamped address +
       // select), so the ring's straight-line bookkeeping holds for any K.  PH_GEMM_CONV_RING=0: the round-2 one-deep schedule
       static const int conv_ring = env_int("PH_GEMM_CONV_RING", 1);
-      if (conv_ring) return BMsel == 128 ? launch_grouped<128, false, false, PH_RING128, 1>(g, total, max_blocks, stream)
-                                         : launch_grouped<64, false, false, PH_RING64, 1>(g, total, max_blocks, stream);
-      return BMsel == 128 ? launch_grouped<128, false, false, 1, 1>(g, total, max_blocks, stream)
-                          : launch_grouped<64, false, false, 1, 1>(g, total, max_blocks, stream);
+      return BMsel == 128 ? reg::launch_grouped_128(g, total, max_blocks, 0, 0, conv_ring ? 1 : 0, 1, stream)
+                          : reg::launch_grouped_64(g, total, max_blocks, 0, 0, conv_ring ? 1 : 0, 1, stream);
     }
-    return BMsel == 128 ? launch_grouped<128, true, true, 1, 2>(g, total, max_blocks, stream)
-                        : launch_grouped<64, true, true, 1, 2>(g, total, max_blocks, stream);
+    return BMsel == 128 ? reg::launch_grouped_128(g, total, max_blocks, 1, 1, 0, 2, stream) : reg::launch_grouped_64(g, total, max_blocks, 1, 1, 0, 2, stream);
   }
   if (BMsel == 128) {
     static const int tt_ring = env_int("PH_GEMM_TT_RING", 1);        // prefetch ring for the [K,M] x [K,N] weight-gradient groups too (round 3:
                                                                      // step -0.07 / -0.17 ms in two same-box pairs; round 1 measured -4 % on single launches)
-    if (kfull && PH_RING128 > 1 && (!ta || tt_ring)) return launch_grouped_layout<128, PH_RING128>(g, total, max_blocks, ta, tb, stream);
-    return launch_grouped_layout<128, 1>(g, total, max_blocks, ta, tb, stream);
+    return reg::launch_grouped_128(g, total, max_blocks, ta, tb, (kfull && (!ta || tt_ring)) ? 1 : 0, 0, stream);
   }
-  if (kfull && PH_RING64 > 1) return launch_grouped_layout<64, PH_RING64>(g, total, max_blocks, ta, tb, stream);
-  return launch_grouped_layout<64, 1>(g, total, max_blocks, ta, tb, stream);
+  return reg::launch_grouped_64(g, total, max_blocks, ta, tb, kfull ? 1 : 0, 0, stream);
 }
 
 extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
@@ -864,12 +528,10 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
     if (ks2 > 0 && plain64 && t64 <= 512 && (splits == 1 || ks2 >= 2)) {
       p.tiles_m = ceil_div(a->M, 64); p.tiles_n = ceil_div(a->N, 64);
       p.k_tiles_per_split = kt; p.ws = nullptr;
-      return a->trans_b ? launch_ks2<false, true>(p, stream) : launch_ks2<false, false>(p, stream);
+      return reg::launch_ks2(p, a->trans_b, stream);
     }
   }
-  int rc = BM == 64 ? dispatch_layout<64, 64>(p, a->trans_a, a->trans_b, splits, stream)
-           : BN == 64 ? dispatch_layout<128, 64>(p, a->trans_a, a->trans_b, splits, stream)
-                      : dispatch_layout<128, 128>(p, a->trans_a, a->trans_b, splits, stream);
+  int rc = BM == 64 ? reg::launch_single_64(p, a->trans_a, a->trans_b, splits, stream) : reg::launch_single_128(p, BN, a->trans_a, a->trans_b, splits, stream);
   if (rc != PH_OK || !p.ws) return rc;
   const int64_t vecs = (int64_t)a->M * ((a->N + 3) / 4);
   if (deferred) {                                         // the fold pass joins the queue (the partials stay where they are until the flush)

@@ -143,12 +143,22 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
     //        all shares of tile t+1 are then in LDS, the first read of tile t+1 is in phase 2t+2 (one barrier later).
     //   WAR  R phases end with lgkmcnt(0) BEFORE their barrier; stage (t+2)%3 = stage of tile t-1 was last read in phase 2t-1 and
     //        is overwritten from phase 2t+1 (group 0) / 2t (group 1, tile t+2 = (t-1)+3) on.
+    // LEAN tail (VARIANT & 8, round 4): no surplus DMA.  The clamped re-loads of the last iterations kept every wait at vmcnt(6) but had
+    // to be drained before the ring could hold the C tile (0.45 us per tile, tools/timeline_probe.py), and group 0 idled through group 1's
+    // last M phase.  Here a tile that does not exist is not requested: a wave whose newest request is the tile it needs waits vmcnt(0)
+    // instead (newer = "tile t+2 exists"), nothing is in flight after the loop, group 1 skips the barrier behind its last M phase (pure
+    // register work) and group 0 goes straight from its last barrier to the epilogue -- both groups have then passed 1 + 2*nk barriers.
+    constexpr bool LEAN = (VARIANT & 8) != 0;
     const int grp = wave >> 2;
     issue(0, 0);
     issue(min(1, nk - 1), 1);
     if (grp) {
-      issue(min(2, nk - 1), 2);
-      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      if (!LEAN || nk > 2) {
+        issue(min(2, nk - 1), 2);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      }
     } else {
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     }
@@ -161,6 +171,7 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
       // R(t)
       const char* la = smem + st * STAGE;
       const char* lb = la + A_BYTES;
+      const bool newer = !LEAN || t + 2 < nk;                  // tile t+2 exists (group 1 requested it in M(t-1), group 0 does in M(t))
       bf16x8 fx[BK / 16][2], fw[BK / 16][2];
 #pragma unroll
       for (int kk = 0; kk < BK / 16; ++kk) {
@@ -169,15 +180,19 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
 #pragma unroll
         for (int j = 0; j < 2; ++j) fw[kk][j] = TB ? frag_ks_dma<256>(lb, wn * 64 + j * 32, kk, lane) : frag_kc(lb, wn * 64 + j * 32, kk, lane);
       }
-      if (grp) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (grp) {
+        if (newer) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       // M(t)
       int sn = st + 2 + grp; sn = sn >= 3 ? sn - 3 : sn;
       if (VARIANT & 1) __builtin_amdgcn_s_setprio(1);
-      issue(min(t + 2 + grp, nk - 1), sn);
+      if (!LEAN || t + 2 + grp < nk) issue(min(t + 2 + grp, nk - 1), sn);
 #pragma unroll
       for (int kk = 0; kk < BK / 16; ++kk)
 #pragma unroll
@@ -185,25 +200,31 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[kk][j], fx[kk][i], acc[i][j], 0, 0, 0);
       if (VARIANT & 1) __builtin_amdgcn_s_setprio(0);
-      if (!grp) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      if (!grp) {
+        if (newer) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
+      if (!(LEAN && grp && t == nk - 1)) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       st = st + 1 == 3 ? 0 : st + 1;
     }
     PH_TL(3);
-    if (!grp) __builtin_amdgcn_s_barrier();                    // group 0 idles through the last phase (group 1's M(nk-1))
+    if (!LEAN && !grp) __builtin_amdgcn_s_barrier();           // group 0 idles through the last phase (group 1's M(nk-1))
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // drain the surplus DMA before the ring is reused as the C tile
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
+  if constexpr ((VARIANT & 8) == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // drain the surplus DMA before the ring is reused as the C tile
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
   PH_TL(4);
 
   // ---- epilogue (same chain as gemm_body, 512 threads, 256 x 128 tile).  The reads of the fused chain (bias, residual, saved
   // derivative) are requested here, before the accumulators are parked: their latency hides behind the LDS transpose and the store
   // loop never waits on memory (gemm_common.h, "Round 4").  Raw s_barrier + lgkmcnt(0): __syncthreads() would drain those loads.
+  const int epi = epi_classify(p, false);
   PH_WO_DECL(BM, BN, NTHR);
-  writeout_prefetch<BM, BN, NTHR>(p, m0, n0, false, PH_WO_ARGS);
+  wo_prefetch<BM, BN, NTHR>(epi, p, m0, n0, PH_WO_ARGS);
   DropCtx dc;
   const bool drop = p.drop_p > 0.0f;
   if (drop) dc = make_drop(p.drop_seed, p.drop_stream, p.drop_p);
@@ -221,7 +242,7 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   PH_TL(5);
-  tile_writeout<BM, BN, NTHR>(PH_TL_ARG p, cl, m0, n0, false, drop, dc, PH_WO_ARGS);
+  tile_writeout<BM, BN, NTHR>(PH_TL_ARG epi, p, cl, m0, n0, false, drop, dc, PH_WO_ARGS);
   PH_TL(8);
 #ifdef PH_TIMELINE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -276,8 +297,9 @@ int launch_grouped(const GroupParams& g, int total, hipStream_t s) {
 namespace big {
 int launch_single(const GemmParams& p, int variant, bool ta, bool tb, hipStream_t s) {
   if (ta) return launch<4, true, true>(p, s);                      // weight-gradient layout: ping-pong only
-  if (tb) return variant == 0 ? launch<0, false, true>(p, s) : variant == 5 ? launch<5, false, true>(p, s) : launch<4, false, true>(p, s);
-  return variant == 0 ? launch<0, false, false>(p, s) : variant == 5 ? launch<5, false, false>(p, s) : launch<4, false, false>(p, s);
+  // variant 5 (ping-pong + s_setprio, measured negative in round 2) gave its slot to the LEAN tail (VARIANT 12) in round 4
+  if (tb) return variant == 0 ? launch<0, false, true>(p, s) : variant == 5 ? launch<12, false, true>(p, s) : launch<4, false, true>(p, s);
+  return variant == 0 ? launch<0, false, false>(p, s) : variant == 5 ? launch<12, false, false>(p, s) : launch<4, false, false>(p, s);
 }
 int launch_grouped_wgrad(const GroupParams& g, int total, hipStream_t s) { return launch_grouped<4, true, true>(g, total, s); }
 }  // namespace big

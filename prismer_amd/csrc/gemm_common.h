@@ -50,6 +50,7 @@ struct GemmParams {
   const bf16* A; const bf16* B; void* C;
   int M, N, K, lda, ldb, ldc;
   const float* bias;
+  const float* bias_or_zero;   // bias, or the library's device-resident zero vector when the call has none (N <= PH_ZERO_BIAS_FLOATS), or null
   bf16* pre_out;
   const bf16* act_in; int ld_act;
   const bf16* residual; int ldr; int res_f32;
@@ -330,21 +331,12 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int m, int n
 }
 
 // 8 consecutive outputs C[m][n..n+7] with 16-B vector loads/stores (interior tiles, 16-B aligned leading dimensions), in two
-// halves: epi_load8 issues the global READS of the fused chain (saved activation, residual, the old C of an accumulating call),
-// epi_apply8 does the arithmetic and the stores.
-//
-// Round 4 -- every read of the write-out is issued BEFORE its first store.  gfx950 retires a wave's vector-memory operations on ONE
-// in-order counter: a wait for a load that was issued after a store also waits for that store's write acknowledgement (1-2 us under
-// load).  The round-1..3 write-out loaded the bias inside every step and the residual / saved activation per group of four steps, so a
-// 256x128 tile with bias + residual paid eight to ten dependent store-ack + load latencies: 11.7 us of write-out against an 8 us k loop
-// (tools/timeline_probe.py, profiles/r4_timeline_before.txt); the same tile without bias and residual wrote out in 4.3 us.  Now
-// writeout_prefetch() requests the bias (a per-thread constant: a thread's column block does not change over its steps) and the
-// inputs of ALL steps before the accumulators are parked; their latency hides behind the LDS transpose, and the store loop never waits
-// on memory again.  (Stores to C may alias the residual -- in-place residual adds; every thread reads exactly the elements it later
-// writes, and reads them all first, which keeps the reordering exact.)
-struct EpiIn { bf16x8 a, rb; f32x4 r0, r1; };   // act_in | bf16 residual or old bf16 C | fp32 residual or old fp32 C (typed fields: no punning
-                                                 // through the aggregate, or it is not promoted to registers)
-__device__ __forceinline__ bool epi_c_prefetched(const GemmParams& p) { return p.accumulate && p.out_f32 && !p.residual; }
+// halves: epi_load8 issues the global READS of the fused chain (saved activation, residual), epi_apply8 does the arithmetic and the
+// stores.  The write-out loops issue the loads of several steps before the first apply, so their latency (1-2 us under load) is
+// paid once per group instead of once per step (stores to C may alias the residual -- in-place residual adds -- so the compiler
+// cannot hoist the loads by itself; every thread reads exactly the elements it later writes, which keeps the reordering exact).
+struct EpiIn { bf16x8 a, rb; f32x4 r0, r1; };   // act_in | bf16 residual | fp32 residual (typed fields: no punning through the
+                                                 // aggregate, or it is not promoted to registers)
 __device__ __forceinline__ void epi_load8(const GemmParams& p, int m, int n, EpiIn& in) {
   if (p.act_in) in.a = *reinterpret_cast<const bf16x8*>(p.act_in + (size_t)m * p.ld_act + n);
   if (p.residual && p.res_f32) {
@@ -352,10 +344,7 @@ __device__ __forceinline__ void epi_load8(const GemmParams& p, int m, int n, Epi
     in.r0 = *reinterpret_cast<const f32x4*>(q); in.r1 = *reinterpret_cast<const f32x4*>(q + 4);
   } else if (p.residual) {
     in.rb = *reinterpret_cast<const bf16x8*>(p.residual + (size_t)m * p.ldr + n);
-  } else if (p.accumulate && p.out_f32) {           // accumulating call without residual: the old C travels in the residual's registers
-    const float* q = reinterpret_cast<const float*>(p.C) + crow(p, m) * p.ldc + n;
-    in.r0 = *reinterpret_cast<const f32x4*>(q); in.r1 = *reinterpret_cast<const f32x4*>(q + 4);
-  }                                                 // (bf16 accumulate: read in the loop -- no call site of the step uses it)
+  }
 }
 __device__ __forceinline__ void epi_apply8(const GemmParams& p, int m, int n, float (&v)[8], bool drop, const DropCtx& dc, const EpiIn& in,
                                            const f32x4& b0, const f32x4& b1) {
@@ -400,9 +389,7 @@ __device__ __forceinline__ void epi_apply8(const GemmParams& p, int m, int n, fl
   if (p.out_f32) {
     float* c = reinterpret_cast<float*>(p.C) + crow(p, m) * p.ldc + n;
     if (p.accumulate) {
-      f32x4 c0, c1;
-      if (epi_c_prefetched(p)) { c0 = in.r0; c1 = in.r1; }
-      else { c0 = *reinterpret_cast<const f32x4*>(c); c1 = *reinterpret_cast<const f32x4*>(c + 4); }     // (accumulate + residual: rare, in-loop read)
+      f32x4 c0 = *reinterpret_cast<const f32x4*>(c), c1 = *reinterpret_cast<const f32x4*>(c + 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] += c0[e]; v[4 + e] += c1[e]; }
     }
@@ -412,7 +399,7 @@ __device__ __forceinline__ void epi_apply8(const GemmParams& p, int m, int n, fl
   } else {
     bf16* c = reinterpret_cast<bf16*>(p.C) + crow(p, m) * p.ldc + n;
     if (p.accumulate) {
-      const bf16x8 t = *reinterpret_cast<const bf16x8*>(c);
+      bf16x8 t = *reinterpret_cast<const bf16x8*>(c);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += bf2f(t[e]);
     }
@@ -423,69 +410,62 @@ __device__ __forceinline__ void epi_apply8(const GemmParams& p, int m, int n, fl
   }
 }
 
-// Inputs of a tile's write-out, requested before the tile is parked (see above).  vec8 = the fast path applies: 8 outputs per thread
-// per step through 16-B loads / stores (every leading dimension and pointer of the fused chain 16-B aligned).  A thread's column block
-// c is the same for all its steps (NTHR is a multiple of the CH / 2 column blocks of a tile row), its rows are ml = (u * NTHR + tid) / (CH / 2).
-template <int BM, int BN, int NTHR>
-struct WoCfg {
-  static constexpr int CH = BN / 4, IT = BM * CH / (2 * NTHR);
-  static_assert(NTHR % (CH / 2) == 0 && IT >= 1, "write-out: a thread must keep its column block over its steps");
-};
-// (the prefetched values are plain locals of the calling kernel, passed by reference: an aggregate holding them ended up in scratch memory)
-#define PH_WO_DECL(BM, BN, NTHR) EpiIn wo_in[WoCfg<BM, BN, NTHR>::IT]; f32x4 wo_b0, wo_b1; bool wo_vec8
-#define PH_WO_ARGS wo_in, wo_b0, wo_b1, wo_vec8
-template <int BM, int BN, int NTHR>
-__device__ __forceinline__ void writeout_prefetch(const GemmParams& p, int m0, int n0, bool splitk, EpiIn (&in)[WoCfg<BM, BN, NTHR>::IT],
-                                                  f32x4& b0, f32x4& b1, bool& vec8) {
-  constexpr int CH = BN / 4, IT = WoCfg<BM, BN, NTHR>::IT;
-  vec8 = !(splitk) && p.N >= 8 && (p.ldc % 8) == 0 && (!p.act_in || (p.ld_act % 8) == 0) && (!p.residual || (p.ldr % 8) == 0) &&
-         ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.pre_out) | reinterpret_cast<uintptr_t>(p.act_in) |
-           reinterpret_cast<uintptr_t>(p.residual) | reinterpret_cast<uintptr_t>(p.bias)) & 15) == 0;
-  b0 = f32x4{0.f, 0.f, 0.f, 0.f}; b1 = f32x4{0.f, 0.f, 0.f, 0.f};
-  static_for(std::make_integer_sequence<int, IT>{}, [&](auto uu) { in[decltype(uu)::value] = EpiIn{}; });
-  if (!vec8) return;
-  const int c = ((int)threadIdx.x % (CH / 2)) * 2;
-  const int n = (n0 + c * 4 + 8 <= p.N) ? n0 + c * 4 : 0;          // always a valid address: the loads are unconditional
-  if (p.bias) { b0 = *reinterpret_cast<const f32x4*>(p.bias + n); b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4); }
-  static_for(std::make_integer_sequence<int, IT>{}, [&](auto uu) {
-    constexpr int u = decltype(uu)::value;
-    const int ml = (u * NTHR + (int)threadIdx.x) / (CH / 2);
-    epi_load8(p, min(m0 + ml, p.M - 1), n, in[u]);
-  });
-}
-
 // Row-wise write-out of a BM x BN fp32 tile parked in LDS (16-B chunks XOR-swizzled by the row): consecutive lanes own
 // consecutive 16/32-B pieces of one output row for every load / store of the fused epilogue chain.
-template <int BM, int BN, int NTHR>
-__device__ __forceinline__ void tile_writeout(PH_TL_PARAM const GemmParams& p, const float* cl, int m0, int n0, bool splitk, bool drop,
-                                              const DropCtx& dc, const EpiIn (&in)[WoCfg<BM, BN, NTHR>::IT], const f32x4& b0, const f32x4& b1, const bool vec8,
-                                              const float* cl2 = nullptr, int split_id = 0) {   // cl2: second partial tile to add (KS = 2); split_id: workspace slice of a split-K block
+template <int BM, int BN, int NTHR, int GCAP = 4>      // GCAP: cap on the prefetch group (register budget of the caller)
+__device__ __forceinline__ void tile_writeout_generic(PH_TL_PARAM const GemmParams& p, const float* cl, int m0, int n0, bool splitk, bool drop,
+                                              const DropCtx& dc, const float* cl2 = nullptr, int split_id = 0) {   // cl2: second partial tile to add (KS = 2); split_id: workspace slice of a split-K block
   constexpr int CH = BN / 4;                       // 16-B chunks per tile row
+  // fast path: 8 outputs per thread per step (16-B loads/stores) when every leading dimension / pointer allows it
+  const bool vec8 = !(splitk) && p.N >= 8 && (p.ldc % 8) == 0 && (!p.act_in || (p.ld_act % 8) == 0) && (!p.residual || (p.ldr % 8) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.pre_out) | reinterpret_cast<uintptr_t>(p.act_in) |
+                      reinterpret_cast<uintptr_t>(p.residual) | reinterpret_cast<uintptr_t>(p.bias)) & 15) == 0;
   if (vec8) {
-    constexpr int IT = WoCfg<BM, BN, NTHR>::IT;
-    PH_TL(6);
-    static_for(std::make_integer_sequence<int, IT>{}, [&](auto uu) {
-      constexpr int u = decltype(uu)::value;
-      const int id = u * NTHR + (int)threadIdx.x;
-      const int ml = id / (CH / 2), c = (id % (CH / 2)) * 2;
-      const int m = m0 + ml, n = n0 + c * 4;
-      const int sw = ml & (CH - 1);
-      f32x4 t0 = *reinterpret_cast<const f32x4*>(cl + ml * BN + ((c ^ sw) << 2));
-      f32x4 t1 = *reinterpret_cast<const f32x4*>(cl + ml * BN + (((c + 1) ^ sw) << 2));
-      if (cl2) {
-        t0 += *reinterpret_cast<const f32x4*>(cl2 + ml * BN + ((c ^ sw) << 2));
-        t1 += *reinterpret_cast<const f32x4*>(cl2 + ml * BN + (((c + 1) ^ sw) << 2));
-      }
-      if (m < p.M && n + 8 <= p.N) {
-        float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-        epi_apply8(p, m, n, v, drop, dc, in[u], b0, b1);
-      } else if (m < p.M) {
-        float v0[4] = {t0[0], t0[1], t0[2], t0[3]}, v1[4] = {t1[0], t1[1], t1[2], t1[3]};
-        if (n < p.N) epilogue_store(p, m, n, v0, false, drop, dc);
-        if (n + 4 < p.N) epilogue_store(p, m, n + 4, v1, false, drop, dc);
-      }
-      if (u == 0) PH_TL(7);
-    });
+    // the bias of a thread's column block is the same for all its steps (NTHR is a multiple of the CH / 2 column blocks of a row): read once,
+    // ahead of every store (round 4, see "epilogue classes" below)
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+    {
+      const int c = ((int)threadIdx.x % (CH / 2)) * 2;
+      const int n = (n0 + c * 4 + 8 <= p.N) ? n0 + c * 4 : 0;
+      if (p.bias) { b0 = *reinterpret_cast<const f32x4*>(p.bias + n); b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4); }
+    }
+    // steps per thread; steps per load group (16 VGPRs of prefetched inputs per step: 4 for the 512-thread kernel, whose register budget
+    // is 256/lane at its occupancy; 2 for the 256-thread kernels, which must stay under 192 + 64 accumulators for 2 blocks per CU)
+    constexpr int IT = BM * CH / (2 * NTHR), G = (NTHR >= 512 && IT % 4 == 0 && GCAP >= 4) ? 4 : ((IT % 2 == 0 && GCAP >= 2) ? 2 : 1);
+    for (int it0 = 0; it0 < IT; it0 += G) {
+      EpiIn in[G];                  // (indexed with compile-time constants only and fully initialised: stays in VGPRs)
+      static_for(std::make_integer_sequence<int, G>{}, [&](auto uu) {
+        constexpr int u = decltype(uu)::value;
+        const int id = (it0 + u) * NTHR + threadIdx.x;
+        const int ml = id / (CH / 2), c = (id % (CH / 2)) * 2;
+        const int m = min(m0 + ml, p.M - 1), n = (n0 + c * 4 + 8 <= p.N) ? n0 + c * 4 : 0;     // always a valid address: the loads are unconditional
+        in[u] = EpiIn{};
+        epi_load8(p, m, n, in[u]);
+      });
+      if (it0 == 0) PH_TL(6);
+      static_for(std::make_integer_sequence<int, G>{}, [&](auto uu) {
+        constexpr int u = decltype(uu)::value;
+        const int id = (it0 + u) * NTHR + threadIdx.x;
+        const int ml = id / (CH / 2), c = (id % (CH / 2)) * 2;
+        const int m = m0 + ml, n = n0 + c * 4;
+        const int sw = ml & (CH - 1);
+        f32x4 t0 = *reinterpret_cast<const f32x4*>(cl + ml * BN + ((c ^ sw) << 2));
+        f32x4 t1 = *reinterpret_cast<const f32x4*>(cl + ml * BN + (((c + 1) ^ sw) << 2));
+        if (cl2) {
+          t0 += *reinterpret_cast<const f32x4*>(cl2 + ml * BN + ((c ^ sw) << 2));
+          t1 += *reinterpret_cast<const f32x4*>(cl2 + ml * BN + (((c + 1) ^ sw) << 2));
+        }
+        if (m < p.M && n + 8 <= p.N) {
+          float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+          epi_apply8(p, m, n, v, drop, dc, in[u], b0, b1);
+        } else if (m < p.M) {
+          float v0[4] = {t0[0], t0[1], t0[2], t0[3]}, v1[4] = {t1[0], t1[1], t1[2], t1[3]};
+          if (n < p.N) epilogue_store(p, m, n, v0, false, drop, dc);
+          if (n + 4 < p.N) epilogue_store(p, m, n + 4, v1, false, drop, dc);
+        }
+      });
+      if (it0 == 0) PH_TL(7);
+    }
   } else {
 #pragma unroll 4
     for (int it = 0; it < BM * CH / NTHR; ++it) {
@@ -497,6 +477,160 @@ __device__ __forceinline__ void tile_writeout(PH_TL_PARAM const GemmParams& p, c
       float v[4] = {t[0], t[1], t[2], t[3]};
       if (m < p.M && n < p.N) epilogue_store(p, m, n, v, splitk, drop, dc, split_id);
     }
+  }
+}
+
+// BatchNorm statistics of a conv-as-GEMM output, taken from the tile while it is parked in LDS: per column the sum and the sum of
+// ---- epilogue classes (round 4) -----------------------------------------------------------------------------------------------
+// gfx950 retires a wave's vector-memory operations on ONE in-order counter: a wait for a load that was issued after a store also
+// waits for that store's write acknowledgement (1-2 us under load).  The generic write-out above reads the bias / residual / saved
+// derivative between its stores, behind two dozen wave-uniform runtime branches that hipcc answers with s_waitcnt vmcnt(0) at every
+// join: a 256x128 tile with bias + residual paid eight to ten dependent store-ack + load round trips -- 11.7 us of write-out against
+// an 8 us k loop, 4.3 us for the same tile without bias and residual (tools/timeline_probe.py, profiles/r4_timeline_before.txt).
+// The call sites of the training step need only a handful of chains, so each of them is a CLASS with a branch-free write-out:
+//   every global read of the tile (bias, residual or saved derivative or old C, for ALL steps of the thread) is requested by
+//   wo_prefetch() before the accumulators are parked -- its latency hides behind the LDS transpose -- and wo_apply<EPI>() is straight-line
+//   code: LDS read -> arithmetic -> store, no memory wait between the stores.
+// Everything else (dropout, fp32 residual streams, row maps, ragged N, split-K partials, ...) takes the generic path.
+enum { EPI_GENERIC = 0,
+       EPI_PLAIN,        // bias -> bf16                                   (QKV / K,V projections, plain data gradients)
+       EPI_RES,          // bias + bf16 residual -> bf16                   (attention out-proj, adaptor up, MLP proj; dgrad + skip gradient)
+       EPI_QGELU_GRAD,   // bias, QuickGELU value -> bf16 C, derivative -> bf16 pre_out          (ViT c_fc)
+       EPI_RELU2_GRAD,   // bias, squared-ReLU value -> C, derivative -> pre_out                 (adaptor down, resampler fc)
+       EPI_SAVED,        // x saved derivative (act_in) -> bf16            (data gradient through an activation)
+       EPI_F32 };        // alpha * acc -> fp32                            (weight gradients, single writer; accumulating calls: generic path --
+                         //                                                  their old C would cost 64 more prefetch registers per thread)
+constexpr int PH_ZERO_BIAS_FLOATS = 1 << 16;          // the library substitutes a device-resident zero vector for a null bias (fill_params)
+__device__ __forceinline__ int epi_classify(const GemmParams& p, bool splitk) {
+  const bool aligned = p.N >= 8 && (p.N % 8) == 0 && (p.ldc % 8) == 0 && (!p.act_in || (p.ld_act % 8) == 0) && (!p.residual || (p.ldr % 8) == 0) &&
+                       ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.pre_out) | reinterpret_cast<uintptr_t>(p.act_in) |
+                         reinterpret_cast<uintptr_t>(p.residual) | reinterpret_cast<uintptr_t>(p.bias_or_zero)) & 15) == 0;
+  if (!aligned || splitk || p.drop_p > 0.0f || p.rm_wo != 0 || !p.bias_or_zero) return EPI_GENERIC;
+  const bool plain_in = !p.pre_out && !p.act_in && p.act == PH_ACT_NONE;
+  if (p.out_f32) return (plain_in && !p.residual && !p.bias && !p.accumulate) ? EPI_F32 : EPI_GENERIC;
+  if (p.accumulate) return EPI_GENERIC;
+  if (p.act_in) return (p.act == PH_ACT_SAVED_GRAD && !p.pre_out && !p.residual && !p.bias) ? EPI_SAVED : EPI_GENERIC;
+  if (p.pre_out) {
+    if (!p.pre_grad || p.residual) return EPI_GENERIC;
+    return p.act == PH_ACT_QUICKGELU ? EPI_QGELU_GRAD : (p.act == PH_ACT_RELU2 ? EPI_RELU2_GRAD : EPI_GENERIC);
+  }
+  if (p.act != PH_ACT_NONE) return EPI_GENERIC;
+  if (p.residual) return p.res_f32 ? EPI_GENERIC : EPI_RES;
+  return EPI_PLAIN;
+}
+
+template <int BM, int BN, int NTHR>
+struct WoCfg {
+  static constexpr int CH = BN / 4, IT = BM * CH / (2 * NTHR);      // 16-B chunks per tile row; steps of 8 outputs per thread
+  static_assert(NTHR % (CH / 2) == 0 && IT >= 1, "write-out: a thread must keep its column block over its steps");
+};
+// the prefetched values are plain locals of the calling kernel (an aggregate holding them ended up in scratch memory)
+#define PH_WO_DECL(BM, BN, NTHR) bf16x8 wo_x[WoCfg<BM, BN, NTHR>::IT]; f32x4 wo_b0, wo_b1
+#define PH_WO_ARGS wo_x, wo_b0, wo_b1
+template <int BM, int BN, int NTHR>
+__device__ __forceinline__ void wo_prefetch(const int epi, const GemmParams& p, int m0, int n0, bf16x8 (&x)[WoCfg<BM, BN, NTHR>::IT],
+                                            f32x4& b0, f32x4& b1) {
+  constexpr int CH = BN / 4, IT = WoCfg<BM, BN, NTHR>::IT;
+  if (epi == EPI_GENERIC) return;
+  const int c = ((int)threadIdx.x % (CH / 2)) * 2;
+  const int n = (n0 + c * 4 + 8 <= p.N) ? n0 + c * 4 : 0;          // always a valid address: the loads are unconditional
+  b0 = *reinterpret_cast<const f32x4*>(p.bias_or_zero + n);          // (a zero vector when the call has no bias: no branch, no select)
+  b1 = *reinterpret_cast<const f32x4*>(p.bias_or_zero + n + 4);
+  if (epi == EPI_RES || epi == EPI_SAVED) {
+    const bf16* src = epi == EPI_RES ? p.residual : p.act_in;
+    const int ld = epi == EPI_RES ? p.ldr : p.ld_act;
+    static_for(std::make_integer_sequence<int, IT>{}, [&](auto uu) {
+      constexpr int u = decltype(uu)::value;
+      const int ml = (u * NTHR + (int)threadIdx.x) / (CH / 2);
+      x[u] = *reinterpret_cast<const bf16x8*>(src + (size_t)min(m0 + ml, p.M - 1) * ld + n);
+    });
+  }
+}
+__device__ __forceinline__ void wo_settle(f32x4& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void wo_settle(bf16x8& v) {
+  u32x4 t = __builtin_bit_cast(u32x4, v);
+  asm volatile("" : "+v"(t));
+  v = __builtin_bit_cast(bf16x8, t);
+}
+template <int EPI, int BM, int BN, int NTHR>
+__device__ __forceinline__ void wo_apply(PH_TL_PARAM const GemmParams& p, const float* cl, int m0, int n0, bf16x8 (&x)[WoCfg<BM, BN, NTHR>::IT],
+                                         f32x4& b0, f32x4& b1, const float* cl2) {
+  constexpr int CH = BN / 4, IT = WoCfg<BM, BN, NTHR>::IT;
+  // ONE wait for everything wo_prefetch requested (no store of this wave is in flight yet, so it waits for those reads only), then the
+  // values pass through an empty asm: to hipcc they are plain registers from here on.  Without this its waitcnt pass answers every use
+  // behind the conditional stores below with s_waitcnt vmcnt(0) -- the number of stores issued since the read is unknown to it -- and the
+  // wave stalls on its own previous store in every step.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wo_settle(b0); wo_settle(b1);
+  if constexpr (EPI == EPI_RES || EPI == EPI_SAVED) {
+    static_for(std::make_integer_sequence<int, IT>{}, [&](auto uu) { wo_settle(x[decltype(uu)::value]); });
+  }
+  PH_TL(6);
+  static_for(std::make_integer_sequence<int, IT>{}, [&](auto uu) {
+    constexpr int u = decltype(uu)::value;
+    const int id = u * NTHR + (int)threadIdx.x;
+    const int ml = id / (CH / 2), c = (id % (CH / 2)) * 2;
+    const int m = m0 + ml, n = n0 + c * 4;
+    const int sw = ml & (CH - 1);
+    f32x4 t0 = *reinterpret_cast<const f32x4*>(cl + ml * BN + ((c ^ sw) << 2));
+    f32x4 t1 = *reinterpret_cast<const f32x4*>(cl + ml * BN + (((c + 1) ^ sw) << 2));
+    if (cl2) {
+      t0 += *reinterpret_cast<const f32x4*>(cl2 + ml * BN + ((c ^ sw) << 2));
+      t1 += *reinterpret_cast<const f32x4*>(cl2 + ml * BN + (((c + 1) ^ sw) << 2));
+    }
+    float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+    const bool live = m < p.M && n < p.N;               // (N % 8 == 0 in every class: a live chunk is a whole chunk)
+    if constexpr (EPI == EPI_PLAIN || EPI == EPI_RES || EPI == EPI_QGELU_GRAD || EPI == EPI_RELU2_GRAD) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+    }
+    if constexpr (EPI == EPI_QGELU_GRAD || EPI == EPI_RELU2_GRAD) {
+      bf16x8 gq;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float y, g;
+        act_fwd_grad(EPI == EPI_QGELU_GRAD ? PH_ACT_QUICKGELU : PH_ACT_RELU2, v[e], y, g);
+        v[e] = y; gq[e] = f2bf(g);
+      }
+      if (live) *reinterpret_cast<bf16x8*>(p.pre_out + (size_t)m * p.ldc + n) = gq;
+    }
+    if constexpr (EPI == EPI_SAVED) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= bf2f(x[u][e]);
+    }
+    if constexpr (EPI == EPI_RES) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bf2f(x[u][e]);
+    }
+    if constexpr (EPI == EPI_F32) {
+      if (live) {
+        float* cp = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+        f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+        *reinterpret_cast<f32x4*>(cp) = o0;
+        *reinterpret_cast<f32x4*>(cp + 4) = o1;
+      }
+    } else {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+      if (live) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.C) + (size_t)m * p.ldc + n) = o;
+    }
+    if (u == 0) PH_TL(7);
+  });
+}
+// write-out of a parked tile by class (wave-uniform switch: one branch per tile)
+template <int BM, int BN, int NTHR>
+__device__ __forceinline__ void tile_writeout(PH_TL_PARAM const int epi, const GemmParams& p, const float* cl, int m0, int n0, bool splitk, bool drop,
+                                              const DropCtx& dc, bf16x8 (&x)[WoCfg<BM, BN, NTHR>::IT], f32x4& b0, f32x4& b1,
+                                              const float* cl2 = nullptr, int split_id = 0) {
+  switch (epi) {
+    case EPI_PLAIN: wo_apply<EPI_PLAIN, BM, BN, NTHR>(PH_TL_ARG p, cl, m0, n0, x, b0, b1, cl2); break;
+    case EPI_RES: wo_apply<EPI_RES, BM, BN, NTHR>(PH_TL_ARG p, cl, m0, n0, x, b0, b1, cl2); break;
+    case EPI_QGELU_GRAD: wo_apply<EPI_QGELU_GRAD, BM, BN, NTHR>(PH_TL_ARG p, cl, m0, n0, x, b0, b1, cl2); break;
+    case EPI_RELU2_GRAD: wo_apply<EPI_RELU2_GRAD, BM, BN, NTHR>(PH_TL_ARG p, cl, m0, n0, x, b0, b1, cl2); break;
+    case EPI_SAVED: wo_apply<EPI_SAVED, BM, BN, NTHR>(PH_TL_ARG p, cl, m0, n0, x, b0, b1, cl2); break;
+    case EPI_F32: wo_apply<EPI_F32, BM, BN, NTHR>(PH_TL_ARG p, cl, m0, n0, x, b0, b1, cl2); break;
+    default: tile_writeout_generic<BM, BN, NTHR>(PH_TL_ARG p, cl, m0, n0, splitk, drop, dc, cl2, split_id); break;
   }
 }
 
@@ -549,6 +683,16 @@ enum { PH_GEMM_CLS_128 = 0, PH_GEMM_CLS_64, PH_GEMM_CLS_KS2, PH_GEMM_CLS_BIG, PH
        PH_GEMM_CLS_SPLITK_REDUCE, PH_GEMM_CLS_COUNT };
 extern std::atomic<long long> g_gemm_counts[PH_GEMM_CLS_COUNT];
 inline void count_launch(int cls) { g_gemm_counts[cls].fetch_add(1, std::memory_order_relaxed); }
+
+// launchers of the register-staged kernels (gemm_kernels.h, instantiated by gemm_s128.hip / gemm_s64.hip / gemm_g128.hip / gemm_g64.hip)
+namespace reg {
+int launch_single_128(const GemmParams& p, int bn, int ta, int tb, int splits, hipStream_t s);      // 128x128 (bn = 128) or 128x64 tiles
+int launch_single_64(const GemmParams& p, int ta, int tb, int splits, hipStream_t s);               // 64x64 tiles
+int launch_ks2(const GemmParams& p, int tb, hipStream_t s);                                         // 64x64 tiles, k loop split inside the block
+// pf: 0 = depth-1 schedule, 1 = prefetch ring; conv: 0 plain, 1 gathered A (NN layout), 2 gathered B (TT layout)
+int launch_grouped_128(const GroupParams& g, int total, int max_blocks, int ta, int tb, int pf, int conv, hipStream_t s);
+int launch_grouped_64(const GroupParams& g, int total, int max_blocks, int ta, int tb, int pf, int conv, hipStream_t s);
+}  // namespace reg
 
 // launchers of the 256x128 kernels (gemm_big.hip); variant: 0 plain main loop, 4 ping-pong, 5 ping-pong + s_setprio
 namespace big {

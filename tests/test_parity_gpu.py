@@ -473,7 +473,7 @@ def _check_grads_against_golden(g, named_grads, tag):
 PROJ_SLACK = 1.8
 
 
-@pytest.mark.parametrize('name', ['base_b8', 'zbase_b4', 'large_vqa_b1', 'large_vqa_b1+big', 'base_b32'])
+@pytest.mark.parametrize('name', ['base_b8', 'zbase_b4', 'large_vqa_b1', 'large_vqa_b1+big', 'base_b32', 'large_vqa_b4'])
 def test_trainer_hipgraph_step_matches_reference_golden(name):
     force_big = name.endswith('+big')           # LARGE shapes (H = 1024, 24 + 24 layers, S = 1220) through the 256x128 ping-pong kernel:
     name = name.split('+')[0]                   # at B = 1 the cost model never picks it, config 5's bs16 does
@@ -508,6 +508,10 @@ def _hipgraph_step_vs_golden(name, force_big=False):
     print(name, 'GEMM launches by kernel class during warm-up + capture:', by_class)
     if force_big:
         assert by_class['big'] > 0, by_class
+    if name == 'large_vqa_b4':
+        # config 5 at a batch where the dispatch itself (no ph_gemm_tuning override) puts the LARGE shapes -- M = 4 x 1220 rows, K = 1024 /
+        # 4096, ragged text -- on the 256x128 ping-pong kernel and its grouped weight-gradient form (round-3 review: B = 1 had to force them)
+        assert by_class['big'] > 0 and by_class['big_grouped'] > 0, by_class
     if name == 'base_b32':
         # the benchmark configuration itself: the 256x128 ping-pong kernel (M = 8320: N = 768 launches and long reductions) and its
         # grouped persistent form (long-reduction weight gradients) must be ON the path this fixture pins, not just unit-tested

@@ -1,6 +1,6 @@
 """Where does a GEMM launch spend its time?  s_memtime stamps from the -DPH_TIMELINE diagnostics build (never the product library):
 
-    python tools/build_variant.py tl gemm.hip:-DPH_TIMELINE gemm_big.hip:-DPH_TIMELINE
+    python tools/build_variant.py tl gemm_s64.hip:-DPH_TIMELINE gemm_big.hip:-DPH_TIMELINE [attention.hip:-DPH_TIMELINE norm.hip:-DPH_TIMELINE]
     PRISMER_HIP_LIB=prismer_amd/lib/libprismer_hip_tl.so python tools/timeline_probe.py
 
 Per block and thread group (waves 0 / 4 of the 256x128 kernel, thread groups 0 / 1 of the k-split kernel) the kernels keep
@@ -22,8 +22,9 @@ BF = torch.bfloat16
 SLOTS, BLOCKS = 16, 4096
 lib = _lib.lib
 for f in ('ph_tl_fetch_big', 'ph_tl_fetch_gemm', 'ph_tl_fetch_attn', 'ph_tl_fetch_norm'):
-    getattr(lib, f).restype = C.c_int
-    getattr(lib, f).argtypes = [C.c_void_p, C.c_int, C.c_int]
+    if hasattr(lib, f):                                  # (only the translation units built with -DPH_TIMELINE export theirs)
+        getattr(lib, f).restype = C.c_int
+        getattr(lib, f).argtypes = [C.c_void_p, C.c_int, C.c_int]
 
 FLUSH = torch.empty(768 << 20, dtype=torch.uint8, device='cuda')     # larger than L2 + the 256 MB Infinity Cache
 
@@ -169,25 +170,31 @@ def chain_case(name, call, n=40):
 
 if __name__ == '__main__':
     torch.manual_seed(0)
-    _lib.lib.ph_gemm_tuning(5, 128)
+    modes = [int(m) for m in os.environ.get('TL_BIG_MODES', '5,6').split(',')]       # 5: ping-pong, 6: ping-pong with the LEAN tail
+    for mode in modes:
+        _lib.lib.ph_gemm_tuning(mode, 128)
+        for cold in (False, True):
+            tag = f'm{mode} '
+            run(tag + 'big out-proj 8320x768x768 +bias +res', 'ph_tl_fetch_big', 8320, 768, 768, cold, residual=True)
+            run(tag + 'big dgrad 8320x768x768 tb', 'ph_tl_fetch_big', 8320, 768, 768, cold, tb=True, bias=False)
+            run(tag + 'big proj 8320x768x3072 +res', 'ph_tl_fetch_big', 8320, 768, 3072, cold, residual=True)
+            run(tag + 'big qkv 8320x2304x768', 'ph_tl_fetch_big', 8320, 2304, 768, cold)
+            run(tag + 'big c_fc 8192x3072x768 qgelu + grad', 'ph_tl_fetch_big', 8192, 3072, 768, cold, act=ACT_QUICKGELU, pre=True)
+            run(tag + 'big dgrad c_proj 8192x3072x768 tb *saved', 'ph_tl_fetch_big', 8192, 3072, 768, cold, tb=True, bias=False, act_in=True)
+            run(tag + 'big tiny-K 8320x768x128 +res (fixed cost alone)', 'ph_tl_fetch_big', 8320, 768, 128, cold, residual=True)
+    _lib.lib.ph_gemm_tuning(modes[0], 128)
     for cold in (False, True):
-        run('big out-proj 8320x768x768 +bias +res', 'ph_tl_fetch_big', 8320, 768, 768, cold, residual=True)
-        run('big dgrad 8320x768x768 tb', 'ph_tl_fetch_big', 8320, 768, 768, cold, tb=True, bias=False)
-        run('big proj 8320x768x3072 +res', 'ph_tl_fetch_big', 8320, 768, 3072, cold, residual=True)
-        run('big qkv 8320x2304x768', 'ph_tl_fetch_big', 8320, 2304, 768, cold)
-        run('big c_fc 8192x3072x768 qgelu + grad', 'ph_tl_fetch_big', 8192, 3072, 768, cold, act=ACT_QUICKGELU, pre=True)
-        run('big dgrad c_proj 8192x3072x768 tb *saved', 'ph_tl_fetch_big', 8192, 3072, 768, cold, tb=True, bias=False, act_in=True)
         run('ks2 dec dense 960x768x768 +bias +drop +res32', 'ph_tl_fetch_gemm', 960, 768, 768, cold, residual=True, f32res=True, drop=True)
         run('ks2 dec dgrad 960x768x768 tb', 'ph_tl_fetch_gemm', 960, 768, 768, cold, tb=True, bias=False)
         run('ks2 dec fc 960x3072x768 gelu + grad', 'ph_tl_fetch_gemm', 960, 3072, 768, cold, act=ACT_GELU, pre=True)
         run('ks2 dec proj 960x768x3072 +res32', 'ph_tl_fetch_gemm', 960, 768, 3072, cold, residual=True, f32res=True, drop=True)
         run('64 dec qkv 960x2304x768', 'ph_tl_fetch_gemm', 960, 2304, 768, cold)
-        run('big tiny-K 8320x768x128 +res (fixed cost alone)', 'ph_tl_fetch_big', 8320, 768, 128, cold, residual=True)
-        attn_case('attn ViT 32x12 S=260 dh64 plain', 32, 12, 260, 260, 64, cold)
-        attn_case('attn dec self 32x12 T=30 causal+mask+drop', 32, 12, 30, 30, 64, cold, causal=True, masked=True, drop=True)
-        attn_case('attn dec cross 32x12 T=30 S=260 drop', 32, 12, 30, 260, 64, cold, drop=True)
-        ln_case('ln dec 960x768 f32 in, bf16+f32 out', 960, 768, cold, True)
-        ln_case('ln vit 8320x768 bf16', 8320, 768, cold, False)
+        if os.environ.get('TL_SMALL', '1') != '0':
+            attn_case('attn ViT 32x12 S=260 dh64 plain', 32, 12, 260, 260, 64, cold)
+            attn_case('attn dec self 32x12 T=30 causal+mask+drop', 32, 12, 30, 30, 64, cold, causal=True, masked=True, drop=True)
+            attn_case('attn dec cross 32x12 T=30 S=260 drop', 32, 12, 30, 260, 64, cold, drop=True)
+            ln_case('ln dec 960x768 f32 in, bf16+f32 out', 960, 768, cold, True)
+            ln_case('ln vit 8320x768 bf16', 8320, 768, cold, False)
     # per-launch cost in a dependent chain under graph replay (what the step pays): same launches, no stamps read
     x32 = torch.randn(960, 768, device='cuda'); g1, b1 = torch.ones(768, device='cuda'), torch.zeros(768, device='cuda')
     y16, y32 = torch.empty(960, 768, dtype=BF, device='cuda'), torch.empty(960, 768, device='cuda')
@@ -196,6 +203,17 @@ if __name__ == '__main__':
     o32 = torch.empty(960, 768, device='cuda')
     chain_case('ks2 960x768x768 +bias+res32 -> f32', lambda: ops.gemm(a, w, out=o32, out_f32=True, bias=bias, residual=x32))
     a8 = torch.randn(8320, 768, device='cuda').to(BF); r8 = torch.randn(8320, 768, device='cuda').to(BF); o8 = torch.empty(8320, 768, dtype=BF, device='cuda')
-    chain_case('big 8320x768x768 +bias+res', lambda: ops.gemm(a8, w, out=o8, bias=bias, residual=r8))
+    a83 = torch.randn(8320, 3072, device='cuda').to(BF); w3 = (torch.randn(768, 3072, device='cuda') * 0.05).to(BF)
+    wf = (torch.randn(3072, 768, device='cuda') * 0.05).to(BF); bf_ = torch.zeros(3072, device='cuda')
+    of = torch.empty(8192, 3072, dtype=BF, device='cuda'); pf = torch.empty(8192, 3072, dtype=BF, device='cuda')
+    wq = (torch.randn(2304, 768, device='cuda') * 0.05).to(BF); bq = torch.zeros(2304, device='cuda'); oq = torch.empty(8320, 2304, dtype=BF, device='cuda')
+    for mode in modes:
+        _lib.lib.ph_gemm_tuning(mode, 128)
+        chain_case(f'm{mode} big 8320x768x768 +bias+res', lambda: ops.gemm(a8, w, out=o8, bias=bias, residual=r8))
+        chain_case(f'm{mode} big 8320x768x768 plain', lambda: ops.gemm(a8, w, out=o8))
+        chain_case(f'm{mode} big 8320x768x3072 +bias+res', lambda: ops.gemm(a83, w3, out=o8, bias=bias, residual=r8))
+        chain_case(f'm{mode} big c_fc 8192x3072x768 qgelu+grad', lambda: ops.gemm(a8[:8192], wf, out=of, bias=bf_, act=ACT_QUICKGELU, pre_out=pf, pre_grad=True))
+        chain_case(f'm{mode} big qkv 8320x2304x768 +bias', lambda: ops.gemm(a8, wq, out=oq, bias=bq))
+    _lib.lib.ph_gemm_tuning(modes[0], 128)
     empty = torch.empty(64, device='cuda')
     chain_case('torch fill_ of 64 floats (boundary of a trivial kernel)', lambda: empty.fill_(1.0))
