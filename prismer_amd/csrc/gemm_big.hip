@@ -167,11 +167,15 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
     PH_TL(2);
     if (grp) __builtin_amdgcn_s_barrier();                     // group 1 idles through phase 0
     int st = 0;
-    for (int t = 0; t < nk; ++t) {
+    // one k-tile of the schedule; NEWER: tile t+2 exists, ISS0 / ISS1: group 0 / 1 has a tile to request in M(t), LAST: t == nk - 1.
+    // The flags are compile-time so that the steady-state loop carries no branch on t (the first LEAN build tested them inside the loop
+    // and lost 0.1 us per k-tile to it: k loop 8.0 -> 9.3 us at K = 768, profiles/r4_timeline_after_epilogue_classes.txt); the last
+    // three k-tiles of a LEAN launch are peeled copies of the body.
+    auto ktile = [&](const int t, auto newer_c, auto iss0_c, auto iss1_c, auto last_c) {
+      constexpr bool NEWER = decltype(newer_c)::value, ISS0 = decltype(iss0_c)::value, ISS1 = decltype(iss1_c)::value, LAST = decltype(last_c)::value;
       // R(t)
       const char* la = smem + st * STAGE;
       const char* lb = la + A_BYTES;
-      const bool newer = !LEAN || t + 2 < nk;                  // tile t+2 exists (group 1 requested it in M(t-1), group 0 does in M(t))
       bf16x8 fx[BK / 16][2], fw[BK / 16][2];
 #pragma unroll
       for (int kk = 0; kk < BK / 16; ++kk) {
@@ -181,7 +185,7 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
         for (int j = 0; j < 2; ++j) fw[kk][j] = TB ? frag_ks_dma<256>(lb, wn * 64 + j * 32, kk, lane) : frag_kc(lb, wn * 64 + j * 32, kk, lane);
       }
       if (grp) {
-        if (newer) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        if constexpr (NEWER) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -192,7 +196,8 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
       // M(t)
       int sn = st + 2 + grp; sn = sn >= 3 ? sn - 3 : sn;
       if (VARIANT & 1) __builtin_amdgcn_s_setprio(1);
-      if (!LEAN || t + 2 + grp < nk) issue(min(t + 2 + grp, nk - 1), sn);
+      if constexpr (ISS0 && ISS1) issue(min(t + 2 + grp, nk - 1), sn);
+      else if constexpr (ISS0) { if (!grp) issue(min(t + 2, nk - 1), sn); }
 #pragma unroll
       for (int kk = 0; kk < BK / 16; ++kk)
 #pragma unroll
@@ -201,13 +206,24 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[kk][j], fx[kk][i], acc[i][j], 0, 0, 0);
       if (VARIANT & 1) __builtin_amdgcn_s_setprio(0);
       if (!grp) {
-        if (newer) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if constexpr (NEWER) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (!(LEAN && grp && t == nk - 1)) __builtin_amdgcn_s_barrier();
+      if constexpr (LAST) { if (!grp) __builtin_amdgcn_s_barrier(); }       // (LEAN: group 1 skips the barrier behind its last M phase)
+      else __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       st = st + 1 == 3 ? 0 : st + 1;
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+    if constexpr (!LEAN) {
+      for (int t = 0; t < nk; ++t) ktile(t, T_{}, T_{}, T_{}, F_{});          // clamped surplus requests keep every wait at vmcnt(6)
+    } else {
+      int t = 0;
+      for (; t + 3 < nk; ++t) ktile(t, T_{}, T_{}, T_{}, F_{});               // tiles t+2 (group 0) and t+3 (group 1) exist
+      if (nk >= 3) { ktile(t, T_{}, T_{}, F_{}, F_{}); ++t; }                 // t = nk-3: only group 0 still has a tile to request
+      ktile(t, F_{}, F_{}, F_{}, F_{}); ++t;                                  // t = nk-2: the newest request is the tile the wave needs
+      ktile(t, F_{}, F_{}, F_{}, T_{});                                       // t = nk-1
     }
     PH_TL(3);
     if (!LEAN && !grp) __builtin_amdgcn_s_barrier();           // group 0 idles through the last phase (group 1's M(nk-1))
@@ -296,12 +312,14 @@ int launch_grouped(const GroupParams& g, int total, hipStream_t s) {
 
 namespace big {
 int launch_single(const GemmParams& p, int variant, bool ta, bool tb, hipStream_t s) {
-  if (ta) return launch<4, true, true>(p, s);                      // weight-gradient layout: ping-pong only
+  if (ta) return variant == 5 ? launch<12, true, true>(p, s) : launch<4, true, true>(p, s);      // weight-gradient layout: ping-pong only
   // variant 5 (ping-pong + s_setprio, measured negative in round 2) gave its slot to the LEAN tail (VARIANT 12) in round 4
   if (tb) return variant == 0 ? launch<0, false, true>(p, s) : variant == 5 ? launch<12, false, true>(p, s) : launch<4, false, true>(p, s);
   return variant == 0 ? launch<0, false, false>(p, s) : variant == 5 ? launch<12, false, false>(p, s) : launch<4, false, false>(p, s);
 }
-int launch_grouped_wgrad(const GroupParams& g, int total, hipStream_t s) { return launch_grouped<4, true, true>(g, total, s); }
+int launch_grouped_wgrad(const GroupParams& g, int total, int variant, hipStream_t s) {
+  return variant == 5 ? launch_grouped<12, true, true>(g, total, s) : launch_grouped<4, true, true>(g, total, s);
+}
 }  // namespace big
 #ifdef PH_TIMELINE
 extern "C" int ph_tl_fetch_big(unsigned long long* host, int n, int reset) {

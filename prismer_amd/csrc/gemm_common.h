@@ -412,9 +412,9 @@ __device__ __forceinline__ void epi_apply8(const GemmParams& p, int m, int n, fl
 
 // Row-wise write-out of a BM x BN fp32 tile parked in LDS (16-B chunks XOR-swizzled by the row): consecutive lanes own
 // consecutive 16/32-B pieces of one output row for every load / store of the fused epilogue chain.
-template <int BM, int BN, int NTHR, int GCAP = 4>      // GCAP: cap on the prefetch group (register budget of the caller)
+template <int BM, int BN, int NTHR, int NPART = 1, int GCAP = 4>      // NPART: partial tiles to sum (intra-block k split); GCAP: cap on the prefetch group
 __device__ __forceinline__ void tile_writeout_generic(PH_TL_PARAM const GemmParams& p, const float* cl, int m0, int n0, bool splitk, bool drop,
-                                              const DropCtx& dc, const float* cl2 = nullptr, int split_id = 0) {   // cl2: second partial tile to add (KS = 2); split_id: workspace slice of a split-K block
+                                              const DropCtx& dc, int split_id = 0) {   // split_id: workspace slice of a split-K block; the NPART partial tiles lie back to back at cl
   constexpr int CH = BN / 4;                       // 16-B chunks per tile row
   // fast path: 8 outputs per thread per step (16-B loads/stores) when every leading dimension / pointer allows it
   const bool vec8 = !(splitk) && p.N >= 8 && (p.ldc % 8) == 0 && (!p.act_in || (p.ld_act % 8) == 0) && (!p.residual || (p.ldr % 8) == 0) &&
@@ -451,9 +451,10 @@ __device__ __forceinline__ void tile_writeout_generic(PH_TL_PARAM const GemmPara
         const int sw = ml & (CH - 1);
         f32x4 t0 = *reinterpret_cast<const f32x4*>(cl + ml * BN + ((c ^ sw) << 2));
         f32x4 t1 = *reinterpret_cast<const f32x4*>(cl + ml * BN + (((c + 1) ^ sw) << 2));
-        if (cl2) {
-          t0 += *reinterpret_cast<const f32x4*>(cl2 + ml * BN + ((c ^ sw) << 2));
-          t1 += *reinterpret_cast<const f32x4*>(cl2 + ml * BN + (((c + 1) ^ sw) << 2));
+#pragma unroll
+        for (int q = 1; q < NPART; ++q) {
+          t0 += *reinterpret_cast<const f32x4*>(cl + q * BM * BN + ml * BN + ((c ^ sw) << 2));
+          t1 += *reinterpret_cast<const f32x4*>(cl + q * BM * BN + ml * BN + (((c + 1) ^ sw) << 2));
         }
         if (m < p.M && n + 8 <= p.N) {
           float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
@@ -473,7 +474,8 @@ __device__ __forceinline__ void tile_writeout_generic(PH_TL_PARAM const GemmPara
       const int ml = id / CH, c = id % CH;
       const int m = m0 + ml, n = n0 + c * 4;
       f32x4 t = *reinterpret_cast<const f32x4*>(cl + ml * BN + ((c ^ (ml & (CH - 1))) << 2));
-      if (cl2) t += *reinterpret_cast<const f32x4*>(cl2 + ml * BN + ((c ^ (ml & (CH - 1))) << 2));
+#pragma unroll
+      for (int q = 1; q < NPART; ++q) t += *reinterpret_cast<const f32x4*>(cl + q * BM * BN + ml * BN + ((c ^ (ml & (CH - 1))) << 2));
       float v[4] = {t[0], t[1], t[2], t[3]};
       if (m < p.M && n < p.N) epilogue_store(p, m, n, v, splitk, drop, dc, split_id);
     }
@@ -552,9 +554,9 @@ __device__ __forceinline__ void wo_settle(bf16x8& v) {
   asm volatile("" : "+v"(t));
   v = __builtin_bit_cast(bf16x8, t);
 }
-template <int EPI, int BM, int BN, int NTHR>
+template <int EPI, int BM, int BN, int NTHR, int NPART>
 __device__ __forceinline__ void wo_apply(PH_TL_PARAM const GemmParams& p, const float* cl, int m0, int n0, bf16x8 (&x)[WoCfg<BM, BN, NTHR>::IT],
-                                         f32x4& b0, f32x4& b1, const float* cl2) {
+                                         f32x4& b0, f32x4& b1) {
   constexpr int CH = BN / 4, IT = WoCfg<BM, BN, NTHR>::IT;
   // ONE wait for everything wo_prefetch requested (no store of this wave is in flight yet, so it waits for those reads only), then the
   // values pass through an empty asm: to hipcc they are plain registers from here on.  Without this its waitcnt pass answers every use
@@ -574,9 +576,10 @@ __device__ __forceinline__ void wo_apply(PH_TL_PARAM const GemmParams& p, const 
     const int sw = ml & (CH - 1);
     f32x4 t0 = *reinterpret_cast<const f32x4*>(cl + ml * BN + ((c ^ sw) << 2));
     f32x4 t1 = *reinterpret_cast<const f32x4*>(cl + ml * BN + (((c + 1) ^ sw) << 2));
-    if (cl2) {
-      t0 += *reinterpret_cast<const f32x4*>(cl2 + ml * BN + ((c ^ sw) << 2));
-      t1 += *reinterpret_cast<const f32x4*>(cl2 + ml * BN + (((c + 1) ^ sw) << 2));
+#pragma unroll
+    for (int q = 1; q < NPART; ++q) {
+      t0 += *reinterpret_cast<const f32x4*>(cl + q * BM * BN + ml * BN + ((c ^ sw) << 2));
+      t1 += *reinterpret_cast<const f32x4*>(cl + q * BM * BN + ml * BN + (((c + 1) ^ sw) << 2));
     }
     float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
     const bool live = m < p.M && n < p.N;               // (N % 8 == 0 in every class: a live chunk is a whole chunk)
@@ -619,18 +622,17 @@ __device__ __forceinline__ void wo_apply(PH_TL_PARAM const GemmParams& p, const 
   });
 }
 // write-out of a parked tile by class (wave-uniform switch: one branch per tile)
-template <int BM, int BN, int NTHR>
+template <int BM, int BN, int NTHR, int NPART = 1>
 __device__ __forceinline__ void tile_writeout(PH_TL_PARAM const int epi, const GemmParams& p, const float* cl, int m0, int n0, bool splitk, bool drop,
-                                              const DropCtx& dc, bf16x8 (&x)[WoCfg<BM, BN, NTHR>::IT], f32x4& b0, f32x4& b1,
-                                              const float* cl2 = nullptr, int split_id = 0) {
+                                              const DropCtx& dc, bf16x8 (&x)[WoCfg<BM, BN, NTHR>::IT], f32x4& b0, f32x4& b1, int split_id = 0) {
   switch (epi) {
-    case EPI_PLAIN: wo_apply<EPI_PLAIN, BM, BN, NTHR>(PH_TL_ARG p, cl, m0, n0, x, b0, b1, cl2); break;
-    case EPI_RES: wo_apply<EPI_RES, BM, BN, NTHR>(PH_TL_ARG p, cl, m0, n0, x, b0, b1, cl2); break;
-    case EPI_QGELU_GRAD: wo_apply<EPI_QGELU_GRAD, BM, BN, NTHR>(PH_TL_ARG p, cl, m0, n0, x, b0, b1, cl2); break;
-    case EPI_RELU2_GRAD: wo_apply<EPI_RELU2_GRAD, BM, BN, NTHR>(PH_TL_ARG p, cl, m0, n0, x, b0, b1, cl2); break;
-    case EPI_SAVED: wo_apply<EPI_SAVED, BM, BN, NTHR>(PH_TL_ARG p, cl, m0, n0, x, b0, b1, cl2); break;
-    case EPI_F32: wo_apply<EPI_F32, BM, BN, NTHR>(PH_TL_ARG p, cl, m0, n0, x, b0, b1, cl2); break;
-    default: tile_writeout_generic<BM, BN, NTHR>(PH_TL_ARG p, cl, m0, n0, splitk, drop, dc, cl2, split_id); break;
+    case EPI_PLAIN: wo_apply<EPI_PLAIN, BM, BN, NTHR, NPART>(PH_TL_ARG p, cl, m0, n0, x, b0, b1); break;
+    case EPI_RES: wo_apply<EPI_RES, BM, BN, NTHR, NPART>(PH_TL_ARG p, cl, m0, n0, x, b0, b1); break;
+    case EPI_QGELU_GRAD: wo_apply<EPI_QGELU_GRAD, BM, BN, NTHR, NPART>(PH_TL_ARG p, cl, m0, n0, x, b0, b1); break;
+    case EPI_RELU2_GRAD: wo_apply<EPI_RELU2_GRAD, BM, BN, NTHR, NPART>(PH_TL_ARG p, cl, m0, n0, x, b0, b1); break;
+    case EPI_SAVED: wo_apply<EPI_SAVED, BM, BN, NTHR, NPART>(PH_TL_ARG p, cl, m0, n0, x, b0, b1); break;
+    case EPI_F32: wo_apply<EPI_F32, BM, BN, NTHR, NPART>(PH_TL_ARG p, cl, m0, n0, x, b0, b1); break;
+    default: tile_writeout_generic<BM, BN, NTHR, NPART>(PH_TL_ARG p, cl, m0, n0, splitk, drop, dc, split_id); break;
   }
 }
 
@@ -694,11 +696,11 @@ int launch_grouped_128(const GroupParams& g, int total, int max_blocks, int ta, 
 int launch_grouped_64(const GroupParams& g, int total, int max_blocks, int ta, int tb, int pf, int conv, hipStream_t s);
 }  // namespace reg
 
-// launchers of the 256x128 kernels (gemm_big.hip); variant: 0 plain main loop, 4 ping-pong, 5 ping-pong + s_setprio
+// launchers of the 256x128 kernels (gemm_big.hip); variant: 0 plain main loop, 4 ping-pong, 5 ping-pong with the LEAN tail
 namespace big {
 constexpr int BM = 256, BN = 128;
 int launch_single(const GemmParams& p, int variant, bool ta, bool tb, hipStream_t s);
-int launch_grouped_wgrad(const GroupParams& g, int total, hipStream_t s);      // A = [K,M], B = [K,N], ping-pong, persistent grid
+int launch_grouped_wgrad(const GroupParams& g, int total, int variant, hipStream_t s);      // A = [K,M], B = [K,N], ping-pong, persistent grid
 }  // namespace big
 
 }  // namespace phg

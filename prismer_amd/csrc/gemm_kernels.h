@@ -19,7 +19,9 @@ namespace {
 template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0, bool XCD_REMAP = true, int KS = 1>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int block_id, const int kt_begin, const int kt_end, const bool splitk,
                                           const int split_id = 0) {
-  static_assert(KS == 1 || (KS == 2 && CONV == 0 && PF > 1), "intra-block k split: plain ring kernels only");
+  static_assert(KS == 1 || (KS == 2 && CONV == 0 && PF > 1), "intra-block k split: plain ring kernels only");   // (KS = 4, 1024 threads:
+  // built and measured in round 4 -- every M = 960 launch 1 us SLOWER than KS = 2, profiles/r4_probe_ks4.txt: sixteen waves share one
+  // block-wide barrier per k-tile and the LDS write/read passes of four groups; the code below stays generic in KS)
   static_assert(CONV == 0 || (CONV == 1 && !TA && !TB) || (CONV == 2 && TA && TB), "conv gather: A of an NN problem or B of a TT problem");
   constexpr int WM = BM / 2, WN = BN / 2;   // wave tile
   constexpr int TM = WM / 32, TN = WN / 32; // 32x32 MFMA tiles per wave
@@ -47,8 +49,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int block_i
   int m0 = tm * BM, n0 = tn * BN;
   if (kt_begin >= kt_end) return;
 
-  const int tid = KS == 2 ? (int)(threadIdx.x & 255) : (int)threadIdx.x;
-  const int grp = KS == 2 ? (int)(threadIdx.x >> 8) : 0;
+  const int tid = KS > 1 ? (int)(threadIdx.x & 255) : (int)threadIdx.x;
+  const int grp = KS > 1 ? (int)(threadIdx.x >> 8) : 0;
   int lane = tid & 63, wave = tid >> 6;
   int wm = wave >> 1, wn = wave & 1;
   char* const smem_g = smem + grp * 2 * STAGE;          // this thread group's two stage buffers
@@ -188,7 +190,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int block_i
   // stage buffers, 16-B chunks XOR-swizzled by the row so both sides are conflict-free) and re-read row-wise: 32
   // consecutive lanes then own 256 contiguous bytes of one output row for every load/store of the fused epilogue.
   PH_TL(3);
-  constexpr int WO_THR = KS == 2 ? 512 : 256;
+  constexpr int WO_THR = KS > 1 ? 512 : 256;
   const int epi = epi_classify(p, splitk);
   PH_WO_DECL(BM, BN, WO_THR);
   DropCtx dc;
@@ -212,12 +214,13 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int block_i
   // every read of the fused chain for ALL steps of this thread, requested before its first store (epilogue classes, gemm_common.h).  These
   // kernels run two blocks per CU on a 256-register budget: the reads are requested after the accumulators are parked (64 registers
   // freed) and their latency is covered by the co-resident block; the one-block-per-CU 256x128 kernel requests them before parking.
-  wo_prefetch<BM, BN, WO_THR>(epi, p, m0, n0, PH_WO_ARGS);
-  if constexpr (KS == 2) {
-    static_assert(2 * BM * BN * 4 <= 4 * STAGE, "two parked fp32 tiles must fit the four stage buffers");
-    tile_writeout<BM, BN, 512>(PH_TL_ARG epi, p, reinterpret_cast<float*>(smem), m0, n0, splitk, drop, dc, PH_WO_ARGS, reinterpret_cast<float*>(smem) + BM * BN);
+  if constexpr (KS > 1) {
+    static_assert(KS * BM * BN * 4 <= 2 * KS * STAGE, "the parked fp32 partial tiles must fit the stage buffers");
+    wo_prefetch<BM, BN, WO_THR>(epi, p, m0, n0, PH_WO_ARGS);
+    tile_writeout<BM, BN, 512, KS>(PH_TL_ARG epi, p, reinterpret_cast<float*>(smem), m0, n0, splitk, drop, dc, PH_WO_ARGS);
   } else {
-    tile_writeout<BM, BN, 256>(PH_TL_ARG epi, p, cl, m0, n0, splitk, drop, dc, PH_WO_ARGS, nullptr, split_id);
+    wo_prefetch<BM, BN, WO_THR>(epi, p, m0, n0, PH_WO_ARGS);
+    tile_writeout<BM, BN, 256, 1>(PH_TL_ARG epi, p, cl, m0, n0, splitk, drop, dc, PH_WO_ARGS, split_id);
     if (p.col_stats) tile_colstats<BM, BN, 256>(p, cl, m0, n0);
   }
   PH_TL(8);
@@ -280,7 +283,6 @@ template <bool TA, bool TB>
 __global__ __launch_bounds__(512) void gemm_ks2_kernel(GemmParams p) {
   gemm_tile<64, 64, TA, TB, PH_RING64, 0, true, 2>(p, blockIdx.x, 0, p.K / BK, false);
 }
-
 template <bool TA, bool TB>
 int launch_ks2(const GemmParams& p, hipStream_t s) {
   constexpr int smem = 4 * ((TA ? TileBytes<64>::ks : TileBytes<64>::kc) + (TB ? TileBytes<64>::ks : TileBytes<64>::kc));

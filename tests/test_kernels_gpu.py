@@ -181,7 +181,7 @@ def test_gemm_big_tile_lds_dma_kernel(ops, M, N, K, act, mode, trans_b):
             assert rel_fro(pre_big, z) < 6e-3 and rel_fro(big, fn(z) + res.float()) < 6e-3, rep
             assert rel_fro(big, old.float()) < 2e-3 and rel_fro(pre_big, pre_old.float()) < 2e-3, rep
     finally:
-        _lib.lib.ph_gemm_tuning(5, 128)
+        _lib.lib.ph_gemm_tuning(*_lib.GEMM_BIG_DEFAULT)
 
 
 @pytest.mark.parametrize('shapes', [

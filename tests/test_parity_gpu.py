@@ -479,11 +479,11 @@ def test_trainer_hipgraph_step_matches_reference_golden(name):
     name = name.split('+')[0]                   # at B = 1 the cost model never picks it, config 5's bs16 does
     from prismer_amd import _lib as _l
     if force_big:
-        _l.lib.ph_gemm_tuning(5, 1)
+        _l.lib.ph_gemm_tuning(_l.GEMM_BIG_DEFAULT[0], 1)
     try:
         _hipgraph_step_vs_golden(name, force_big)
     finally:
-        _l.lib.ph_gemm_tuning(5, 128)
+        _l.lib.ph_gemm_tuning(*_l.GEMM_BIG_DEFAULT)
 
 
 def _hipgraph_step_vs_golden(name, force_big=False):

@@ -166,8 +166,13 @@ def test_model_constants_match_the_kernel_source():
     assert body.count(f'"s_waitcnt vmcnt({DMA_PER_TILE}) lgkmcnt(0)"') == 1       # group 1 at the end of R(t)
     assert body.count('"s_waitcnt vmcnt(0) lgkmcnt(0)"') == 1 and body.count('"s_waitcnt vmcnt(0)"') == 2     # the same two waits without a newer tile (LEAN) + the non-LEAN drain
     assert body.count(f'"s_waitcnt vmcnt({2 * DMA_PER_TILE})"') == 1              # group 1 prologue (three tiles issued)
-    assert 'if (!LEAN || t + 2 + grp < nk) issue(min(t + 2 + grp, nk - 1), sn);' in body and 'int sn = st + 2 + grp' in body
-    assert 'const bool newer = !LEAN || t + 2 < nk;' in body
+    assert 'if constexpr (ISS0 && ISS1) issue(min(t + 2 + grp, nk - 1), sn);' in body and 'int sn = st + 2 + grp' in body
+    assert 'else if constexpr (ISS0) { if (!grp) issue(min(t + 2, nk - 1), sn); }' in body
+    # the peeled LEAN tail: steady state while tile t+3 exists, then nk-3 (group 0 only requests), nk-2 and nk-1 (nobody requests, vmcnt(0))
+    assert 'for (; t + 3 < nk; ++t) ktile(t, T_{}, T_{}, T_{}, F_{});' in body
+    assert 'if (nk >= 3) { ktile(t, T_{}, T_{}, F_{}, F_{}); ++t; }' in body
+    assert 'ktile(t, F_{}, F_{}, F_{}, F_{}); ++t;' in body and 'ktile(t, F_{}, F_{}, F_{}, T_{});' in body
+    assert 'for (int t = 0; t < nk; ++t) ktile(t, T_{}, T_{}, T_{}, F_{});' in body                  # non-LEAN: every k-tile alike
     assert 'if (grp) __builtin_amdgcn_s_barrier();' in body and 'if (!LEAN && !grp) __builtin_amdgcn_s_barrier();' in body
-    assert 'if (!(LEAN && grp && t == nk - 1)) __builtin_amdgcn_s_barrier();' in body
-    assert body.count('__builtin_amdgcn_s_barrier()') == 5                        # B0, skew, end of R, end of M, trailing
+    assert 'if constexpr (LAST) { if (!grp) __builtin_amdgcn_s_barrier(); }' in body
+    assert body.count('__builtin_amdgcn_s_barrier()') == 6                        # B0, skew, end of R, end of M (two forms), trailing

@@ -101,7 +101,7 @@ if __name__ == '__main__':
         case('resampler kv 39680x1536x768', 39680, 1536, 768)
         case('cross kv all 8320x18432x768', 8320, 18432, 768)
         case('vit out 8320x768x768 +res', 8320, 768, 768, residual=True)
-        _lib.lib.ph_gemm_tuning(5, 128)
+        _lib.lib.ph_gemm_tuning(*_lib.GEMM_BIG_DEFAULT)
         sys.exit(0)
     if os.environ.get('BIG_ONLY_FC'):
         case('vit fc 8320x3072x768 qgelu+pre', 8320, 3072, 768, act=ACT_QUICKGELU, pre=True)
@@ -124,4 +124,4 @@ if __name__ == '__main__':
     case('ragged 8300x2312x704', 8300, 2312, 704, act=ACT_RELU2, pre=True, residual=True)
     case('ragged tb 8300x2312x704', 8300, 2312, 704, act=ACT_RELU2, pre=True, residual=True, tb=True)
     case('f32 out/res 4160x1536x768', 4160, 1536, 768, residual=True, f32res=True, out_f32=True)
-    _lib.lib.ph_gemm_tuning(5, 128)
+    _lib.lib.ph_gemm_tuning(*_lib.GEMM_BIG_DEFAULT)

@@ -182,7 +182,7 @@ if __name__ == '__main__':
             run(tag + 'big c_fc 8192x3072x768 qgelu + grad', 'ph_tl_fetch_big', 8192, 3072, 768, cold, act=ACT_QUICKGELU, pre=True)
             run(tag + 'big dgrad c_proj 8192x3072x768 tb *saved', 'ph_tl_fetch_big', 8192, 3072, 768, cold, tb=True, bias=False, act_in=True)
             run(tag + 'big tiny-K 8320x768x128 +res (fixed cost alone)', 'ph_tl_fetch_big', 8320, 768, 128, cold, residual=True)
-    _lib.lib.ph_gemm_tuning(modes[0], 128)
+    _lib.lib.ph_gemm_tuning(*_lib.GEMM_BIG_DEFAULT)
     for cold in (False, True):
         run('ks2 dec dense 960x768x768 +bias +drop +res32', 'ph_tl_fetch_gemm', 960, 768, 768, cold, residual=True, f32res=True, drop=True)
         run('ks2 dec dgrad 960x768x768 tb', 'ph_tl_fetch_gemm', 960, 768, 768, cold, tb=True, bias=False)
