@@ -27,19 +27,31 @@ typedef __attribute__((address_space(3))) void lptr_t;
 template <int VARIANT, bool TA, bool TB, bool XCD_REMAP>
 __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // tile mapping: same XCD-contiguous + grouped rasterisation as gemm_tile
-  const int nt = p.tiles_m * p.tiles_n;
-  int bid = block_id;
-  if constexpr (XCD_REMAP) {
-    int q = nt / 8, r = nt % 8, xcd = bid % 8, idx = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
+  // tile mapping.  Hardware places block b on XCD b % 8, each XCD with its own 4-MB L2.  One-tile-per-block launches (XCD_REMAP) give every
+  // XCD WHOLE row panels: XCD x owns tiles_m / 8 (+1) consecutive 256-row panels with ALL their column tiles, so an A panel is fetched
+  // by one L2 only (round 4: the round-1 numbering cut the tile list into eight equal runs, which put the 24-tile panel groups of a
+  // 198-tile launch astride two XCDs -- FETCH_SIZE 29.6 MB for 14.0 MB of operands, profiles/r4_fetch_write_by_shape_before.txt).
+  // The grid is 8 x (largest share); the blocks beyond an XCD's share exit.  Inside a share, tiles run in groups of GM panels, rows
+  // fastest, so that the ~32 tiles an XCD holds at once cover GM row panels x 8 column panels of operands.
   constexpr int GM = 4;
-  const int group_sz = GM * p.tiles_n;
-  const int first_m = (bid / group_sz) * GM;
-  const int gm = min(GM, p.tiles_m - first_m);
-  const int rin = bid % group_sz;
-  const int tm = first_m + rin % gm, tn = rin / gm;
+  int tm, tn;
+  if constexpr (XCD_REMAP) {
+    const int xcd = block_id & 7, idx = block_id >> 3;
+    const int q = p.tiles_m >> 3, r = p.tiles_m & 7;
+    const int cnt = q + (xcd < r ? 1 : 0), p0 = xcd * q + min(xcd, r);
+    if (idx >= cnt * p.tiles_n) return;
+    const int group_sz = GM * p.tiles_n;
+    const int first = (idx / group_sz) * GM;
+    const int gm = min(GM, cnt - first);
+    const int rin = idx - (idx / group_sz) * group_sz;
+    tm = p0 + first + rin % gm; tn = rin / gm;
+  } else {
+    const int group_sz = GM * p.tiles_n;
+    const int first_m = (block_id / group_sz) * GM;
+    const int gm = min(GM, p.tiles_m - first_m);
+    const int rin = block_id % group_sz;
+    tm = first_m + rin % gm; tn = rin / gm;
+  }
   const int m0 = tm * BM, n0 = tn * BN;
   const int nk = p.K / BK;
 
@@ -276,7 +288,7 @@ template <int VARIANT, bool TA, bool TB>
 int launch(const GemmParams& p, hipStream_t s) {
   PH_SET_SMEM_ONCE((&gemm_big_kernel<VARIANT, TA, TB>), SMEM);
   count_launch(PH_GEMM_CLS_BIG);
-  hipLaunchKernelGGL((gemm_big_kernel<VARIANT, TA, TB>), dim3(p.tiles_m * p.tiles_n), dim3(NTHR), SMEM, s, p);
+  hipLaunchKernelGGL((gemm_big_kernel<VARIANT, TA, TB>), dim3(8 * ((p.tiles_m + 7) / 8) * p.tiles_n), dim3(NTHR), SMEM, s, p);      // (XCD shares, see big_tile)
   PH_LAUNCH_CHECK("gemm_big_kernel");
   return PH_OK;
 }
