@@ -13,7 +13,10 @@ Synthetic inputs are resident in HBM before the timed region.  Rank 0 prints ONE
 Extra legs (rank 0, N = 1 only):
   roofline      the bf16 MFMA GEMM kernel family: algorithmic FLOPs (2*M*N*K per launch) / summed launch durations, measured
                 with HIP events on the launch stream in an instrumented (eager, non-graph) pass of the same step
-  cpu_baseline  the CPU oracle (oracle/prismer_oracle.py, fp32, all host cores) on a bounded sample of the same workload
+  cpu_baseline  the CPU oracle (oracle/prismer_oracle.py, fp32) on a bounded sample of the same workload: batch 8, every logical CPU of
+                the host and 32 threads, the better of the two reported with its thread count
+  secondary     BASELINE configs 2 and 5, the drop-in nn.Module loop (model -> loss.backward -> torch.optim.AdamW) and a loader-fed
+                Trainer (a new pinned-host batch through set_batch every step), all under the same clock as the headline
 """
 import argparse
 import ctypes
@@ -147,17 +150,16 @@ def pmc_traffic():
     return None, None
 
 
-def cpu_baseline(seconds_budget=20.0):
+def cpu_baseline(seconds_budget=30.0, only_cores=None):
     """CPU oracle (a port: plain-PyTorch fp32 restatement of the reference modules, pinned to reference outputs by
-    tests/golden) timed on the host: Prismer-BASE caption train step (fwd+bwd+AdamW), batch 2, T=30, freeze_vision.
-    Bounded: at most 32 threads (torch's CPU kernels thrash with hundreds of threads on these op sizes) and the loop stops
-    as soon as the budget is exceeded -- at least one timed step."""
+    tests/golden) timed on this host: Prismer-BASE caption train step (fwd+bwd+AdamW), batch 8, T=30, freeze_vision -- the batch
+    BASELINE.md section 3 times the reference classes at.  Two thread counts inside the budget: every logical CPU of the host (what
+    "the same host" means) and 32 (torch's CPU kernels often lose to their own synchronisation beyond that on these op sizes);
+    `value` is the better one and `cores` says which, both are in `sample`."""
     from oracle import prismer_oracle as O
     from prismer_amd import config as pcfg, synth
-    cores = min(32, os.cpu_count() or 1)
-    torch.set_num_threads(cores)
     d = pcfg.prismer_base()
-    B, T = 2, 30
+    B, T = 8, 30
     esd, dsd = synth.synth_encoder_state(d, 0), synth.synth_decoder_state(d, 0)
     names = ['expert_encoder.' + k for k in esd] + ['text_decoder.' + k for k in dsd]
     fm = O.freeze_mask(names, 'freeze_vision')
@@ -176,16 +178,108 @@ def cpu_baseline(seconds_budget=20.0):
         loss, _, _ = O.caption_loss(esd, dsd, x, ids, mask, labels, d, train_bn=True, instance_table=tab, bn_updates={})
         loss.backward()
         opt.step()
-    times = []
-    t_start = time.time()
-    while True:
-        t0 = time.time(); step(); times.append(time.time() - t0)
-        if time.time() - t_start > seconds_budget or len(times) >= 6:
-            break
-    dt = min(times)                                    # first step carries one-off allocation cost: report the best step
-    return dict(value=round(B / dt, 3), unit='images/sec', cores=cores, kind='port',
-                sample=f'Prismer-BASE caption train step (fwd+bwd+AdamW, freeze_vision, fp32 oracle), batch {B}, T={T}: best of '
-                       f'{len(times)} step(s) = {dt:.2f} s on {cores} threads (host has {os.cpu_count()} cpus)')
+    ncpu = os.cpu_count() or 1
+
+    def timed(cores, max_steps, budget):
+        torch.set_num_threads(cores)
+        times, t_start = [], time.time()
+        while len(times) < max_steps and (not times or time.time() - t_start + min(times) < budget):
+            t0 = time.time(); step(); times.append(time.time() - t0)
+        return min(times), len(times)                      # the first step carries one-off allocation cost: the best step counts
+    if only_cores is not None:                             # child process of the all-cores attempt: one bounded measurement, one JSON line
+        t, n = timed(only_cores, 2, seconds_budget)
+        print(json.dumps({'t': t, 'n': n}), flush=True)
+        return None
+    results, note = {}, ''
+    base = min(32, ncpu)
+    results[base] = timed(base, 3, seconds_budget * 0.6)
+    if ncpu > base:
+        # every logical CPU: in a child process with a hard time limit -- torch's CPU kernels can collapse with hundreds of threads on these
+        # op sizes (one step then takes minutes), and a running step cannot be interrupted from inside the process
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, '-c', f'import bench; bench.cpu_baseline({seconds_budget * 0.4}, only_cores={ncpu})'], cwd=ROOT,
+                               capture_output=True, text=True, timeout=seconds_budget * 0.4 + 15)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            results[ncpu] = (d['t'], d['n'])
+        except Exception as e:
+            note = f'; {ncpu} threads: no step finished inside {seconds_budget * 0.4 + 15:.0f} s ({type(e).__name__}): slower than {base} threads'
+    best = min(results, key=lambda c: results[c][0])
+    dt = results[best][0]
+    return dict(value=round(B / dt, 3), unit='images/sec', cores=best, kind='port',
+                sample=f'Prismer-BASE caption train step (fwd+bwd+AdamW, freeze_vision, fp32 oracle), batch {B}, T={T}; ' +
+                       '; '.join(f'{c} threads: best of {n} step(s) = {t:.2f} s = {B / t:.2f} images/s' for c, (t, n) in sorted(results.items())) +
+                       note + f' (host has {ncpu} logical cpus)')
+
+
+def dropin_leg(steps=10, warmup=3, batch=32):
+    """What the reference's own loop gets from the drop-in modules (train_caption.py:121-136): `loss = model(experts, caption, prefix=...)`,
+    `loss.backward()`, `torch.optim.AdamW.step()` -- each top module one torch.autograd.Function over the HIP layer programs, parameter
+    gradients handed to autograd, PyTorch's optimizer on the fp32 masters (bf16 shadows refreshed on the next forward).  No hipGraph."""
+    from prismer_amd import config as pcfg
+    from prismer_amd.model.prismer_caption import PrismerCaption
+    torch.manual_seed(0)
+    dims = pcfg.prismer_base()
+    model = PrismerCaption({'experts': pcfg.CAPTION_EXPERTS, 'image_resolution': 224, 'prismer_model': 'prismer_base', 'freeze': 'freeze_vision'}).cuda()
+    model.train()
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=5e-5, weight_decay=0.05)
+    x, ids, mask, _ = make_inputs(dims, batch, 30, 1234, torch.device('cuda'))
+    caption = {'input_ids': ids, 'attention_mask': mask}
+
+    def step():
+        loss = model(x, caption, prefix=4)                 # (token ids instead of strings: no RoBERTa vocabulary on an offline box)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dict(value=round(batch * steps / dt, 2), unit='images/sec', batch=batch, steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 3),
+                hip_graph=False, final_loss=round(float(loss.item()), 4),
+                config='Prismer-BASE caption fine-tune through the drop-in nn.Modules: model(experts, caption) -> loss.backward() -> torch.optim.AdamW '
+                       '(reference loop train_caption.py:126-135), eager launches')
+
+
+def loader_leg(steps=10, warmup=3, batch=32):
+    """The native Trainer fed like a real loader feeds it: every step a NEW batch arrives in pinned host memory and goes through
+    Trainer.set_batch (async H2D into the static buffers) before the replayed step -- compact label experts (uint8 maps + feature
+    tables, in-painted on the device: 56 MB per step instead of 1.2 GB of dense 64-channel fp32 maps)."""
+    tr, dims, _ = build_trainer(batch, True, 0, compact_labels=True)
+
+    def pin(t):
+        return {k: pin(v) for k, v in t.items()} if isinstance(t, dict) else t.cpu().pin_memory()
+    batches = []
+    for i in range(3):                                      # three distinct host batches, cycled
+        x, ids, mask, labels = make_inputs(dims, batch, 30, 4321 + i, torch.device('cuda'), True)
+        batches.append((pin(x), ids.cpu().pin_memory(), mask.cpu().pin_memory(), labels.cpu().pin_memory()))
+    nbytes = sum(t.numel() * t.element_size() for t in _leaves(batches[0][0])) + sum(t.numel() * t.element_size() for t in batches[0][1:])
+    for i in range(warmup):
+        tr.set_batch(*batches[i % 3]); tr.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        tr.set_batch(*batches[i % 3])
+        loss = tr.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dict(value=round(batch * steps / dt, 2), unit='images/sec', batch=batch, steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 3),
+                h2d_mbytes_per_step=round(nbytes / 1e6, 1), hip_graph=bool(tr.graphs is not None), final_loss=round(float(loss.item()), 4),
+                config='Prismer-BASE caption fine-tune, native Trainer, a new batch from pinned host memory every step (set_batch + step), '
+                       'compact label experts in-painted on the device')
+
+
+def _leaves(t):
+    if isinstance(t, dict):
+        for v in t.values():
+            yield from _leaves(v)
+    else:
+        yield t
 
 
 def main():
@@ -354,6 +448,13 @@ def main():
                     gc.collect(); torch.cuda.empty_cache()
                 except Exception as e:                     # a secondary leg must never take the headline line down
                     sec[wl] = dict(error=f'{type(e).__name__}: {e}'[:300])
+            # round 4: the two boundaries the library advertises besides the native Trainer, under the same clock
+            for name, leg in (('dropin', dropin_leg), ('loader', loader_leg)):
+                try:
+                    sec[name] = leg()
+                except Exception as e:
+                    sec[name] = dict(error=f'{type(e).__name__}: {e}'[:300])
+                gc.collect(); torch.cuda.empty_cache()
             out['secondary'] = sec
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -121,6 +121,15 @@ def prismer_large(experts: List[str] = None, image_resolution=480) -> PrismerDim
                        intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16)
 
 
+def prismer_huge(experts: List[str] = None, image_resolution=224) -> PrismerDims:
+    """configs/prismer.json 'prismer_huge' (:50-73: roberta-large decoder reading a 1280-wide vision stream) + CLIP ViT-H/14 geometry
+    (vit.py:211-214: width 1280, 32 layers, heads = width // 64 = 20; the Experts Resampler keeps 8 heads -> head dim 160)."""
+    ex = CAPTION_EXPERTS if experts is None else experts
+    return PrismerDims(image_resolution=image_resolution, patch_size=14, width=1280, vit_layers=32, vit_heads=20,
+                       experts=expert_channels(ex), hidden_size=1024, vision_hidden_size=1280,
+                       intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16)
+
+
 def prismer_tiny(experts: List[str] = None, image_resolution=64, expert_resolution=64, vocab_size=1003) -> PrismerDims:
     """Small geometry used by the golden fixtures (tests/golden/make_golden.py). Same code paths as BASE:
     7 stems, resampler (8 heads x 32), 2 ViT blocks (4 heads x 64), 2 decoder layers + output layer."""
@@ -135,5 +144,6 @@ CONFIGS = {
     'prismer_base': prismer_base,
     'prismerz_base': prismerz_base,
     'prismer_large': prismer_large,
+    'prismer_huge': prismer_huge,
     'prismer_tiny': prismer_tiny,
 }

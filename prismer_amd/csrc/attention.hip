@@ -843,7 +843,9 @@ int set_smem(KernelT k, int bytes) {
 int check_fwd(const ph_attn_fwd_args* f, const char* who) {
   PH_CHECK_ARG(f && f->q && f->k && f->v && f->o, "%s: null pointer", who);
   PH_CHECK_ARG(f->B > 0 && f->H > 0 && f->Sq > 0 && f->Sk > 0, "%s: bad dims", who);
-  PH_CHECK_ARG(f->dh == 32 || f->dh == 64 || f->dh == 96 || f->dh == 128, "%s: head dim %d unsupported (32/64/96/128)", who, f->dh);
+  PH_CHECK_ARG(f->dh == 32 || f->dh == 64 || f->dh == 96 || f->dh == 128 || f->dh == 160, "%s: head dim %d unsupported (32/64/96/128/160)", who, f->dh);
+  // 160 = the Experts Resampler of Prismer-HUGE (ViT-H width 1280 / 8 heads, resampler.py:18-24): plain attention only
+  PH_CHECK_ARG(f->dh != 160 || attn_plain_ok(f), "%s: head dim 160 is built for plain attention (no causal cut, key mask or dropout)", who);
   PH_CHECK_ARG(((f->q_ts | f->k_ts | f->v_ts | f->o_ts | f->q_bs | f->k_bs | f->v_bs | f->o_bs) % 8) == 0, "%s: strides must be multiples of 8 elements", who);
   PH_CHECK_ARG((((uintptr_t)f->q | (uintptr_t)f->k | (uintptr_t)f->v | (uintptr_t)f->o) & 15) == 0, "%s: pointers must be 16-B aligned", who);
   PH_CHECK_ARG(((int64_t)f->Sq * f->q_ts | (int64_t)f->Sk * f->k_ts | (int64_t)f->Sk * f->v_ts) < (1ll << 30),
@@ -873,7 +875,7 @@ extern "C" int ph_attention_fwd(const ph_attn_fwd_args* a, hipStream_t stream) {
     if constexpr (DHV <= 64) { if (qt2) { PH_FWD_LAUNCH(DHV, true, 2) break; } }                  \
     if (plain) PH_FWD_LAUNCH(DHV, true, 1) else PH_FWD_LAUNCH(DHV, false, 1)                      \
   } break;
-  switch (a->dh) { PH_FWD(32) PH_FWD(64) PH_FWD(96) PH_FWD(128) }
+  switch (a->dh) { PH_FWD(32) PH_FWD(64) PH_FWD(96) PH_FWD(128) case 160: PH_FWD_LAUNCH(160, true, 1) break; }
 #undef PH_FWD_LAUNCH
 #undef PH_FWD
   PH_LAUNCH_CHECK("attn_fwd_kernel");
@@ -917,7 +919,7 @@ extern "C" int ph_attention_bwd(const ph_attn_bwd_args* a, hipStream_t stream) {
     }                                                                                                     \
     if (!dkv_done) { if (plain) PH_DKV_LAUNCH(DHV, true, 1) else PH_DKV_LAUNCH(DHV, false, 1) }           \
   } break;
-  switch (f.dh) { PH_BWD(32) PH_BWD(64) PH_BWD(96) PH_BWD(128) }
+  switch (f.dh) { PH_BWD(32) PH_BWD(64) PH_BWD(96) PH_BWD(128) case 160: { PH_DQ_LAUNCH(160, true, 1) PH_DKV_LAUNCH(160, true, 1) } break; }
 #undef PH_DQ_LAUNCH
 #undef PH_DKV_LAUNCH
 #undef PH_BWD

@@ -41,6 +41,9 @@ def test_argument_validation_without_gpu():
     f.dh = 48
     rc = _lib.lib.ph_attention_fwd(C.byref(f), None)
     assert rc == -1 and b'head dim 48' in _lib.lib.ph_last_error()
+    f.dh = 160; f.causal = 1                                                                    # HUGE resampler head dim: plain attention only
+    assert _lib.lib.ph_attention_fwd(C.byref(f), None) == -1 and b'plain attention' in _lib.lib.ph_last_error()
+    f.causal = 0
     f.dh = 64; f.Sk = 1 << 20; f.k_ts = 1 << 12; f.q_ts = f.v_ts = f.o_ts = 64                # K slice of 8 GiB: beyond the 32-bit tile offsets
     rc = _lib.lib.ph_attention_fwd(C.byref(f), None)
     assert rc == -1 and b'2 GiB' in _lib.lib.ph_last_error()

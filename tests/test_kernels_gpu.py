@@ -453,6 +453,7 @@ ATTN_CASES = [  # B, H, Sq, Sk, dh, causal, masked, drop
     (2, 4, 30, 260, 64, False, False, 0.1),      # decoder cross-attention with prob-dropout (roberta.py:123)
     (2, 2, 70, 130, 32, True, False, 0.0),
     (1, 2, 100, 200, 128, False, True, 0.2),
+    (2, 8, 64, 300, 160, False, False, 0.0),     # Prismer-HUGE resampler: ViT-H width 1280 / 8 heads (configs/prismer.json:50-73, resampler.py:18-24)
 ]
 
 

@@ -840,3 +840,25 @@ def test_trainer_pretrain_recipe_freeze_lang_vision_and_warmup():
     for n, p in list(enc.named_parameters()) + list(dec.named_parameters()):
         if n in frozen0:
             assert torch.equal(p.detach(), frozen0[n]), n
+
+
+def test_prismer_huge_geometry_trains_one_step():
+    """SURVEY 8f #4 / configs/prismer.json:50-73: the HUGE geometry (ViT-H/14: width 1280, 32 layers, 20 heads; Experts Resampler 8 heads x 160;
+    roberta-large decoder cross-attending a 1280-wide stream) goes through the same kernels -- head dim 160 in the resampler, 1280-wide
+    LayerNorm / stems, K = 1280 projections.  Shape smoke test: two native steps at batch 2, finite and decreasing loss, finite gradients."""
+    import bench
+    from prismer_amd.model.prismer_caption import PrismerCaption
+    from prismer_amd.trainer import Trainer
+    dims = config.prismer_huge()
+    assert dims.width // dims.resampler_heads == 160 and dims.width // dims.vit_heads == 64 and dims.seq_len == 256 + 64
+    torch.manual_seed(0)
+    model = PrismerCaption({'experts': config.CAPTION_EXPERTS, 'image_resolution': 224, 'prismer_model': 'prismer_huge', 'freeze': 'freeze_vision'}).cuda()
+    x, ids, mask, labels = bench.make_inputs(dims, 2, 16, 7, torch.device('cuda'))
+    tr = Trainer(model, lr=2e-5, total_steps=10, use_graph=False, keep_grads=True)
+    tr.set_batch(x, ids, mask, labels)
+    l1 = tr.step().item()
+    for st in tr.stores:
+        g = st.grad[:st.n_train]
+        assert torch.isfinite(g).all() and g.abs().max() > 0
+    l2 = tr.step().item()
+    assert np.isfinite(l1) and np.isfinite(l2) and l2 < l1, (l1, l2)
