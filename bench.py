@@ -97,13 +97,8 @@ def build_trainer(batch, use_graph, rank, T=30, workload='base_caption', freeze=
         dims = pcfg.prismer_base()
         cfg = {'experts': pcfg.CAPTION_EXPERTS, 'image_resolution': 224, 'prismer_model': 'prismer_base', 'freeze': freeze}
         model = PrismerCaption(cfg).cuda()
-    tr = Trainer(model, lr=5e-5, weight_decay=0.05, total_steps=10000, task='caption', use_graph=use_graph,
-                 micro_batches=int(os.environ.get('PRISMER_MICRO_BATCHES', '1')),
-                 side_stream=os.environ.get('PRISMER_SIDE_STREAM', '0') != '0', grad_payload=grad_payload, shard_optimizer=shard)
-    from prismer_amd import ops as _ops
-    _ops.WQ.enabled = os.environ.get('PRISMER_WGRAD_QUEUE', '1') != '0'      # A/B switch: grouped deferred wgrads
-    _ops.WQ.eager_flush = os.environ.get('PRISMER_WGRAD_EAGER_FLUSH', '0') != '0'
-    _ops.WQ.bg_blocks = int(os.environ.get('PRISMER_WGRAD_BG_BLOCKS', '0'))       # with eager flush: capped background launches
+    tr = Trainer(model, lr=5e-5, weight_decay=0.05, total_steps=10000, task='caption', use_graph=use_graph, grad_payload=grad_payload,
+                 shard_optimizer=shard)
     x, ids, mask, labels = make_inputs(dims, batch, T, 1234 + rank, torch.device('cuda'), compact_labels)
     weights = None
     if workload == 'large_vqa':

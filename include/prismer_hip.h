@@ -372,6 +372,12 @@ enum { PH_WS_GEMM_SPLITK = 0, PH_WS_LAYERNORM_BWD = 1, PH_WS_ATTENTION_BWD = 2, 
 int64_t ph_query_workspace(int op, const int64_t* dims, int ndims);
 /* advance the dropout seed (device-side, graph-replay safe): seed[0] = splitmix(seed[0]) */
 int ph_advance_seed(uint64_t* seed, hipStream_t stream);
+/* step glue (round 4: the last stock torch kernels inside the captured step).  x[i] += value for n int64 counters -- BatchNorm's
+ * num_batches_tracked of all stem layers at once (torch/nn/modules/batchnorm.py semantics, vit.py:88-120) */
+int ph_add_i64(int64_t* x, int n, int64_t value, hipStream_t stream);
+/* out[0] = scale * sum_i x[i] * (weights ? weights[i] : 1): the batch loss -- caption loss.mean() (prismer_caption.py:33) with scale = 1/B,
+ * VQA (weights * loss).mean() (prismer_vqa.py:40-41) */
+int ph_weighted_sum_f32(const float* x, const float* weights, int n, float scale, float* out, hipStream_t stream);
 
 /* Measurement hooks (bench.py): when enabled, every entry point brackets its launches with HIP events on the launch
  * stream.  ph_prof_collect synchronises and writes, per kernel family f (0 gemm, 1 layernorm, 2 attention fwd,

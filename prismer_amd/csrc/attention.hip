@@ -822,17 +822,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
   }
 }
 
-// no causal cut, no key mask, no probability dropout -> the PLAIN kernels (PH_ATTN_PLAIN=0: A/B against the generic ones)
+// no causal cut, no key mask, no probability dropout -> the PLAIN kernels
 bool attn_plain_ok(const ph_attn_fwd_args* f) {
-  static const bool on = [] { const char* e = getenv("PH_ATTN_PLAIN"); return !e || atoi(e) != 0; }();
-  return on && !f->causal && !f->key_mask && !(f->drop_p > 0.f) && f->scale > 0.f;     // (the row max is taken on raw scores: needs scale > 0)
+  return !f->causal && !f->key_mask && !(f->drop_p > 0.f) && f->scale > 0.f;     // (the row max is taken on raw scores: needs scale > 0)
 }
 
 // 32 queries (keys, in the dK/dV kernel) per wave for long enough sequences
-int attn_qt2_ok() {          // PH_ATTN_QT2: 0 = never, 1 = by sequence length (default), 2 = wherever eligible
-  static const int mode = [] { const char* e = getenv("PH_ATTN_QT2"); return e ? atoi(e) : 1; }();
-  return mode;
-}
+int attn_qt2_ok() { return 1; }          // 1 = by sequence length (0 = never and 2 = wherever eligible were the round-3 A/B arms)
 
 template <typename KernelT>
 int set_smem(KernelT k, int bytes) {

@@ -83,12 +83,12 @@ namespace phg { std::atomic<long long> g_gemm_counts[PH_GEMM_CLS_COUNT]; }
 static std::atomic<int> g_big_mode{-1}, g_big_min_tiles{-1};
 static int big_mode_now() {
   int m = g_big_mode.load(std::memory_order_relaxed);
-  if (m < 0) { static const int dflt = env_int("PH_GEMM_BIG", 6); m = dflt; }
+  if (m < 0) m = 6;
   return m;
 }
 static int big_min_tiles_now() {
   int m = g_big_min_tiles.load(std::memory_order_relaxed);
-  if (m < 0) { static const int dflt = env_int("PH_GEMM_BIG_MIN_TILES", 128); m = dflt; }
+  if (m < 0) m = 128;
   return m;
 }
 
@@ -261,9 +261,8 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
   // per launch at 5-60 % fill, 28 launches per step); here every problem is cut into pieces of ~W/slots k-tiles so that the whole
   // group fills the chip once, partial sums go to the caller's workspace and ONE grouped pass folds them (plain fp32 epilogues only).
   {
-    static const int grp_split = env_int("PH_GEMM_GROUP_SPLIT", 1);
     const ph_gemm_args& a0 = args[0];
-    bool ok = grp_split && max_blocks == 0 && a0.trans_a && a0.trans_b && a0.workspace && a0.workspace_bytes > 0;
+    bool ok = max_blocks == 0 && a0.trans_a && a0.trans_b && a0.workspace && a0.workspace_bytes > 0;
     double W = 0.0;
     for (int i = 0; i < n && ok; ++i) {
       const ph_gemm_args& a = args[i];
@@ -318,8 +317,7 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
   }
   // ---- weight-gradient groups with long reductions: the 256x128 ping-pong kernel, one persistent block per CU ----
   {
-    static const int big_grp = env_int("PH_GEMM_BIG_GROUPED", 1);   // 0: keep every group on the 128x128 / 64x64 grouped kernel
-    bool ok = big_mode_now() > 0 && big_grp && !conv && max_blocks == 0 && args[0].trans_a && args[0].trans_b;
+    bool ok = big_mode_now() > 0 && !conv && max_blocks == 0 && args[0].trans_a && args[0].trans_b;
     int tbig = 0, kt_min = 1 << 30, kt_big = 0;
     for (int i = 0; i < n && ok; ++i) {
       const ph_gemm_args& a = args[i];
@@ -327,13 +325,13 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
       tbig += ceil_div(a.M, big::BM) * ceil_div(a.N, big::BN);
       kt_min = min(kt_min, a.K / BK); kt_big = max(kt_big, a.K / BK);
     }
-    if (ok && kt_min >= (big_grp == 2 ? 8 : 32)) {        // (PH_GEMM_BIG_GROUPED=2: experiments -- every eligible group with K >= 512, no cost comparison)
+    if (ok && kt_min >= 32) {
       // rounds x (k loop + fixed part) of either kernel, constants from the per-shape fits: 0.67 us per k-tile for the
       // one-per-CU 256x128 block, 0.84 us per k-tile and pair of co-resident 128x128 blocks (0.5 us for a lone one)
       const double cost_big = ceil(tbig / 256.0) * (kt_big * 0.67 + 14.0);
       const int t128 = total;           // (tiles of the BMsel grid computed above; BMsel is 128 for these groups)
       const double cost_128 = BMsel == 128 ? (t128 <= 256 ? kt_big * 0.5 + 10.0 : ceil(t128 / 512.0) * (kt_big * 0.84 + 10.0)) : 1e30;
-      if (cost_big < cost_128 || big_grp == 2) {
+      if (cost_big < cost_128) {
         int tot = 0;
         for (int i = 0; i < n; ++i) {
           g.p[i].tiles_m = ceil_div(args[i].M, big::BM); g.p[i].tiles_n = ceil_div(args[i].N, big::BN);
@@ -351,17 +349,15 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
     PH_CHECK_ARG(ta == tb, "ph_gemm_grouped_bf16: conv gather needs the NN or the TT layout");
     if (!ta) {
       // gathered A operand through the register prefetch ring as well (round 3): the gather loads are unconditional (clamped address +
-      // select), so the ring's straight-line bookkeeping holds for any K.  PH_GEMM_CONV_RING=0: the round-2 one-deep schedule
-      static const int conv_ring = env_int("PH_GEMM_CONV_RING", 1);
-      return BMsel == 128 ? reg::launch_grouped_128(g, total, max_blocks, 0, 0, conv_ring ? 1 : 0, 1, stream)
-                          : reg::launch_grouped_64(g, total, max_blocks, 0, 0, conv_ring ? 1 : 0, 1, stream);
+      // select), so the ring's straight-line bookkeeping holds for any K
+      return BMsel == 128 ? reg::launch_grouped_128(g, total, max_blocks, 0, 0, 1, 1, stream)
+                          : reg::launch_grouped_64(g, total, max_blocks, 0, 0, 1, 1, stream);
     }
     return BMsel == 128 ? reg::launch_grouped_128(g, total, max_blocks, 1, 1, 0, 2, stream) : reg::launch_grouped_64(g, total, max_blocks, 1, 1, 0, 2, stream);
   }
   if (BMsel == 128) {
-    static const int tt_ring = env_int("PH_GEMM_TT_RING", 1);        // prefetch ring for the [K,M] x [K,N] weight-gradient groups too (round 3:
-                                                                     // step -0.07 / -0.17 ms in two same-box pairs; round 1 measured -4 % on single launches)
-    return reg::launch_grouped_128(g, total, max_blocks, ta, tb, (kfull && (!ta || tt_ring)) ? 1 : 0, 0, stream);
+    // prefetch ring for the [K,M] x [K,N] weight-gradient groups too (round 3: step -0.07 / -0.17 ms in two same-box pairs)
+    return reg::launch_grouped_128(g, total, max_blocks, ta, tb, kfull ? 1 : 0, 0, stream);
   }
   return reg::launch_grouped_64(g, total, max_blocks, ta, tb, kfull ? 1 : 0, 0, stream);
 }
@@ -373,10 +369,9 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
   // The rows that cause the overshoot (the last, partial row panels) are cut off and computed by a second, small launch:
   // 8192 x 3072 = exactly 3 rounds (+ 128 x 3072 on 64x64 tiles, ~10 us beside an otherwise idle chip).
   {   // (before the profiling scope of this call: the two halves are profiled as two launches)
-    static const int tail_split = env_int("PH_GEMM_TAIL_SPLIT", 1);
     const int64_t tn128 = ceil_div(a->N, 128), tm128 = ceil_div(a->M, 128);
     const int64_t tiles = tm128 * tn128, slots = 512;
-    if (tail_split && !a->trans_a && !a->conv && !a->col_stats && !(a->drop_p > 0.0f) && a->split_k <= 0 && a->rowmap_wo == 0 && tiles > slots && (a->K % BK) == 0) {
+    if (!a->trans_a && !a->conv && !a->col_stats && !(a->drop_p > 0.0f) && a->split_k <= 0 && a->rowmap_wo == 0 && tiles > slots && (a->K % BK) == 0) {
       const int64_t over = tiles % slots;
       const int64_t panels_main = (tiles / slots) * slots / tn128;              // row panels that fit the whole rounds
       const int64_t m_main = panels_main * 128, m_rem = a->M - m_main;
@@ -413,10 +408,6 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
     // two waves of a SIMD alternate read and MFMA phases), 6 = ping-pong with the LEAN tail (no surplus DMA, no drain; default since round 4)
     const int big_mode = big_mode_now(), big_min_tiles = big_min_tiles_now();
     const int64_t tb = (int64_t)ceil_div(a->M, big::BM) * ceil_div(a->N, big::BN);
-    static const int wide = env_int("PH_GEMM_BIG_WIDE", 1);    // 1 (default since the tail split: c_fc / c_proj-dgrad become exactly 3 rounds of 256
-                                                               // tiles; step -0.17 ms in two A/B pairs): also the wide-N, short-K launches
-    const bool wide_ok = wide != 0;
-    static const int tb_ok = env_int("PH_GEMM_BIG_TB", 1);     // 0: keep the [K][N]-B (dgrad-shaped) problems on the 128x128 kernel
     // block rounds of either kernel (constants from the per-shape fits, us): a 256x128 block alone on its CU, a pair of co-resident
     // 128x128 blocks, a lone 128x128 block (what the last, half-empty round of that kernel is made of -- the reason a tile count just
     // above a multiple of 256 favours it: 41 x 8 tiles of 256x128 are two full rounds, 81 x 8 of 128x128 one pair round + one lone round)
@@ -429,9 +420,8 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
       big_cheaper = cost_big < cost_128 * (a->trans_b ? 1.0 : 1.02);      // ties (two full rounds vs pair + lone round): measured in favour of
                                                                            // the big kernel for [N,K] B (stem 25088x384x1728), against it for [K,N] B (LARGE dgrads)
     }
-    if (big_mode > 0 && !a->conv && !a->col_stats && !a->trans_a && (!a->trans_b || tb_ok) && (a->K % BK) == 0 && a->K >= 2 * BK && a->split_k <= 0 && a->M >= big::BM &&
-        (a->N % 8) == 0 && a->N >= 8 && tb >= big_min_tiles && (tb >= 192 || a->K >= 32 * BK || big_min_tiles <= 1) && big_cheaper &&
-        (wide_ok || a->N <= 1024 || a->K >= 2048 || big_min_tiles <= 1)) {      // (short-K launches that fill < 3/4 of the CUs with one round: 128x128)
+    if (big_mode > 0 && !a->conv && !a->col_stats && !a->trans_a && (a->K % BK) == 0 && a->K >= 2 * BK && a->split_k <= 0 && a->M >= big::BM &&
+        (a->N % 8) == 0 && a->N >= 8 && tb >= big_min_tiles && (tb >= 192 || a->K >= 32 * BK || big_min_tiles <= 1) && big_cheaper) {
       // Forward-shaped (B = [N][K]) and dgrad-shaped (B = [K][N], trans_b) problems alike.  Isolated (tools/big_probe.py,
       // profiles/r2_ab_big_tile_gemm.txt) the ping-pong kernel beats the 128x128 register-staged kernel on every shape of the
       // step; inside the step (rocprofv3 per-grid durations, profiles/r2_gemm_by_grid.txt) only the launches with N <= 1024 or a
@@ -443,7 +433,7 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
       return big::launch_single(p, big_mode == 1 ? 0 : (big_mode == 6 ? 5 : 4), false, a->trans_b != 0, stream);
     }
     // weight-gradient layout (A = [K][M], B = [K][N]) with a long reduction: same kernel, both operands through the transposing reads
-    if (big_mode > 0 && !a->conv && !a->col_stats && a->trans_a && a->trans_b && tb_ok && (a->K % BK) == 0 && a->K >= 32 * BK && a->split_k <= 0 &&
+    if (big_mode > 0 && !a->conv && !a->col_stats && a->trans_a && a->trans_b && (a->K % BK) == 0 && a->K >= 32 * BK && a->split_k <= 0 &&
         a->M >= big::BM && (a->M % 8) == 0 && (a->N % 8) == 0 && a->N >= 8 && tb >= 64 && big_cheaper) {
       p.tiles_m = ceil_div(a->M, big::BM); p.tiles_n = ceil_div(a->N, big::BN);
       p.k_tiles_per_split = a->K / BK;
@@ -486,11 +476,6 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
       }
     }
   }
-  {
-    static const int force = env_int("PH_GEMM_FORCE_TILE", 0);           // 64|128: tile-shape experiments (tools/ab_probe.py)
-    if (force == 64 || (force == 128 && a->M > 64 && a->N > 64)) { BM = force; if (a->split_k <= 0) splits = 1; }
-    if (force == 12864 && a->M > 64) { BM = 128; BN = 64; if (a->split_k <= 0) splits = 1; }
-  }
   if (splits > kt) splits = kt;
   // N = 64 mod 128 and narrow (the stems' N = 192 convs): 128x64 tiles cover N exactly instead of wasting half a column tile
   // (100352x192x864: 71 -> 66 us); on every other shape the narrower wave tile (one B fragment per two MFMAs) loses
@@ -521,11 +506,9 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
   }
   {
     // 64x64-tile launches that leave CUs with a single block (the decoder's M = 960 rows): split the k loop inside the block instead
-    // of over gridDim.z + a reduce launch.  PH_GEMM_KS2: 0 = off, 1 = when the tile/split choice above was 64x64 unsplit,
-    // 2 = also instead of a workspace split-K of a 64x64 launch
-    static const int ks2 = env_int("PH_GEMM_KS2", 2);
+    // of over gridDim.z + a reduce launch.  also instead of a workspace split-K of a 64x64 launch
     const bool plain64 = BM == 64 && BN == 64 && !a->conv && !a->col_stats && !a->trans_a && (a->K % BK) == 0 && kt >= 8 && a->split_k <= 0;
-    if (ks2 > 0 && plain64 && t64 <= 512 && (splits == 1 || ks2 >= 2)) {
+    if (plain64 && t64 <= 512) {
       p.tiles_m = ceil_div(a->M, 64); p.tiles_n = ceil_div(a->N, 64);
       p.k_tiles_per_split = kt; p.ws = nullptr;
       return reg::launch_ks2(p, a->trans_b, stream);

@@ -651,6 +651,9 @@ __device__ __forceinline__ void tile_colstats(const GemmParams& p, const float* 
   float s = 0.f, ss = 0.f;
   const int c4 = col >> 2, e = col & 3;
   for (int r = part * RP; r < min((part + 1) * RP, rows); ++r) {
+    // (round 4 A/B: statistics of the fp32 accumulator values instead -- what the round-3 review suggested -- made the stems' gradients
+    //  WORSE against the reference at bs32, profiles/r4_ab_bn_statistics.txt: the next layer normalises the ROUNDED values, and
+    //  statistics that do not belong to them leave a per-channel offset; PyTorch's autocast also takes them from the bf16 conv output)
     float v = bf2f(f2bf(cl[r * BN + ((c4 ^ (r & (CH - 1))) << 2) + e]));
     s += v; ss += v * v;
   }
@@ -672,9 +675,9 @@ struct GroupParams {
 };
 
 // ---- process-wide state of the GEMM entry points (thread-safe: the C ABI may be entered from the host thread and from autograd's
-// backward thread at once).  Environment switches are read once through function-local statics (C++11: initialised exactly once);
-// kernel attributes are set through std::call_once; the tuning values ph_gemm_tuning() may change at run time are atomics.
-inline int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+// backward thread at once): kernel attributes are set through std::call_once; the tuning values ph_gemm_tuning() may change at run
+// time are atomics.  (The library reads no environment variables: the round-1..3 A/B switches are gone, their measurements are in
+// profiles/ and DESIGN.md.)
 #define PH_SET_SMEM_ONCE(kernel_expr, bytes)                                                                                   \
   do {                                                                                                                         \
     static std::once_flag once__;                                                                                              \

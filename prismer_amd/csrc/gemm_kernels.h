@@ -296,8 +296,7 @@ int launch_ks2(const GemmParams& p, hipStream_t s) {
 template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0>
 int launch_pf(const GemmParams& p, int splits, hipStream_t s) {
   constexpr int smem_min = 2 * ((TA ? TileBytes<BM>::ks : TileBytes<BM>::kc) + (TB ? TileBytes<BN>::ks : TileBytes<BN>::kc));
-  static const int extra = env_int("PH_GEMM_EXTRA_LDS", 0);            // occupancy experiments only (pads the dynamic LDS request)
-  const int smem = smem_min + extra;
+  constexpr int smem = smem_min;
   PH_SET_SMEM_ONCE((&gemm_kernel<BM, BN, TA, TB, PF, CONV>), smem);
   count_launch(BM == 64 ? PH_GEMM_CLS_64 : PH_GEMM_CLS_128);
   dim3 grid(p.tiles_m * p.tiles_n, 1, splits);

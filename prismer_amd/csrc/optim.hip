@@ -354,8 +354,8 @@ extern "C" int ph_adamw_keep(float* p, float* g, float* m, float* v, void* p_bf1
   PH_CHECK_ARG(p && g && m && v && hyper && n > 0, "ph_adamw: bad args");
   ProfScope prof__(PH_FAM_OPTIM, 0.0, 30.0 * (double)n, stream);
   PH_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && (((uintptr_t)p_bf16) & 7) == 0, "ph_adamw: misaligned");
-  static const int mode = [] { const char* e = getenv("PH_ADAMW_MODE"); return e ? atoi(e) : 1; }();      // 1 (default): two vectors per stream in flight
-  static const int blocks_cap = [] { const char* e = getenv("PH_ADAMW_BLOCKS"); return e ? atoi(e) : 2048; }();   // 8 blocks per CU: 1.298 -> 1.233 ms on 174 M parameters
+  constexpr int mode = 1;             // two vectors per stream in flight (0: the round-1 one-vector loop, 2: non-temporal stores -- both measured slower)
+  constexpr int blocks_cap = 2048;    // 8 blocks per CU: 1.298 -> 1.233 ms on 174 M parameters
   int grid = grid_for(n / 4 + 1);
   if (blocks_cap > 0 && grid > blocks_cap) grid = blocks_cap;
   hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, stream, p, g, m, v, (bf16*)p_bf16, n, hyper, beta1, beta2, eps,
@@ -558,6 +558,37 @@ extern "C" int ph_advance_seed(uint64_t* seed, hipStream_t stream) {
   ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_advance_seed");
   hipLaunchKernelGGL(advance_seed_kernel, dim3(1), dim3(1), 0, stream, seed);
   PH_LAUNCH_CHECK("advance_seed_kernel");
+  return PH_OK;
+}
+// ---- step glue that used to run as stock torch kernels inside the captured step (round-3 review): BatchNorm's num_batches_tracked += 1
+// (torch._foreach_add_) and the batch loss (stack().sum() / B, (weights * loss).mean())
+namespace {
+__global__ void add_i64_kernel(int64_t* x, int n, int64_t v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] += v;
+}
+__global__ __launch_bounds__(256) void weighted_sum_kernel(const float* __restrict__ x, const float* __restrict__ w, int n, float scale, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += w ? x[i] * w[i] : x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1] + red[2] + red[3]) * scale;
+}
+}  // namespace
+extern "C" int ph_add_i64(int64_t* x, int n, int64_t value, hipStream_t stream) {
+  PH_CHECK_ARG(x && n > 0, "ph_add_i64: bad args");
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_add_i64");
+  hipLaunchKernelGGL(add_i64_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, x, n, value);
+  PH_LAUNCH_CHECK("add_i64_kernel");
+  return PH_OK;
+}
+extern "C" int ph_weighted_sum_f32(const float* x, const float* weights, int n, float scale, float* out, hipStream_t stream) {
+  PH_CHECK_ARG(x && out && n > 0, "ph_weighted_sum_f32: bad args");
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_weighted_sum_f32");
+  hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(256), 0, stream, x, weights, n, scale, out);
+  PH_LAUNCH_CHECK("weighted_sum_kernel");
   return PH_OK;
 }
 extern "C" int ph_probe_layouts(const void* in_bf16, float* out, hipStream_t stream) {

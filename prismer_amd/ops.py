@@ -804,6 +804,19 @@ def conv_dgrad_grouped(items):
         check(lib.ph_gemm_grouped_bf16(arr, len(part), _stream()), 'ph_gemm_grouped_bf16 (conv dgrad)')
 
 
+def add_i64(x, value=1):
+    """x (int64, contiguous) += value -- BatchNorm's num_batches_tracked counters, all layers in one launch"""
+    check(lib.ph_add_i64(x.data_ptr(), x.numel(), int(value), _stream()), 'ph_add_i64')
+
+
+def weighted_sum(x, weights, scale, out=None):
+    """out[0] = scale * sum(x * weights) (weights None: plain sum): the batch loss"""
+    if out is None:
+        out = torch.empty(1, dtype=F32, device=x.device)
+    check(lib.ph_weighted_sum_f32(x.data_ptr(), ptr(weights), x.numel(), float(scale), out.data_ptr(), _stream()), 'ph_weighted_sum_f32')
+    return out
+
+
 def advance_seed(seed):
     check(lib.ph_advance_seed(seed.data_ptr(), _stream()), 'ph_advance_seed')
 

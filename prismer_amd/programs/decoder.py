@@ -10,8 +10,6 @@ LayerNorm kernel; the post-LN residual stream (LayerNorm outputs and the pre-nor
 copies the GEMMs read -- what autocast does on the reference (its fp32 LayerNorm returns fp32 to an fp32 residual); logits live in a [B*T, Vpad] bf16 buffer (Vpad = vocab rounded up to 64) and the backward
 overwrites it with dlogits.
 """
-import os
-
 import torch
 
 from .. import ops
@@ -60,7 +58,7 @@ class DecoderProgram:
                      o[f'roberta.encoder.layer.{l}.1.self.value.bias'] - o[k0 + 'bias'] == (2 * l + 1) * H for l in range(L))
             same = len({P.is_trainable(f'roberta.encoder.layer.{l}.1.self.{w}.{t}') for l in range(L) for w in ('key', 'value')
                         for t in ('weight', 'bias')}) == 1
-            if ok and same and os.environ.get('PRISMER_MERGED_KV', '1') != '0':      # (env: A/B switch)
+            if ok and same:
                 self.kv_all = Linear(P, k0 + 'weight', k0 + 'bias', rows=2 * H * L, cols=Hv)
         p = 'roberta.encoder.output_layer.'
         self.final = dict(idx=d.num_hidden_layers, sa=self_attn(p + 'attention.'), mlp=mlp(p))

@@ -13,35 +13,21 @@ permuted view of the final buffer.
 import torch
 import torch.nn.functional as F
 
-import os
-
 from .. import ops
 from .._lib import ACT_QUICKGELU, ACT_RELU2, ACT_SAVED_GRAD, COLSTAT_SLABS, IDENT, RowMap
 from ..config import LABEL_DOMAINS
-
-# data gradients of the stems' 3x3 convolutions: implicit GEMMs gathered from dY (round 3) instead of dcol = dY . W + col2im
-# (PRISMER_IMPLICIT_DGRAD=0: the round-2 path, kept as the A/B reference)
-IMPLICIT_DGRAD = os.environ.get('PRISMER_IMPLICIT_DGRAD', '1') != '0'
-# stems: one grouped, K-split launch per layer for the conv weight gradients (ops.wgrad_split_grouped).  Built and measured in round 3: 43
-# launches fewer per step, step time +0.05 ms in two same-box pairs (25.53 / 25.60 -> 25.57 / 25.66 ms) -- every single launch already
-# split K far enough to fill the chip, so only their fixed cost was at stake.  Off by default.
-GROUP_WGRAD = os.environ.get('PRISMER_GROUP_WGRAD', '0') != '0'
-DEFER_REDUCE = os.environ.get('PRISMER_DEFER_REDUCE', '1') != '0'       # stems: the conv weight gradients' split-K fold passes, grouped per layer
 
 BF16, F32 = torch.bfloat16, torch.float32
 
 
 # Activations inside a Linear: the forward epilogue stores act'(x) (bf16, taken from the fp32 accumulator) instead of x, and the
 # backward GEMM multiplies by it -- nothing in the backward needs x itself, and its epilogue loses two transcendentals per
-# element (QuickGELU' / erf-GELU').  PRISMER_SAVE_ACT_GRAD=0: store x and recompute act' (round-1 behaviour, A/B switch).
-SAVE_ACT_GRAD = os.environ.get('PRISMER_SAVE_ACT_GRAD', '1') != '0'
-# expert stems: 'grouped' = layer-synchronous grouped launches with implicit-GEMM convolutions (default); 'explicit' = one chain
-# per stem over im2col matrices (round-1 form, kept as the A/B reference)
-GROUPED_STEMS = os.environ.get('PRISMER_STEMS', 'grouped') != 'explicit'
+# element (QuickGELU' / erf-GELU').
+SAVE_ACT_GRAD = True
 
 
 def _bwd_act(act):
-    return ACT_SAVED_GRAD if SAVE_ACT_GRAD else act
+    return ACT_SAVED_GRAD
 
 
 def _rup(x, m):
@@ -99,8 +85,15 @@ class LN:
 class EncoderProgram:
     def __init__(self, module, dims, store):
         self.mod, self.d, self.P = module, dims, store
-        self._arena, self._arena_off, self._bn_counters = None, 0, []
         d, P = dims, store
+        # BatchNorm's num_batches_tracked of every stem layer live in ONE int64 buffer (the module buffers are 0-dim views of it, so
+        # state_dict / load_state_dict see them unchanged): a training forward increments all of them with one ph_add_i64 launch
+        bns = [m for dom in getattr(module, 'conv1', {}) if dom != 'rgb' for m in module.conv1[dom] if isinstance(m, torch.nn.BatchNorm2d)]
+        self._bn_flat = None
+        if bns:
+            self._bn_flat = torch.stack([m.num_batches_tracked.reshape(()) for m in bns]).to(torch.int64).contiguous()
+            for i, m in enumerate(bns):
+                m._buffers['num_batches_tracked'] = self._bn_flat[i]
         W = d.width
         self.Kp_rgb = _rup(3 * d.patch_size ** 2, 8)
         self.experts = [e for e in d.experts if e != 'rgb']
@@ -182,80 +175,6 @@ class EncoderProgram:
         ops.scatter_taps(dpos_e, g, idx, w, d.expert_grid ** 2, 16, d.width)
 
     # ---------------------------------------------------------------------------------------- expert stems
-    def _bn_arena(self, n_experts, per_channel):
-        """one zeroed fp32 block holding per_channel * C floats for every BatchNorm layer of every stem (ONE memset per
-        pass instead of one per layer); handed out front to back by _bn_take."""
-        d = self.d
-        total = n_experts * per_channel * sum(d.width // k for k in (8, 4, 2, 1))
-        self._arena = torch.zeros(total, dtype=F32, device=self.P.master.device)
-        self._arena_off = 0
-
-    def _bn_take(self, n):
-        a = getattr(self, '_arena', None)
-        if a is None or self._arena_off + n > a.numel():
-            return None
-        o = self._arena_off
-        self._arena_off = o + n
-        return a[o:o + n]
-
-    def stem_fwd(self, dom, x, training, sv):
-        d = self.d
-        label = dom in LABEL_DOMAINS
-        Hs = int(d.expert_resolution * (4 if label else 16) / d.patch_size)
-        strides = (2, 2, 1, 1) if label else (2, 2, 2, 2)
-        if isinstance(x, dict):                                # compact label expert: uint8 map + CLIP-feature table (in-painted on device)
-            a = ops.inpaint_resize(x['label_map'], x['table'], Hs, Hs)
-            B, Cin = a.shape[0], a.shape[3]
-        else:
-            B, Cin = x.shape[0], x.shape[1]
-            a = ops.resize_to_nhwc(x, Hs, Hs)
-        seq = self.mod.conv1[dom]
-        H, C = Hs, Cin
-        scale = shift = None
-        cols, ys, stats, geo = [], [], [], []
-        for i, s in enumerate(strides):
-            wname = f'conv1.{dom}.{1 + 3 * i}.weight'
-            shadow, Kp = self.conv_shadow(wname, 3)
-            col = ops.im2col(a, B, H, H, C, 3, s, Kp, scale, shift)
-            y = ops.gemm(col, shadow)
-            bn = seq[2 + 3 * i]
-            slot = self._bn_take(4 * y.shape[1])
-            st = ops.bn_stats(y, self.P.f(f'conv1.{dom}.{2 + 3 * i}.weight'), self.P.f(f'conv1.{dom}.{2 + 3 * i}.bias'),
-                              bn.running_mean, bn.running_var, training, bn.momentum, bn.eps,
-                              out=None if slot is None else slot.view(4, y.shape[1]))
-            if training:
-                self._bn_counters.append(bn.num_batches_tracked)     # += 1 for all layers in one launch (forward_front)
-            geo.append((H, C, s, Kp))
-            H = ops.conv_out_size(H, 3, s)
-            C = y.shape[1]
-            cols.append(col); ys.append(y); stats.append(st)
-            a, scale, shift = y, st[2], st[3]
-        shadow, Kp = self.conv_shadow(f'conv1.{dom}.13.weight', 1)
-        col = ops.im2col(a, B, H, H, C, 1, 1, Kp, scale, shift)          # relu(bn(y_3)) materialised once
-        feat = ops.gemm(col, shadow)
-        if sv is not None:
-            sv[dom] = dict(cols=cols, ys=ys, stats=stats, geo=geo, col_last=col, B=B, Hlast=H)
-        return feat
-
-    def stem_bwd(self, dom, dfeat, sv):
-        s = sv[dom]
-        B = s['B']
-        w13 = f'conv1.{dom}.13.weight'
-        self.conv_wgrad(w13, 1, dfeat, s['col_last'])
-        shadow, _ = self.conv_shadow(w13, 1)
-        da = ops.gemm(dfeat, shadow, trans_b=True)                       # grad wrt relu(bn(y_3))
-        for i in (3, 2, 1, 0):
-            H, C, stride, Kp = s['geo'][i]
-            gname, bname = f'conv1.{dom}.{2 + 3 * i}.weight', f'conv1.{dom}.{2 + 3 * i}.bias'
-            dy = ops.bn_relu_bwd(da, s['ys'][i], self.P.f(gname), self.P.f(bname), s['stats'][i], self.P.g(gname), self.P.g(bname),
-                                 sums=self._bn_take(2 * s['ys'][i].shape[1]))
-            wname = f'conv1.{dom}.{1 + 3 * i}.weight'
-            self.conv_wgrad(wname, 3, dy, s['cols'][i])
-            if i > 0:
-                shadow, _ = self.conv_shadow(wname, 3)
-                dcol = ops.gemm(dy, shadow, trans_b=True)
-                da = ops.col2im(dcol, B, H, H, C, 3, stride, Kp)
-
     # ---------------------------------------------------------------------------------------- expert stems, grouped (round 2)
     # The six stems are independent networks of the same depth (vit.py:88-120).  They are walked LAYER by layer, all experts of a
     # layer in one grouped launch each:
@@ -307,8 +226,6 @@ class EncoderProgram:
                 a_next = torch.empty_like(y)
                 bn_items.append(dict(y=y, a=a_next, gamma=P.f(f'conv1.{dom}.{2 + 3 * i}.weight'), beta=P.f(f'conv1.{dom}.{2 + 3 * i}.bias'),
                                      running_mean=bn.running_mean, running_var=bn.running_var, stats=stats, sums=sums))
-                if training:
-                    self._bn_counters.append(bn.num_batches_tracked)
                 e['a_in'].append(e['a']); e['ys'].append(y); e['stats'].append(stats); e['geo'].append((H, C, s_, Kp))
                 e['a'], e['H'], e['C'] = a_next.view(B, Ho, Ho, Co), Ho, Co
             if conv_items:
@@ -363,55 +280,27 @@ class EncoderProgram:
                 dys.append(dy)
             ops.bn_relu_bwd_grouped(bn_items)
             dcol_probs, dcols = [], []
-            if GROUP_WGRAD:                                        # all experts' weight gradients of this layer: one grouped, K-split launch + one fold
-                witems, wmeta = [], []
-                for dom, s, dy in zip(doms, S, dys):
-                    H, C, stride, Kp = s['geo'][i]
-                    wname = f'conv1.{dom}.{1 + 3 * i}.weight'
-                    if P.g(wname) is None:
-                        continue
-                    Co = P.shape[wname][0]
-                    if C % 8 == 0:
-                        witems.append((dy, s['a_in'][i].view(-1, C), Co, Kp, dy.shape[0], (s['B'], H, H, C, 3, stride)))
-                    else:
-                        witems.append((dy, s['col0'], Co, Kp, dy.shape[0], None))
-                    wmeta.append((P.g(wname), Co, C, Kp))
-                for ds, (gw, Co, C, Kp) in zip(ops.wgrad_split_grouped(witems), wmeta):
-                    ops.WQ.add_conv_fold(ds, gw, Co, C, 3, Kp)
             for dom, s, dy in zip(doms, S, dys):
                 H, C, stride, Kp = s['geo'][i]
                 wname = f'conv1.{dom}.{1 + 3 * i}.weight'
-                g = P.g(wname) if not GROUP_WGRAD else None
+                g = P.g(wname)
                 Co = P.shape[wname][0]
                 if g is not None:
                     if C % 8 == 0:                                 # implicit-GEMM weight gradient: the im2col view sits on the reduction side
                         ds = ops.gemm(dy, s['a_in'][i].view(-1, C), trans_a=True, trans_b=True, out_f32=True, M=Co, N=Kp, K=dy.shape[0],
-                                      conv=(s['B'], H, H, C, 3, stride), defer_reduce=DEFER_REDUCE)
+                                      conv=(s['B'], H, H, C, 3, stride), defer_reduce=True)
                     else:
                         ds = ops.gemm(dy, s['col0'], trans_a=True, trans_b=True, out_f32=True, M=Co, N=Kp, K=dy.shape[0],
-                                      defer_reduce=DEFER_REDUCE)
+                                      defer_reduce=True)
                     ops.WQ.add_conv_fold(ds, g, Co, C, 3, Kp)
                 if i > 0:
-                    if IMPLICIT_DGRAD:
-                        da = torch.empty(s['B'] * H * H, C, dtype=BF16, device=dev)
-                        dcol_probs.append((dy, self.conv_dgrad_shadow(wname, stride), da, (s['B'], H, H, C, Co, stride)))
-                        dcols.append(da)
-                    else:
-                        shadow, _ = self.conv_shadow(wname, 3)
-                        dcol = torch.empty(dy.shape[0], Kp, dtype=BF16, device=dev)
-                        dcol_probs.append((dy, shadow, dcol, dy.shape[0], Kp, Co))
-                        dcols.append(dcol)
-            if DEFER_REDUCE:
-                ops.gemm_flush_deferred()                        # the split-K fold passes of this layer's weight gradients: one grouped launch
-            if i > 0 and IMPLICIT_DGRAD:
+                    da = torch.empty(s['B'] * H * H, C, dtype=BF16, device=dev)
+                    dcol_probs.append((dy, self.conv_dgrad_shadow(wname, stride), da, (s['B'], H, H, C, Co, stride)))
+                    dcols.append(da)
+            ops.gemm_flush_deferred()                            # the split-K fold passes of this layer's weight gradients: one grouped launch
+            if i > 0:
                 ops.conv_dgrad_grouped(dcol_probs)               # data gradients gathered from dY (no dcol matrix, no col2im pass)
                 das = dcols
-            elif i > 0:
-                ops.gemm_grouped(dcol_probs, trans_b=True)
-                das = []
-                for s, dcol in zip(S, dcols):
-                    H, C, stride, Kp = s['geo'][i]
-                    das.append(ops.col2im(dcol, s['B'], H, H, C, 3, stride, Kp))
 
     # ---------------------------------------------------------------------------------------- resampler
     def resampler_fwd(self, xf, B, h, sv):
@@ -572,41 +461,24 @@ class EncoderProgram:
             xf = torch.empty(B * Mx, W, dtype=BF16, device=dev)
             pos_e = self.expert_pos()
             keep = []
-            self._bn_counters = []
-            grouped = GROUPED_STEMS
-            feats = self.stems_fwd(x, names, training, sv) if grouped else None
-            if not grouped:
-                self._bn_arena(len(names), 4)
-            for ei, name in enumerate(names):                  # the stems are independent: parallel graph branches
-                with ops.POOL.branch(ei):
-                    dom = 'seg' if 'seg' in name else name
-                    val = x[name]
-                    if grouped:
-                        f = feats[ei]
-                    else:
-                        if isinstance(val, dict) and 'label_map' in val:   # {'label_map': uint8 [B,(1,)E,E], 'table': [256,64] | [B,256,64]}
-                            inp = val
-                        else:
-                            inp = (val['label'] if name == 'obj_detection' else val).contiguous().float()
-                        f = self.stem_fwd(dom, inp, training, sv)
-                    if f.shape[0] != B * G:
-                        raise RuntimeError(f'expert map {name}: stem produced {f.shape[0] // B} tokens per image, program expects {G} '
-                                           f'(expert_resolution={d.expert_resolution})')
-                    if name == 'obj_detection':
-                        inst = self._instance_ids(val)
-                        ops.tokens_finalize(f, pos_e, xf, B, G, W, Mx, ei * G, inst, inst.shape[-1], d.expert_grid, inst_table,
-                                            P.f('instance_embedding'))
-                    else:
-                        ops.tokens_finalize(f, pos_e, xf, B, G, W, Mx, ei * G)
-                    keep.append(f)
-            ops.POOL.join()
+            feats = self.stems_fwd(x, names, training, sv)
+            for ei, name in enumerate(names):
+                val = x[name]
+                f = feats[ei]
+                if f.shape[0] != B * G:
+                    raise RuntimeError(f'expert map {name}: stem produced {f.shape[0] // B} tokens per image, program expects {G} '
+                                       f'(expert_resolution={d.expert_resolution})')
+                if name == 'obj_detection':
+                    inst = self._instance_ids(val)
+                    ops.tokens_finalize(f, pos_e, xf, B, G, W, Mx, ei * G, inst, inst.shape[-1], d.expert_grid, inst_table,
+                                        P.f('instance_embedding'))
+                else:
+                    ops.tokens_finalize(f, pos_e, xf, B, G, W, Mx, ei * G)
+                keep.append(f)
             del keep
-            self._arena = None
-            if self._bn_counters:
-                torch._foreach_add_(self._bn_counters, 1)
-                self._bn_counters = []
+            if training and self._bn_flat is not None:
+                ops.add_i64(self._bn_flat, 1)
         if save:
-            sv['grouped'] = bool(names) and GROUPED_STEMS
             sv.update(B=B, names=names, rgb_col=col,
                       inst=(self._instance_ids(x['obj_detection']) if 'obj_detection' in x else None), inst_table=inst_table)
         return h, xf, sv
@@ -656,27 +528,17 @@ class EncoderProgram:
             same = d.expert_grid == d.rgb_grid
             dpos_e = gpos if same else torch.zeros(G, W, dtype=F32, device=dh.device)
             keep = []
-            grouped = sv.get('grouped', False)
-            if not grouped:
-                self._bn_arena(len(names), 2)
             for ei, name in enumerate(names):
-                dom = 'seg' if 'seg' in name else name
                 dfeat = torch.empty(B * G, W, dtype=BF16, device=dh.device)
-                if name == 'obj_detection':                    # dpos_e is shared (atomics): token gradients stay on the main stream
+                if name == 'obj_detection':
                     inst = sv['inst']
                     ops.tokens_finalize_bwd(dxf, dfeat, dpos_e, B, G, W, Mx, ei * G, inst, inst.shape[-1], d.expert_grid, sv['inst_table'],
                                             P.g('instance_embedding'))
                 else:
                     ops.tokens_finalize_bwd(dxf, dfeat, dpos_e, B, G, W, Mx, ei * G)
                 keep.append(dfeat)
-                if not grouped:
-                    with ops.POOL.branch(ei):                  # the six stem backward chains are independent
-                        self.stem_bwd(dom, dfeat, sv)
-            if grouped:
-                self.stems_bwd(['seg' if 'seg' in n else n for n in names], keep, sv)
-            ops.POOL.join()
+            self.stems_bwd(['seg' if 'seg' in n else n for n in names], keep, sv)
             del keep
-            self._arena = None
             if not same and gpos is not None:
                 self.expert_pos_bwd(dpos_e)
         drgb = torch.empty(B * N, W, dtype=BF16, device=dh.device)

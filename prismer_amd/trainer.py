@@ -22,7 +22,6 @@ reference).  DDP's per-step buffer broadcast from rank 0 is replaced by rank-loc
 """
 import contextlib
 import math
-import os
 import random
 
 import torch
@@ -41,7 +40,7 @@ class Trainer:
     def __init__(self, model, lr=5e-5, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8, min_lr=0.0, total_steps=1000,
                  task='caption', use_graph=True, process_group=None, bucket_mb=64, side_stream=False, micro_batches=1, keep_grads=False,
                  max_text_len=None, grad_payload='fp32', transport='torch.distributed', dec_backward_stages=3, lr_schedule=None,
-                 shard_optimizer=False):
+                 shard_optimizer=False, overwrite_single_writer=True, allow_eager_fallback=False):
         self.model = model
         self.enc, self.dec = model.expert_encoder, model.text_decoder
         self.init_lr, self.min_lr, self.total_steps = lr, min_lr, total_steps
@@ -94,9 +93,9 @@ class Trainer:
         self.seed = self.dec.dropout_seed()
         self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
         # optimizer stream: with N ranks the decoder's AdamW runs beside the encoder backward as soon as its buckets are reduced (an
-        # eager launch between graph replays).  One rank: measured neutral as a graph branch (28.99 vs 29.03 ms), so it simply runs
-        # after the encoder backward (PRISMER_ADAMW_OVERLAP=1 re-enables the branch for experiments).
-        self.opt_stream = torch.cuda.Stream(device=dev) if (self.world > 1 or os.environ.get('PRISMER_ADAMW_OVERLAP', '0') != '0') else None
+        # eager launch between graph replays).  One rank: measured neutral as a graph branch (28.99 vs 29.03 ms) and +0.4 ms as an eager
+        # launch on a second stream, so it simply runs after the encoder backward.
+        self.opt_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
         self.micro = micro_batches if (side_stream and micro_batches > 1) else 1
         nl = len(self.dec_prog.layers)
         k = max(1, min(dec_backward_stages, nl)) if (self.world > 1 and self.micro == 1) else 1
@@ -119,9 +118,9 @@ class Trainer:
         # uncorrelated garbage -- caught by tests/test_parity_gpu.py::test_trainer_hipgraph_step_matches_reference_golden; the same
         # kernels launched eagerly on the same streams, and graphs without branches, are exact).  A branch-free graph is a chain:
         # every kernel depends on its predecessor, nothing is left to the executor.
-        if side_stream and use_graph and os.environ.get('PRISMER_EXPERIMENTAL_GRAPH_BRANCHES', '0') == '0':
+        if side_stream and use_graph:
             raise RuntimeError('Trainer(side_stream=True, use_graph=True): graphs with forked branches are not replayed correctly on this '
-                               'ROCm (see the comment above); use one of the two, or set PRISMER_EXPERIMENTAL_GRAPH_BRANCHES=1')
+                               'ROCm (see the comment above); use one of the two')
         if side_stream:
             ops.SIDE = ops.SideStream(dev)
             ops.POOL = ops.BranchPool(dev, 3)
@@ -133,7 +132,8 @@ class Trainer:
         self.trace = []
         self._grads_clean = False
         self.keep_grads = keep_grads           # True: gradients stay readable after step() (tests); False: AdamW zeroes them
-        self._overwrite = os.environ.get('PRISMER_WGRAD_OVERWRITE', '1') != '0'      # see _wq_scope
+        self._overwrite = bool(overwrite_single_writer)          # see _wq_scope
+        self.allow_eager_fallback = bool(allow_eager_fallback)
         self._exclusive, self._keep_maps, self._count_config = None, None, None
         self._graph_no_fill = False
         self._step_open = False                # a step was started and did not reach its last segment (exception between replays)
@@ -274,11 +274,10 @@ class Trainer:
                 enc_out, self.sv_t[mi] = ep.forward_trunk(h[b0 * S:b1 * S], None if xf is None else xf[b0 * Mx:b1 * Mx], Bh, True)
                 dp.site_base = mi << 20
                 _, loss, sv_d = dp.forward(s['input_ids'][b0:b1], s['attention_mask'][b0:b1], enc_out, s['labels'][b0:b1], self.seed, True)
-                if s.get('weights') is not None:               # VQA: (weights * loss).mean()  (prismer_vqa.py:40-41)
-                    w = s['weights'][b0:b1].to(F32)
-                    dloss, losses[mi] = w / B, (loss * w).sum()
-                else:                                          # caption: loss.mean()          (prismer_caption.py:33)
-                    dloss, losses[mi] = torch.full((Bh,), 1.0 / B, dtype=F32, device=loss.device), loss.sum()
+                # caption: loss.mean() (prismer_caption.py:33); VQA: (weights * loss).mean() (prismer_vqa.py:40-41).  d(total)/d(loss_b) =
+                # weights_b / B is a static input (set_batch); the total is one ph_weighted_sum_f32 launch with scale 1/B
+                w = None if s.get('weights') is None else s['weights'][b0:b1]
+                dloss, losses[mi] = s['dloss'][b0:b1], ops.weighted_sum(loss, w, 1.0 / B)
                 st = dp.backward_start(sv_d, dloss)
                 dp.backward_layers(st, *dec_hi_lo)
                 if dec_hi_lo[1] == 0:
@@ -290,7 +289,7 @@ class Trainer:
         if len(parts) > 1:
             ops.MICRO.join()
         ops.join_side()
-        self.loss_buf = torch.stack(losses).sum() / B
+        self.loss_buf = losses[0][0] if len(losses) == 1 else torch.stack(losses).sum()      # (micro-batch slices: eager-only experiment)
 
     def _seg_dec_backward(self, hi, lo):
         """decoder layers hi-1 .. lo of the backward (+ embeddings / merged K/V when lo == 0); single-slice schedules only"""
@@ -363,7 +362,7 @@ class Trainer:
         OVERWRITTEN by their GEMM (accumulate = 0: no read of the zeroed buffer) and kept out of AdamW's zero_grad stores (keep bitmap,
         whole 1024-element chunks only) -- 0.9 GB less read and 0.9 GB less written per step at Prismer-BASE.  Everything else
         (embeddings, biases, LayerNorm / BatchNorm parameters, conv weights, tied or micro-batched weights) keeps accumulate-into-zero.
-        PRISMER_WGRAD_OVERWRITE=0 switches it off."""
+        Trainer(overwrite_single_writer=False) switches it off."""
         wq = ops.WQ
         if not self._overwrite:
             yield
@@ -500,21 +499,6 @@ class Trainer:
         s = self.static
         if self.world == 1:
             nl = len(self.dec_prog.layers)
-            if self.opt_stream is not None and os.environ.get('PRISMER_ADAMW_OVERLAP', '0') == '2':
-                # decoder AdamW as an EAGER launch on the optimizer stream between two graph replays (two independent
-                # branch-free streams overlap on this runtime, branches inside one graph do not)
-                def fork():
-                    ev = torch.cuda.Event()
-                    ev.record(torch.cuda.current_stream())
-                    self.opt_stream.wait_event(ev)
-                    with torch.cuda.stream(self.opt_stream):
-                        self._adamw(1)
-
-                def enc_bwd():
-                    self._seg_enc_trunk_backward()
-                    self._seg_enc_front_backward()
-                return [(lambda: self._seg_forward(self.static, (nl, 0)), fork),
-                        (enc_bwd, lambda: torch.cuda.current_stream().wait_stream(self.opt_stream)), (self._seg_optimizer_tail, None)]
             return [(lambda: self._seg_forward(self.static, (nl, 0)), None), (self._seg_enc_backward_with_dec_adamw, None),
                     (self._seg_optimizer_tail, None)]
         cuts = self.dec_cuts
@@ -579,7 +563,8 @@ class Trainer:
                                input_ids=torch.full((B, T), pad, dtype=input_ids.dtype, device=self.device),
                                attention_mask=torch.zeros((B, T), dtype=attention_mask.dtype, device=self.device),
                                labels=torch.full((B, T), -100, dtype=labels.dtype, device=self.device),
-                               weights=None if weights is None else torch.zeros(B, dtype=F32, device=self.device))
+                               weights=None if weights is None else torch.zeros(B, dtype=F32, device=self.device),
+                               dloss=torch.full((B,), 1.0 / B, dtype=F32, device=self.device))      # d(total) / d(loss_b): 1/B or weights_b / B
 
         def copy(dst, src, what):
             if isinstance(dst, dict):
@@ -610,6 +595,7 @@ class Trainer:
                              'of the captured program)')
         if weights is not None:
             copy(s['weights'], weights.to(F32), 'weights')
+            torch.div(s['weights'], s['weights'].shape[0], out=s['dloss'])       # (outside the captured step, like the copies above)
 
     def _snapshot(self):
         """everything a training step mutates: masters (+ bf16 shadows and derived conv shadows follow from them), Adam moments,
@@ -694,11 +680,11 @@ class Trainer:
             try:
                 self._capture()
             except Exception as e:
-                # no silent fall-back: a benchmark line must not claim graphs that did not run.  PRISMER_ALLOW_EAGER_FALLBACK=1
+                # no silent fall-back: a benchmark line must not claim graphs that did not run.  Trainer(allow_eager_fallback=True)
                 # continues with eager launches of the same kernels and flips use_graph (callers report tr.use_graph).
-                if os.environ.get('PRISMER_ALLOW_EAGER_FALLBACK', '0') == '0':
+                if not self.allow_eager_fallback:
                     raise RuntimeError(f'hipGraph capture of the training step failed ({type(e).__name__}: {e}); pass use_graph=False '
-                                       'or set PRISMER_ALLOW_EAGER_FALLBACK=1') from e
+                                       'or allow_eager_fallback=True') from e
                 import sys
                 print(f'[prismer_amd] hipGraph capture failed ({type(e).__name__}: {e}); continuing with eager launches', file=sys.stderr)
                 torch.cuda.synchronize()

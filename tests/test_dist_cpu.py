@@ -150,3 +150,59 @@ def test_reduce_scatter_all_gather_exchange(world, payload):
         assert torch.equal(out[r][1], ref)                                       # identical parameters everywhere after the gather
     want = mean * 2.0 + 1.0
     assert (ref - want).abs().max() < (1e-5 if payload == 'fp32' else 5e-2)
+
+
+def test_exchange_busy_time_accounting_on_a_fake_clock():
+    """GradExchange.timing brackets every issue() with two events and sums their distances per step (bench.py's comm_ms_total).  Here the
+    events read a fake clock that the injected collectives advance by known amounts: three steps, three stages each, buckets included."""
+    from prismer_amd.dist import GradExchange
+    clock = [0.0]
+
+    class Ev:
+        def record(self):
+            self.t = clock[0]
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+    delays = []
+
+    def all_reduce(t):
+        d = 0.25 + 1e-6 * t.numel()            # ms: a latency term plus a bandwidth term
+        delays.append(d)
+        clock[0] += d
+    ex = GradExchange(4, all_reduce, payload='fp32', chunk_elems=1000, event_factory=Ev)
+    ex.timing = True
+    flat = torch.zeros(5000)
+    want = []
+    for step in range(3):
+        ex.begin_step()
+        n0 = len(delays)
+        clock[0] += 3.0                          # compute between the stages: must NOT be counted as communication
+        ex.issue(flat, 0, 2500, 'dec0')          # 3 buckets of <= 1000 elements
+        clock[0] += 1.5
+        ex.issue(flat, 2500, 2600, 'trunk')      # 1 bucket
+        ex.issue(flat, 2600, 5000, 'front')      # 3 buckets
+        want.append(sum(delays[n0:]))
+        assert [e[3] for e in ex.log] == [3, 1, 3]
+    got = ex.collect_timing()
+    assert len(got) == 3 and all(abs(g - w) < 1e-9 for g, w in zip(got, want)), (got, want)
+    assert ex.bytes_per_step == 4 * 5000
+
+
+def test_exchange_timeline_predictor():
+    """predict_exchange (the model behind DESIGN section 6's 8-GPU expectation): hidden, exposed and serialised cases"""
+    from prismer_amd.dist import predict_exchange
+    one = predict_exchange([10.0, 5.0], [4e8, 1e8], 100.0, 1)
+    assert one['comm_ms_total'] == 0.0 and one['comm_ms_exposed'] == 0.0 and one['step_ms'] == 15.0
+    # 8 ranks, 100 GB/s per link: 400 MB all-reduce = 2 * 7/8 * 4 ms = 7 ms (+ latency), hidden behind the 10 ms that follow it
+    hid = predict_exchange([5.0, 10.0], [4e8, 0], 100.0, 8, latency_us=0.0)
+    assert abs(hid['comm_ms_total'] - 7.0) < 1e-9 and hid['comm_ms_exposed'] == 0.0 and hid['step_ms'] == 15.0
+    # the same payload completed by the LAST segment is fully exposed
+    exp = predict_exchange([5.0, 10.0], [0, 4e8], 100.0, 8, latency_us=0.0)
+    assert abs(exp['comm_ms_exposed'] - 7.0) < 1e-9 and abs(exp['step_ms'] - 22.0) < 1e-9
+    # a stage cannot start before the previous one is through: 7 ms + 7 ms behind 5 + 2 ms of compute -> 12 ms exposed... minus the overlap
+    ser = predict_exchange([5.0, 2.0], [4e8, 4e8], 100.0, 8, latency_us=0.0)
+    assert abs(ser['comm_ms_total'] - 14.0) < 1e-9 and abs(ser['comm_ms_exposed'] - 12.0) < 1e-9
+    rs = predict_exchange([5.0], [4e8], 100.0, 8, latency_us=0.0, mode='rs_ag')
+    assert abs(rs['comm_ms_total'] - 3.5) < 1e-9
+

@@ -455,7 +455,8 @@ def _check_grads_against_golden(g, named_grads, tag):
             # bar is the exact full-tensor error of PyTorch's own bf16 autocast on the reference modules (ac_rel), with the
             # 1.8x head-room a 16-projection chi-square estimate needs at the 1e-5 level
             e_proj = C.projected_error(C.grad_projections(n, gr), g['gproj.' + n]) / gn
-            bar_p = PROJ_SLACK * max(TOL_GRAD, 2.0 * float(g['ac_rel.' + n]))
+            # (stems: 1.5x autocast since round 4 -- their full-tensor error sits at 0.95x autocast's in the median, 1.42x at worst, at bs32)
+            bar_p = PROJ_SLACK * max(TOL_GRAD, (1.5 if '.conv1.' in n else 2.0) * float(g['ac_rel.' + n]))
             worst_p.append((e_proj / bar_p, e_proj, float(g['ac_rel.' + n]), n))
     worst.sort(reverse=True)
     med = float(np.median([w[2] for w in worst]))
@@ -466,6 +467,9 @@ def _check_grads_against_golden(g, named_grads, tag):
         worst_p.sort(reverse=True)
         med_p = float(np.median([w[1] for w in worst_p]))
         print(tag, 'projections: worst (err/bar, full-tensor error estimate, autocast full-tensor error, name):', worst_p[:3], 'median', med_p)
+        stem = sorted(((w[1] / max(w[2], 1e-9), w[1], w[2], w[3]) for w in worst_p if '.conv1.' in w[3] and w[2] > 0), reverse=True)
+        if stem:
+            print(tag, 'stems: worst (error / autocast error, error, autocast error, name):', stem[:4], 'median ratio', float(np.median([x[0] for x in stem])))
         assert worst_p[0][0] < 1.0, worst_p[:4]
         assert med_p < 3e-2
 
@@ -564,7 +568,7 @@ def test_bench_gradient_handling_equals_the_pinned_one():
         tr, m = _pinned_trainer(case, use_graph=True, lr=1e-4, keep_grads=keep)
         losses = [tr.step().item() for _ in range(3)]
         torch.cuda.synchronize()
-        assert (tr._exclusive is not None and len(tr._exclusive) > 50) or os.environ.get('PRISMER_WGRAD_OVERWRITE') == '0'
+        assert tr._exclusive is not None and len(tr._exclusive) > 50
         res.append((losses, [st.master[:st.n_train].clone() for st in tr.stores], [t.clone() for t in tr.m]))
         del tr, m
     (la, pa, ma), (ln, pn, mn), (lb, pb, mb) = res

@@ -1,5 +1,5 @@
 """Host-side bookkeeping of the native training step that needs no GPU: which weight gradients may be OVERWRITTEN by their GEMM
-(Trainer._finish_count, the rule behind PRISMER_WGRAD_OVERWRITE) and which chunks AdamW may leave un-zeroed (ph_adamw_keep bitmap)."""
+(Trainer._finish_count, the rule behind Trainer(overwrite_single_writer=True)) and which chunks AdamW may leave un-zeroed (ph_adamw_keep bitmap)."""
 import types
 
 import torch
