@@ -622,7 +622,7 @@ __device__ __forceinline__ void wo_apply(PH_TL_PARAM const GemmParams& p, const 
   });
 }
 // write-out of a parked tile by class (wave-uniform switch: one branch per tile)
-template <int BM, int BN, int NTHR, int NPART = 1>
+template <int BM, int BN, int NTHR, int NPART = 1, int GCAP = 4>
 __device__ __forceinline__ void tile_writeout(PH_TL_PARAM const int epi, const GemmParams& p, const float* cl, int m0, int n0, bool splitk, bool drop,
                                               const DropCtx& dc, bf16x8 (&x)[WoCfg<BM, BN, NTHR>::IT], f32x4& b0, f32x4& b1, int split_id = 0) {
   switch (epi) {
@@ -632,7 +632,7 @@ __device__ __forceinline__ void tile_writeout(PH_TL_PARAM const int epi, const G
     case EPI_RELU2_GRAD: wo_apply<EPI_RELU2_GRAD, BM, BN, NTHR, NPART>(PH_TL_ARG p, cl, m0, n0, x, b0, b1); break;
     case EPI_SAVED: wo_apply<EPI_SAVED, BM, BN, NTHR, NPART>(PH_TL_ARG p, cl, m0, n0, x, b0, b1); break;
     case EPI_F32: wo_apply<EPI_F32, BM, BN, NTHR, NPART>(PH_TL_ARG p, cl, m0, n0, x, b0, b1); break;
-    default: tile_writeout_generic<BM, BN, NTHR, NPART>(PH_TL_ARG p, cl, m0, n0, splitk, drop, dc, split_id); break;
+    default: tile_writeout_generic<BM, BN, NTHR, NPART, GCAP>(PH_TL_ARG p, cl, m0, n0, splitk, drop, dc, split_id); break;
   }
 }
 
