@@ -116,8 +116,8 @@ int ph_gemm_flush_deferred(hipStream_t stream);
 int ph_gemm_grouped_bf16(const ph_gemm_args* args, int n, hipStream_t stream);
 /* tuning hook for benchmarks and tests: variant of the big-tile (256x128, LDS-DMA) kernel -- 0 = off, 1 = plain main loop, 5 = ping-pong
  * main loop, 6 = ping-pong with the LEAN tail (no surplus DMA, no drain; default) -- and the tile count from which it is used (1 = every eligible launch, bypassing the
- * dispatch cost model); a negative value leaves the setting unchanged.  Environment defaults: PH_GEMM_BIG, PH_GEMM_BIG_MIN_TILES
- * (further switches: INTEGRATION.md section 6). */
+ * dispatch cost model); a negative value leaves the setting unchanged.  The library reads no environment variable: the defaults
+ * (6, 128) are compiled in and this call is the only switch. */
 int ph_gemm_tuning(int big_mode, int big_min_tiles);
 /* same, as a BACKGROUND launch: at most `max_blocks` blocks (0 = one per tile), each walking several tiles.  Deferred weight
  * gradients issued beside the latency-bound backward chain of the decoder (roberta.py:212-231 in reverse) then fill the

@@ -430,7 +430,7 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
       p.tiles_m = ceil_div(a->M, big::BM); p.tiles_n = ceil_div(a->N, big::BN);
       p.k_tiles_per_split = a->K / BK;
       p.ws = nullptr; p.ldws = 0;
-      return big::launch_single(p, big_mode == 1 ? 0 : (big_mode == 7 ? 7 : (big_mode == 6 ? 5 : 4)), false, a->trans_b != 0, stream);
+      return big::launch_single(p, big_mode == 1 ? 0 : (big_mode == 6 ? 5 : 4), false, a->trans_b != 0, stream);
     }
     // weight-gradient layout (A = [K][M], B = [K][N]) with a long reduction: same kernel, both operands through the transposing reads
     if (big_mode > 0 && !a->conv && !a->col_stats && a->trans_a && a->trans_b && (a->K % BK) == 0 && a->K >= 32 * BK && a->split_k <= 0 &&
@@ -438,7 +438,7 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
       p.tiles_m = ceil_div(a->M, big::BM); p.tiles_n = ceil_div(a->N, big::BN);
       p.k_tiles_per_split = a->K / BK;
       p.ws = nullptr; p.ldws = 0;
-      return big::launch_single(p, big_mode == 7 ? 7 : (big_mode == 6 ? 5 : 4), true, true, stream);
+      return big::launch_single(p, big_mode == 6 ? 5 : 4, true, true, stream);
     }
   }
 

@@ -279,215 +279,6 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Wave-specialised form (round 4): 768 threads = the 8 consumer waves of big_tile + 4 PRODUCER waves (one per SIMD) that issue every
-// LDS-DMA of the block.  Why: in the ping-pong loop a consumer wave issues its 6 DMA instructions between the barrier and the 16
-// MFMAs of its M phase, and a wave is in-order -- ~60 cycles of VMEM issue per instruction in front of (or between) MFMAs that need
-// 32 cycles each.  The timeline build puts the k-tile at ~1400 cycles against 2 x 512 cycles of MFMA issue per SIMD: the M phase
-// (512 + ~190), not the R phase (~400), sets the pace.  A producer wave issues from its own instruction stream, beside the MFMAs of
-// the consumers on the same SIMD, and owns the whole vmcnt bookkeeping: consumers only read LDS, multiply and meet the barriers.
-//   phases (one workgroup barrier each; consumers exactly as in the LEAN ping-pong loop):
-//     phase 2t   : group 0 R(t)  | group 1 M(t-1) | producers request tile t+2 (t >= 1; tiles 0..2 in the prologue)
-//     phase 2t+1 : group 0 M(t)  | group 1 R(t)   | producers wait until tile t+1 has landed
-//   RAW  tile t+1 is waited for (vmcnt(12) with tile t+2 behind it, vmcnt(0) without) before the barrier that ends phase 2t+1; its first
-//        read is group 0's R(t+1) in phase 2t+2.
-//   WAR  tile t+2 goes to stage (t+2) % 3 = the stage of tile t-1, whose last reader is group 1's R(t-1) in phase 2t-1 (lgkmcnt(0) before
-//        that phase's barrier); the request is issued in phase 2t.
-//   Every wave passes 1 + 2 nk barriers before the barrier behind the parked C tile (group 1: skew barrier in phase 0, none behind its last
-//   M phase; producers: B0, two per k-tile, then the park barrier, then they leave).  tests/test_pingpong_schedule_cpu.py checks it.
-constexpr int NTHR_WS = 768;
-template <bool TA, bool TB, bool XCD_REMAP>
-__device__ __forceinline__ void big_tile_ws(const GemmParams& p, const int block_id) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int GM = 4;
-  int tm, tn;
-  if constexpr (XCD_REMAP) {               // every XCD owns whole row panels (see big_tile)
-    const int xcd = block_id & 7, idx = block_id >> 3;
-    const int q = p.tiles_m >> 3, r = p.tiles_m & 7;
-    const int cnt = q + (xcd < r ? 1 : 0), p0 = xcd * q + min(xcd, r);
-    if (idx >= cnt * p.tiles_n) return;
-    const int group_sz = GM * p.tiles_n;
-    const int first = (idx / group_sz) * GM;
-    const int gm = min(GM, cnt - first);
-    const int rin = idx - (idx / group_sz) * group_sz;
-    tm = p0 + first + rin % gm; tn = rin / gm;
-  } else {
-    const int group_sz = GM * p.tiles_n;
-    const int first_m = (block_id / group_sz) * GM;
-    const int gm = min(GM, p.tiles_m - first_m);
-    const int rin = block_id % group_sz;
-    tm = first_m + rin % gm; tn = rin / gm;
-  }
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int nk = p.K / BK;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-
-  if (wave >= 8) {
-    // ================================================================ producer: DMA instructions pid, pid + 4, ... of every k-tile
-    const int pid = wave - 8;
-    constexpr int A_PER = BM / 8 / 4, B_PER = BN / 8 / 4;         // 8 + 4 instructions per producer wave and k-tile (1 KB each)
-    const bf16* a_src[A_PER];
-    const bf16* b_src[B_PER];
-#pragma unroll
-    for (int i = 0; i < A_PER; ++i) {
-      const int q = i * 4 + pid;                                   // instruction index inside the A image: LDS bytes [q * 1024, +1024)
-      if constexpr (TA) {
-        const int kr = q * 2 + (lane >> 5), pos = lane & 31;
-        const int c = (((pos >> 2) ^ (kr & 3)) << 2) | (pos & 3);
-        a_src[i] = p.A + (size_t)kr * p.lda + min(m0 + c * 8, p.M - 8);
-      } else {
-        const int r = q * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        a_src[i] = p.A + (size_t)min(m0 + r, p.M - 1) * p.lda + c * 8;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < B_PER; ++i) {
-      const int q = i * 4 + pid;
-      if constexpr (TB) {
-        const int kr = q * 4 + (lane >> 4), pos = lane & 15;
-        const int c = (((pos >> 2) ^ (kr & 3)) << 2) | (pos & 3);
-        b_src[i] = p.B + (size_t)kr * p.ldb + min(n0 + c * 8, p.N - 8);
-      } else {
-        const int r = q * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        b_src[i] = p.B + (size_t)min(n0 + r, p.N - 1) * p.ldb + c * 8;
-      }
-    }
-    // half 0 = A instructions 0..3 + B 0..1, half 1 = the rest: a k-tile's 12 requests are spread over both phases of the k-tile, so the
-    // LDS-DMA writes trickle in beside the consumers' fragment reads instead of arriving as one burst (LDS bandwidth is the co-limiter)
-    auto request_half = [&](int kt, int stage, auto half_c) {
-      constexpr int H = decltype(half_c)::value;
-      char* sa = smem + stage * STAGE;
-      char* sb = sa + A_BYTES;
-      const int koff = kt * BK;
-#pragma unroll
-      for (int i = H * A_PER / 2; i < (H + 1) * A_PER / 2; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t*)(a_src[i] + (TA ? (size_t)koff * p.lda : (size_t)koff)), (lptr_t*)(sa + (i * 4 + pid) * 1024), 16, 0, 0);
-#pragma unroll
-      for (int i = H * B_PER / 2; i < (H + 1) * B_PER / 2; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t*)(b_src[i] + (TB ? (size_t)koff * p.ldb : (size_t)koff)), (lptr_t*)(sb + (i * 4 + pid) * 1024), 16, 0, 0);
-    };
-    auto request = [&](int kt, int stage) { request_half(kt, stage, std::integral_constant<int, 0>{}); request_half(kt, stage, std::integral_constant<int, 1>{}); };
-    request(0, 0);
-    if (nk > 1) request(1, 1);
-    if (nk > 2) request(2, 2);
-    if (nk > 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else if (nk > 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                              // B0: tile 0 is in LDS
-    int st2 = 2;                                               // stage of tile t + 2 = (t + 2) % 3, kept incrementally
-    for (int t = 0; t < nk; ++t) {
-      const bool req = t >= 1 && t + 2 < nk;
-      // phase 2t
-#ifndef PH_WS_NOLOAD              // diagnostics build: consumers run on stale LDS contents -- the pace of the consumer loop alone
-      if (req) request_half(t + 2, st2, std::integral_constant<int, 0>{});
-#endif
-      __builtin_amdgcn_s_barrier();
-      // phase 2t+1: the second half of tile t+2, then tile t+1 must be in LDS before anybody passes this phase's barrier
-#ifndef PH_WS_NOLOAD
-      if (req) request_half(t + 2, st2, std::integral_constant<int, 1>{});
-#endif
-      if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      st2 = st2 + 1 == 3 ? 0 : st2 + 1;                         // (t = 0: stage 2 was filled in the prologue; t = 1 -> stage 0, ...)
-    }
-    __builtin_amdgcn_s_barrier();                              // the barrier behind the parked C tile
-    return;
-  }
-
-  // ==================================================================== consumers: the LEAN ping-pong loop without memory operations
-  const int wm = wave >> 1, wn = wave & 1;
-  const int grp = wave >> 2;
-  PH_TL_DECL;
-  PH_TL(0);
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  PH_TL(1);
-  __builtin_amdgcn_s_barrier();                                // B0
-  PH_TL(2);
-  if (grp) __builtin_amdgcn_s_barrier();                       // group 1 idles through phase 0
-  int st = 0;
-  auto ktile = [&](auto last_c) {
-    constexpr bool LAST = decltype(last_c)::value;
-    const char* la = smem + st * STAGE;
-    const char* lb = la + A_BYTES;
-    bf16x8 fx[BK / 16][2], fw[BK / 16][2];
-#pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) fx[kk][i] = TA ? frag_ks_dma<512>(la, wm * 64 + i * 32, kk, lane) : frag_kc(la, wm * 64 + i * 32, kk, lane);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) fw[kk][j] = TB ? frag_ks_dma<256>(lb, wn * 64 + j * 32, kk, lane) : frag_kc(lb, wn * 64 + j * 32, kk, lane);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[kk][j], fx[kk][i], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (LAST) { if (!grp) __builtin_amdgcn_s_barrier(); }       // group 1 skips the barrier behind its last M phase
-    else __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    st = st + 1 == 3 ? 0 : st + 1;
-  };
-  for (int t = 0; t + 1 < nk; ++t) ktile(std::false_type{});
-  ktile(std::true_type{});
-  PH_TL(3);
-  PH_TL(4);
-
-  // ---- epilogue: as in big_tile (the prefetched reads of the fused chain are the only memory operations a consumer wave ever waits for)
-  const int epi = epi_classify(p, false);
-  PH_WO_DECL(BM, BN, NTHR);
-  wo_prefetch<BM, BN, NTHR>(epi, p, m0, n0, PH_WO_ARGS);
-  DropCtx dc;
-  const bool drop = p.drop_p > 0.0f;
-  if (drop) dc = make_drop(p.drop_seed, p.drop_stream, p.drop_p);
-  constexpr int CH = BN / 4;
-  float* cl = reinterpret_cast<float*>(smem);
-  static_for(std::make_integer_sequence<int, 2 * 2 * 4>{}, [&](auto idx) {
-    constexpr int i = decltype(idx)::value / 8, j = (decltype(idx)::value / 4) % 2, g = decltype(idx)::value % 4;
-    const int ml = wm * 64 + i * 32 + (lane & 31);
-    const int c = (wn * 64 + j * 32 + g * 8 + (lane >> 5) * 4) >> 2;
-    f32x4 v = {acc[i][j][g * 4 + 0] * p.alpha, acc[i][j][g * 4 + 1] * p.alpha, acc[i][j][g * 4 + 2] * p.alpha,
-               acc[i][j][g * 4 + 3] * p.alpha};
-    *reinterpret_cast<f32x4*>(cl + ml * BN + ((c ^ (ml & (CH - 1))) << 2)) = v;
-  });
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  PH_TL(5);
-  tile_writeout<BM, BN, NTHR, 1, 2>(PH_TL_ARG epi, p, cl, m0, n0, false, drop, dc, PH_WO_ARGS);      // (168-register budget: generic path in groups of 2)
-  PH_TL(8);
-#ifdef PH_TIMELINE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  PH_TL(9);
-  PH_TL_FLUSH(block_id, wave >> 2, (threadIdx.x & 255) == 0);
-#endif
-}
-
-template <bool TA, bool TB>
-__global__ __launch_bounds__(NTHR_WS) void gemm_big_ws_kernel(GemmParams p) {
-  big_tile_ws<TA, TB, true>(p, blockIdx.x);
-}
-template <bool TA, bool TB>
-int launch_ws(const GemmParams& p, hipStream_t s) {
-  PH_SET_SMEM_ONCE((&gemm_big_ws_kernel<TA, TB>), SMEM);
-  count_launch(PH_GEMM_CLS_BIG);
-  hipLaunchKernelGGL((gemm_big_ws_kernel<TA, TB>), dim3(8 * ((p.tiles_m + 7) / 8) * p.tiles_n), dim3(NTHR_WS), SMEM, s, p);
-  PH_LAUNCH_CHECK("gemm_big_ws_kernel");
-  return PH_OK;
-}
 
 template <int VARIANT, bool TA, bool TB>
 __global__ __launch_bounds__(NTHR) void gemm_big_kernel(GemmParams p) {
@@ -534,10 +325,6 @@ int launch_grouped(const GroupParams& g, int total, hipStream_t s) {
 
 namespace big {
 int launch_single(const GemmParams& p, int variant, bool ta, bool tb, hipStream_t s) {
-  if (variant == 7) {                     // wave-specialised: producer waves own the LDS-DMA ring
-    if (ta) return launch_ws<true, true>(p, s);
-    return tb ? launch_ws<false, true>(p, s) : launch_ws<false, false>(p, s);
-  }
   if (ta) return variant == 5 ? launch<12, true, true>(p, s) : launch<4, true, true>(p, s);      // weight-gradient layout: ping-pong only
   // variant 5 (ping-pong + s_setprio, measured negative in round 2) gave its slot to the LEAN tail (VARIANT 12) in round 4
   if (tb) return variant == 0 ? launch<0, false, true>(p, s) : variant == 5 ? launch<12, false, true>(p, s) : launch<4, false, true>(p, s);

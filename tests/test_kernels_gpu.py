@@ -156,7 +156,7 @@ def test_gemm_grouped_capped_background_launch(ops):
 
 
 @pytest.mark.parametrize('trans_b', [False, True])
-@pytest.mark.parametrize('mode', [1, 5, 6, 7])
+@pytest.mark.parametrize('mode', [1, 5, 6])
 @pytest.mark.parametrize('M,N,K,act', [(1000, 776, 640, 1), (2048, 256, 128, 0), (515, 1536, 3072, 3)])
 def test_gemm_big_tile_lds_dma_kernel(ops, M, N, K, act, mode, trans_b):
     """the 256x128 LDS-DMA kernel (global_load_lds into a 3-stage ring, counted vmcnt, raw barriers; mode 1 = plain main loop, 5 =

@@ -176,141 +176,3 @@ def test_model_constants_match_the_kernel_source():
     assert 'if (grp) __builtin_amdgcn_s_barrier();' in body and 'if (!LEAN && !grp) __builtin_amdgcn_s_barrier();' in body
     assert 'if constexpr (LAST) { if (!grp) __builtin_amdgcn_s_barrier(); }' in body
     assert body.count('__builtin_amdgcn_s_barrier()') == 6                        # B0, skew, end of R, end of M (two forms), trailing
-
-
-# ---------------------------------------------------------------------------------------------------------------------------
-# Wave-specialised form (big_tile_ws, round 4): four producer waves issue every LDS-DMA and own the vmcnt bookkeeping, the eight
-# consumer waves only read LDS, multiply and meet the barriers.  Three actors: consumer group 0, consumer group 1, the producers.
-WS_DMA_PER_TILE = 12      # instructions per PRODUCER wave and k-tile (8 A + 4 B)
-
-
-def schedule_ws(nk, actor):
-    if actor == 'p':
-        ev = [('issue', 0, 0)]
-        if nk > 1:
-            ev += [('issue', 1, 1)]
-        if nk > 2:
-            ev += [('issue', 2, 2)]
-        ev += [('wait_vm', (min(nk, 3) - 1) * WS_DMA_PER_TILE), ('barrier',)]             # B0: tile 0 landed
-        st2 = 2
-        for t in range(nk):
-            req = t >= 1 and t + 2 < nk
-            if req:
-                ev += [('issue_half', t + 2, st2, 0)]                                     # first six requests of tile t+2 in phase 2t ...
-            ev += [('barrier',)]                                                          # end of phase 2t
-            if req:
-                ev += [('issue_half', t + 2, st2, 1)]                                     # ... the other six in phase 2t+1, in front of the wait
-            ev += [('wait_vm', WS_DMA_PER_TILE if t + 2 < nk else 0), ('barrier',)]        # end of phase 2t+1: tile t+1 landed
-            st2 = (st2 + 1) % 3
-        ev += [('barrier',)]                                                              # the barrier behind the parked C tile
-        return ev
-    ev = [('barrier',)]
-    if actor:
-        ev += [('barrier',)]                      # group 1 idles through phase 0
-    st = 0
-    for t in range(nk):
-        ev += [('read', t, st), ('wait_lgkm',), ('barrier',)]
-        if not (actor and t == nk - 1):
-            ev += [('barrier',)]
-        st = (st + 1) % 3
-    ev += [('park',), ('barrier',)]
-    return ev
-
-
-def run_ws(nk, mutate=None):
-    actors = [0, 1, 'p']
-    evs = {a: schedule_ws(nk, a) for a in actors}
-    if mutate:
-        evs = mutate(evs)
-    nb = {a: sum(e[0] == 'barrier' for e in evs[a]) for a in actors}
-    assert len(set(nb.values())) == 1, nb                                                 # barrier parity of all twelve waves
-    pos = {a: 0 for a in actors}
-    outstanding, pending_pub, published, landed_halves = [], set(), set(), set()
-    reads_inflight = {0: [], 1: []}
-    retired_unpub = {0: set(), 1: set()}
-    busy = {0: set(), 1: set(), 2: set()}
-    content = {0: None, 1: None, 2: None}
-    parked = {0: False, 1: False}
-    while any(pos[a] < len(evs[a]) for a in actors):
-        for a in actors:
-            while pos[a] < len(evs[a]):
-                e = evs[a][pos[a]]; pos[a] += 1
-                if e[0] == 'issue':
-                    _, tile, stage = e
-                    assert not any(parked.values()), f'nk={nk}: tile {tile} requested after a C tile was parked in the ring'
-                    assert not busy[stage], f'nk={nk}: tile {tile} overwrites stage {stage} while groups {busy[stage]} may read it'
-                    assert stage == tile % 3, (nk, tile, stage)
-                    outstanding += [(tile, stage, 0), (tile, stage, 1)]; content[stage] = tile
-                elif e[0] == 'issue_half':
-                    _, tile, stage, h = e
-                    assert not any(parked.values()), f'nk={nk}: tile {tile} requested after a C tile was parked in the ring'
-                    assert not busy[stage], f'nk={nk}: tile {tile} overwrites stage {stage} while groups {busy[stage]} may read it'
-                    assert stage == tile % 3, (nk, tile, stage)
-                    outstanding.append((tile, stage, h)); content[stage] = tile
-                elif e[0] == 'wait_vm':
-                    keep = e[1] // (WS_DMA_PER_TILE // 2)                                  # the counter counts instructions: six per half tile
-                    done, outstanding = outstanding[:len(outstanding) - keep], outstanding[len(outstanding) - keep:]
-                    landed_halves |= set(done)
-                    pending_pub |= {(t_, s_) for (t_, s_, h_) in done if (t_, s_, 1 - h_) in landed_halves}
-                elif e[0] == 'read':
-                    _, tile, stage = e
-                    assert (tile, stage) in published, f'nk={nk}: group {a} reads tile {tile} before it is published'
-                    assert content[stage] == tile, (nk, a, tile, stage, content[stage])
-                    reads_inflight[a].append(stage); busy[stage].add(a)
-                elif e[0] == 'wait_lgkm':
-                    retired_unpub[a] |= set(reads_inflight[a]); reads_inflight[a] = []
-                elif e[0] == 'park':
-                    assert not outstanding, f'nk={nk}: group {a} parks the C tile with DMA in flight {outstanding}'
-                    for stage in (0, 1, 2):
-                        assert not busy[stage], f'nk={nk}: group {a} parks over stage {stage} while {busy[stage]} may read it'
-                    parked[a] = True
-                elif e[0] == 'barrier':
-                    break
-        published |= pending_pub; pending_pub = set()
-        for a in (0, 1):
-            for stage in retired_unpub[a]:
-                busy[stage].discard(a)
-            retired_unpub[a] = set()
-    assert not outstanding and all(parked.values())
-    assert {t for t, _ in published} == set(range(nk))                                    # every k-tile was requested exactly as needed
-
-
-@pytest.mark.parametrize('nk', list(range(2, 41)) + [48, 96, 620])
-def test_wave_specialised_ring_has_no_raw_or_war_hazard(nk):
-    run_ws(nk)
-
-
-def test_ws_model_detects_an_early_request_and_a_shallow_wait():
-    def early(evs):                                # request tile t+2 one phase early (phase 2t-1): group 1 may still read tile t-1
-        ev = list(evs['p'])
-        i = next(k for k, e in enumerate(ev) if e[0] == 'issue_half' and e[1] == 3)
-        e = ev.pop(i)
-        j = max(k for k in range(i) if ev[k][0] == 'barrier')          # in front of the previous barrier
-        ev.insert(j, e)
-        return dict(evs, p=ev)
-    with pytest.raises(AssertionError):
-        run_ws(8, early)
-
-    def shallow(evs):                              # allow two tiles in flight where one is the limit: tile t+1 read before it landed
-        return dict(evs, p=[('wait_vm', 2 * WS_DMA_PER_TILE) if (e[0] == 'wait_vm' and e[1] == WS_DMA_PER_TILE) else e for e in evs['p']])
-    with pytest.raises(AssertionError):
-        run_ws(8, shallow)
-
-
-def test_ws_model_constants_match_the_kernel_source():
-    import os
-    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'prismer_amd', 'csrc', 'gemm_big.hip')).read()
-    body = src[src.index('__device__ __forceinline__ void big_tile_ws('):src.index('__global__ __launch_bounds__(NTHR_WS) void gemm_big_ws_kernel')]
-    assert 'constexpr int A_PER = BM / 8 / 4, B_PER = BN / 8 / 4;' in body and (256 // 8 + 128 // 8) // 4 == WS_DMA_PER_TILE
-    assert 'if (nk > 2) asm volatile("s_waitcnt vmcnt(24)"' in body and 'else if (nk > 1) asm volatile("s_waitcnt vmcnt(12)"' in body
-    assert 'const bool req = t >= 1 && t + 2 < nk;' in body and 'int st2 = 2;' in body
-    loop = body[body.index('for (int t = 0; t < nk; ++t) {'):]
-    h0, b1, h1, w = (loop.index('request_half(t + 2, st2, std::integral_constant<int, 0>{})'), loop.index('__builtin_amdgcn_s_barrier();'),
-                     loop.index('request_half(t + 2, st2, std::integral_constant<int, 1>{})'), loop.index('s_waitcnt vmcnt(12)'))
-    assert h0 < b1 < h1 < w                                          # half 0 | barrier | half 1, wait | barrier
-    assert 'if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");\n      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");' in body
-    prod = body[body.index('if (wave >= 8) {'):body.index('// ==================================================================== consumers')]
-    assert prod.count('__builtin_amdgcn_s_barrier()') == 4          # B0, two per k-tile, the park barrier
-    cons = body[body.index('// ==================================================================== consumers'):]
-    assert 'vmcnt' not in cons.split('// ---- epilogue')[0]          # consumers carry no memory waits in the k loop
-    assert 'if constexpr (LAST) { if (!grp) __builtin_amdgcn_s_barrier(); }' in cons

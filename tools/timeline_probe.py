@@ -170,7 +170,7 @@ def chain_case(name, call, n=40):
 
 if __name__ == '__main__':
     torch.manual_seed(0)
-    modes = [int(m) for m in os.environ.get('TL_BIG_MODES', '6,7').split(',')]       # 5: ping-pong, 6: + LEAN tail, 7: wave-specialised (producer waves own the DMA ring)
+    modes = [int(m) for m in os.environ.get('TL_BIG_MODES', '5,6').split(',')]       # 5: ping-pong, 6: + LEAN tail (default)
     for mode in modes:
         _lib.lib.ph_gemm_tuning(mode, 128)
         for cold in (False, True):
