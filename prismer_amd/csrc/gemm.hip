@@ -177,6 +177,7 @@ static int fill_params(const ph_gemm_args* a, GemmParams& p) {
   p.A = (const bf16*)a->A; p.B = (const bf16*)a->B; p.C = a->C;
   p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc;
   p.bias = a->bias; p.bias_or_zero = a->bias ? a->bias : (a->N <= PH_ZERO_BIAS_FLOATS ? zero_bias_ptr() : nullptr);
+  p.zero16 = reinterpret_cast<const bf16*>(zero_bias_ptr());
   p.pre_out = (bf16*)a->pre_out; p.act_in = (const bf16*)a->act_in; p.ld_act = a->ld_act;
   p.residual = (const bf16*)a->residual; p.ldr = a->ldr; p.res_f32 = a->residual_f32;
   p.drop_p = a->drop_p; p.drop_seed = a->drop_seed; p.drop_stream = a->drop_stream;
@@ -345,6 +346,28 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
     }
   }
   const int ta = args[0].trans_a, tb = args[0].trans_b;
+  // ---- forward-shaped implicit convolutions with many rows and a long reduction (the stems' layers 2..4 and their data gradients): the
+  // 256x128 LDS-DMA kernel with the gather in the DMA source address (round 4; the register-staged gather kernel ran them at ~410 TFLOP/s)
+  if (conv && !ta && !tb && big_mode_now() > 1 && max_blocks == 0) {
+    bool ok = true;
+    for (int i = 0; i < n && ok; ++i) {
+      const ph_gemm_args& a = args[i];
+      ok = a.M >= big::BM && a.K >= 2 * BK && (a.N % 8) == 0 && a.N >= 8 && (a.ldb % 8) == 0 && a.split_k <= 1 &&
+           (int64_t)a.conv->B * a.conv->H * a.conv->W * a.conv->C < (1ll << 31);          // 32-bit element offsets in the gather
+    }
+    if (ok) {
+      int blocks = 0;
+      for (int i = 0; i < n; ++i) {
+        g.p[i].tiles_m = ceil_div(args[i].M, big::BM); g.p[i].tiles_n = ceil_div(args[i].N, big::BN);
+        g.p[i].k_tiles_per_split = ceil_div(args[i].K, BK);
+        g.p[i].ws = nullptr; g.p[i].ldws = 0;
+        g.tile_start[i] = blocks;
+        blocks += 8 * ceil_div(g.p[i].tiles_m, 8) * g.p[i].tiles_n;          // (XCD shares, see big_tile: the blocks beyond a share exit)
+      }
+      g.tile_start[n] = blocks;
+      return big::launch_grouped_conv(g, blocks, big_mode_now() == 6 ? 5 : 4, stream);
+    }
+  }
   if (conv) {               // gathered operand: forward (NN, A = im2col view) or weight gradient (TT, B = im2col view); no prefetch ring
     PH_CHECK_ARG(ta == tb, "ph_gemm_grouped_bf16: conv gather needs the NN or the TT layout");
     if (!ta) {

@@ -24,8 +24,14 @@ constexpr int SMEM = STAGES * STAGE;                                            
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
-template <int VARIANT, bool TA, bool TB, bool XCD_REMAP>
+// CONV = 1 (round 4, the stems' 3x3 convolutions and their data gradients): the A operand is the im2col VIEW of an NHWC activation
+// (gemm_common.h, ConvGather).  LDS-DMA takes a per-lane global address, so the gather is nothing but a different source address per
+// 16-B chunk: (tap, channel) of the lane's k chunk once per k-tile, the pixel of each of its 4 rows from the loop-invariant PixRow; a
+// chunk that falls outside the image, or beyond the real K, reads the library's ZERO PAGE instead (p.zero16).  K need not be a multiple
+// of 64 here (K = 9 * 96 = 864): the chunks of B beyond K read the zero page as well.
+template <int VARIANT, bool TA, bool TB, bool XCD_REMAP, int CONV = 0>
 __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id) {
+  static_assert(CONV == 0 || (CONV == 1 && !TA && !TB && (VARIANT & 4)), "conv gather: A of a forward-shaped problem, ping-pong loop");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // tile mapping.  Hardware places block b on XCD b % 8, each XCD with its own 4-MB L2.  One-tile-per-block launches (XCD_REMAP) give every
   // XCD WHOLE row panels: XCD x owns tiles_m / 8 (+1) consecutive 256-row panels with ALL their column tiles, so an A panel is fetched
@@ -53,7 +59,7 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
     tm = first_m + rin % gm; tn = rin / gm;
   }
   const int m0 = tm * BM, n0 = tn * BN;
-  const int nk = p.K / BK;
+  const int nk = CONV ? (p.K + BK - 1) / BK : p.K / BK;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -64,9 +70,27 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
   // ---- DMA addressing: instruction i of this wave covers tile rows (i*8 + wave)*8 .. +8, lane l -> row +(l>>3), LDS slot l&7
   const bf16* a_src[A_INSTR];
   const bf16* b_src[B_INSTR];
+  // CONV: per row of the lane (loop invariant) the element offset of tap (0,0) and a 9-bit mask of the taps that fall inside the image
+  int row_off[CONV ? A_INSTR : 1], tap_ok[CONV ? A_INSTR : 1];
+  // the lane's k chunk inside a k-tile is the same for all of its instructions: ((i*8 + wave)*8 + (lane>>3)) >> 1 & 7 does not depend on i
+  const int conv_k = (((lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7))) * 8;
+  if constexpr (CONV == 1) {
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+      const PixRow px = pix_of(p.cv, min(m0 + (i * 8 + wave) * 8 + (lane >> 3), p.M - 1));
+      row_off[i] = (px.base + px.iy0 * p.cv.W + px.ix0) * p.cv.C;          // (may be negative for a border pixel: only used where the tap is valid)
+      int m = 0;
+      for (int ty = 0; ty < p.cv.kh; ++ty)
+        for (int tx = 0; tx < p.cv.kw; ++tx)
+          m |= ((unsigned)(px.iy0 + ty) < (unsigned)p.cv.H && (unsigned)(px.ix0 + tx) < (unsigned)p.cv.W) ? (1 << (ty * p.cv.kw + tx)) : 0;
+      tap_ok[i] = m;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < A_INSTR; ++i) {
-    if constexpr (TA) {   // A = [K][M]: one instruction = 2 k-rows x 512 B; lane -> k-row (lane >> 5), LDS slot lane & 31 holds chunk c
+    if constexpr (CONV == 1) {
+      a_src[i] = nullptr;
+    } else if constexpr (TA) {   // A = [K][M]: one instruction = 2 k-rows x 512 B; lane -> k-row (lane >> 5), LDS slot lane & 31 holds chunk c
       const int kr = (i * 8 + wave) * 2 + (lane >> 5), pos = lane & 31;
       const int c = (((pos >> 2) ^ (kr & 3)) << 2) | (pos & 3);
       a_src[i] = p.A + (size_t)kr * p.lda + min(m0 + c * 8, p.M - 8);
@@ -88,10 +112,67 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
       b_src[i] = p.B + (size_t)min(n0 + r, p.N - 1) * p.ldb + c * 8;
     }
   }
+  // CONV: the gathered source addresses of k-tile kt.  ~60 VALU instructions per wave: inside the ping-pong loop they run in the R phase
+  // (beside the fragment reads), NOT in front of the MFMAs of the M phase -- the phases are barrier-locked, so VALU work at the head of
+  // an M phase idles the matrix pipe of the SIMD for its whole length (first build: 440 instead of 660 TFLOP/s on the 384->768 layer).
+  const bf16* a_nxt[CONV ? A_INSTR : 1];
+  const bf16* b_nxt[CONV ? B_INSTR : 1];
+  // every scalar the per-tile address work needs is pinned in SGPRs up front: left to itself the compiler re-reads them from the kernel
+  // arguments inside the loop (s_load + s_waitcnt lgkmcnt(0) in the middle of the fragment reads) and turns the selects into branches
+  int cvW = p.cv.W, cvC = p.cv.C, cvKreal = p.cv.Kreal, cvkw = p.cv.kw, Kfull = p.K;
+  float cv_inv_c = p.cv.inv_c;
+  const bf16* conv_x = p.A;
+  const bf16* zero_pg = p.zero16 + lane * 8;          // (a wave's padding lanes read 64 different 16-B pieces of the zero page, not one address)
+  if constexpr (CONV == 1) asm volatile("" : "+s"(cvW), "+s"(cvC), "+s"(cvKreal), "+s"(cvkw), "+s"(Kfull), "+s"(cv_inv_c), "+s"(conv_x));
+  // conv_prep(kt) is called for kt = 0, 1, 2, ... in order (every wave requests its tiles in order; at the tail the clamped index
+  // repeats, see below).  C % 64 == 0 (192, 384, 768: every stem layer but the 96-channel one): a k-tile lies inside ONE tap, so the
+  // (tap, channel) bookkeeping is wave-uniform and kept incrementally on the SALU -- no per-lane division; a state that has run past the
+  // last tap (the clamped surplus requests of the non-LEAN loop) has no bit in tap_ok and reads the zero page.
+  const bool conv_c64 = CONV == 1 && (cvC & 63) == 0 && (cvKreal & 63) == 0;
+  int s_ky = 0, s_kx = 0, s_c0 = 0, s_tap = 0;
+  auto conv_prep = [&](int kt) {
+    if constexpr (CONV == 1) {
+      const int koff = kt * BK;
+      const int k = koff + conv_k;
+      int tap_off, tap_bit;
+      if (conv_c64) {
+        tap_off = (s_ky * cvW + s_kx) * cvC + s_c0 + conv_k;
+        tap_bit = s_tap < 16 ? (1 << s_tap) : 0;
+        s_c0 += BK;
+        if (s_c0 >= cvC) { s_c0 = 0; ++s_tap; ++s_kx; if (s_kx == cvkw) { s_kx = 0; ++s_ky; } }
+      } else {
+        const bool kin = k < cvKreal;
+        const int kk = kin ? k : 0;
+        const int tap = fdiv(kk, cvC, cv_inv_c), c0 = kk - tap * cvC;
+        const int ky = cvkw == 3 ? (tap >= 6 ? 2 : (tap >= 3 ? 1 : 0)) : (cvkw == 2 ? (tap >> 1) : tap), kx = tap - ky * cvkw;
+        tap_off = (ky * cvW + kx) * cvC + c0;
+        tap_bit = kin ? (1 << tap) : 0;
+      }
+#pragma unroll
+      for (int i = 0; i < A_INSTR; ++i) {
+        const bf16* src = conv_x + (row_off[i] + tap_off);
+        a_nxt[i] = (tap_ok[i] & tap_bit) ? src : zero_pg;
+      }
+      const bool bin = k < Kfull;
+#pragma unroll
+      for (int i = 0; i < B_INSTR; ++i) { const bf16* src = b_src[i] + koff; b_nxt[i] = bin ? src : zero_pg; }
+#pragma unroll
+      for (int i = 0; i < A_INSTR; ++i) asm volatile("" : "+v"(a_nxt[i]));      // computed HERE (volatile asms keep their order: in front of the phase's wait)
+#pragma unroll
+      for (int i = 0; i < B_INSTR; ++i) asm volatile("" : "+v"(b_nxt[i]));
+    }
+  };
   auto issue = [&](int kt, int stage) {
     char* sa = smem + stage * STAGE;
     char* sb = sa + A_BYTES;
     const int koff = kt * BK;
+    if constexpr (CONV == 1) {          // sources prepared by conv_prep(kt) (ping-pong loop: in the R phase, see there)
+#pragma unroll
+      for (int i = 0; i < A_INSTR; ++i) __builtin_amdgcn_global_load_lds((gptr_t*)a_nxt[i], (lptr_t*)(sa + (i * 8 + wave) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < B_INSTR; ++i) __builtin_amdgcn_global_load_lds((gptr_t*)b_nxt[i], (lptr_t*)(sb + (i * 8 + wave) * 1024), 16, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < A_INSTR; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t*)(a_src[i] + (TA ? (size_t)koff * p.lda : (size_t)koff)), (lptr_t*)(sa + (i * 8 + wave) * 1024), 16, 0, 0);
@@ -162,10 +243,13 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
     // register work) and group 0 goes straight from its last barrier to the epilogue -- both groups have then passed 1 + 2*nk barriers.
     constexpr bool LEAN = (VARIANT & 8) != 0;
     const int grp = wave >> 2;
+    conv_prep(0);
     issue(0, 0);
+    conv_prep(min(1, nk - 1));
     issue(min(1, nk - 1), 1);
     if (grp) {
       if (!LEAN || nk > 2) {
+        conv_prep(min(2, nk - 1));
         issue(min(2, nk - 1), 2);
         asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       } else {
@@ -195,6 +279,14 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
         for (int i = 0; i < 2; ++i) fx[kk][i] = TA ? frag_ks_dma<512>(la, wm * 64 + i * 32, kk, lane) : frag_kc(la, wm * 64 + i * 32, kk, lane);
 #pragma unroll
         for (int j = 0; j < 2; ++j) fw[kk][j] = TB ? frag_ks_dma<256>(lb, wn * 64 + j * 32, kk, lane) : frag_kc(lb, wn * 64 + j * 32, kk, lane);
+      }
+      if constexpr (CONV == 1 && ISS0) {
+        // the sources of the tile this wave requests in M(t), worked out while the fragments arrive, behind ALL 16 fragment reads (interleaved,
+        // the VALU work delays their issue).  Measured on the 384->768 layer, one problem (tools/conv_probe.py; the materialised im2col
+        // matrix through the plain kernel: 44 us): in front of the MFMAs of the M phase 64 us (VALU at the head of a barrier-locked phase
+        // idles the matrix pipe), woven between the MFMAs 63 us, here 58 us with the per-lane division and less with the SALU bookkeeping.
+        __builtin_amdgcn_sched_barrier(0);
+        if (ISS1 || !grp) conv_prep(min(t + 2 + grp, nk - 1));
       }
       if (grp) {
         if constexpr (NEWER) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
@@ -271,6 +363,9 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
   asm volatile("" ::: "memory");
   PH_TL(5);
   tile_writeout<BM, BN, NTHR>(PH_TL_ARG epi, p, cl, m0, n0, false, drop, dc, PH_WO_ARGS);
+  if constexpr (CONV == 1) {
+    if (p.col_stats) tile_colstats<BM, BN, NTHR>(p, cl, m0, n0);       // train-mode BatchNorm sums from the parked tile
+  }
   PH_TL(8);
 #ifdef PH_TIMELINE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -320,6 +415,28 @@ int launch_grouped(const GroupParams& g, int total, hipStream_t s) {
   hipLaunchKernelGGL((gemm_big_grouped_kernel<VARIANT, TA, TB>), dim3(total < 256 ? total : 256), dim3(NTHR), SMEM, s, g);
   PH_LAUNCH_CHECK("gemm_big_grouped_kernel");
   return PH_OK;
+}
+// Forward-shaped implicit-GEMM convolutions, grouped (the same layer of several expert stems, or the parity classes of a stride-2
+// data gradient): one block per tile -- the problems' k loops differ (1, 2 or 4 taps per parity class), so the hardware's block
+// dispatch does the balancing -- numbered per problem like a single launch (XCD x owns whole 256-row panels of the problem: the
+// activation rows a panel gathers, 9 taps each, are fetched by one L2).  tile_start[] counts BLOCKS here, a multiple of 8 per problem.
+template <int VARIANT>
+__global__ __launch_bounds__(NTHR) void gemm_big_conv_kernel(GroupParams g) {
+  const int b = blockIdx.x;
+  int i = 0;
+  while (i + 1 < g.n && b >= g.tile_start[i + 1]) ++i;
+  big_tile<VARIANT, false, false, true, 1>(g.p[i], b - g.tile_start[i]);
+}
+template <int VARIANT>
+int launch_conv_t(const GroupParams& g, int blocks, hipStream_t s) {
+  PH_SET_SMEM_ONCE((&gemm_big_conv_kernel<VARIANT>), SMEM);
+  count_launch(PH_GEMM_CLS_BIG_GROUPED);
+  hipLaunchKernelGGL((gemm_big_conv_kernel<VARIANT>), dim3(blocks), dim3(NTHR), SMEM, s, g);
+  PH_LAUNCH_CHECK("gemm_big_conv_kernel");
+  return PH_OK;
+}
+int launch_grouped_conv(const GroupParams& g, int blocks, int variant, hipStream_t s) {
+  return variant == 5 ? launch_conv_t<12>(g, blocks, s) : launch_conv_t<4>(g, blocks, s);
 }
 }  // namespace big
 

@@ -63,6 +63,7 @@ struct GemmParams {
   double* col_stats;       // optional fp64 [2][N]: += column sums / sums of squares of the (bf16-rounded) outputs (BatchNorm statistics)
   int rm_wo, rm_mul, rm_sub, rm_add; float rm_inv_wo;     // output row map (rm_wo > 0): C row of result row m = m * mul - (m % wo) * sub + add
   ConvGather cv;           // CONV kernels only: geometry of the gathered operand (A for CONV=1, B for CONV=2)
+  const bf16* zero16;      // >= 16 B of device-resident zeros: what an LDS-DMA lane reads for a padding tap / a chunk beyond K (gemm_big.hip, CONV)
 };
 
 // C row of result row m (identity unless an output row map is set: parity-class data gradients of the stride-2 convolutions)
@@ -681,7 +682,7 @@ struct GroupParams {
 #define PH_SET_SMEM_ONCE(kernel_expr, bytes)                                                                                   \
   do {                                                                                                                         \
     static std::once_flag once__;                                                                                              \
-    std::call_once(once__, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_expr), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); }); \
+    std::call_once(once__, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_expr), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); }); \
   } while (0)
 // launches per kernel class since the last reset (ph_gemm_dispatch_counts): lets a test assert WHICH kernels a program ran through
 enum { PH_GEMM_CLS_128 = 0, PH_GEMM_CLS_64, PH_GEMM_CLS_KS2, PH_GEMM_CLS_BIG, PH_GEMM_CLS_BIG_GROUPED, PH_GEMM_CLS_GROUPED,
@@ -704,6 +705,7 @@ namespace big {
 constexpr int BM = 256, BN = 128;
 int launch_single(const GemmParams& p, int variant, bool ta, bool tb, hipStream_t s);
 int launch_grouped_wgrad(const GroupParams& g, int total, int variant, hipStream_t s);      // A = [K,M], B = [K,N], ping-pong, persistent grid
+int launch_grouped_conv(const GroupParams& g, int blocks, int variant, hipStream_t s);       // forward-shaped implicit-GEMM convolutions, one block per tile
 }  // namespace big
 
 }  // namespace phg

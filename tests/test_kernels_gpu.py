@@ -573,7 +573,7 @@ def test_conv_layout_grouped_kernels(ops):
 
 
 @pytest.mark.parametrize('B,H,C,Cout,stride,ks', [(3, 28, 96, 192, 2, 3), (2, 14, 64, 96, 1, 3), (2, 15, 384, 200, 2, 3), (5, 7, 768, 768, 1, 1),
-                                                  (32, 56, 96, 192, 2, 3)])
+                                                  (32, 56, 96, 192, 2, 3), (4, 15, 384, 200, 2, 3), (3, 20, 40, 72, 1, 3), (8, 28, 384, 768, 2, 3)])
 def test_implicit_gemm_conv_forward_stats_and_wgrad(ops, B, H, C, Cout, stride, ks):
     """conv as implicit GEMM (no im2col matrix): forward y = conv(x, w) with BatchNorm statistics from the epilogue, and the weight
     gradient dW = dY^T . im2col(x) with the gathered operand on the reduction side -- against F.conv2d / autograd in fp32."""
@@ -587,7 +587,15 @@ def test_implicit_gemm_conv_forward_stats_and_wgrad(ops, B, H, C, Cout, stride, 
     geo = (B, H, H, C, ks, stride)
     y = torch.empty(M, Cout, dtype=BF, device='cuda')
     slabs = torch.zeros(8, 2, Cout, device='cuda', dtype=torch.float64)          # PH_COLSTAT_SLABS replicated accumulators
+    import ctypes
+    from prismer_amd import _lib
+    cnt = (ctypes.c_int64 * 16)()
+    _lib.lib.ph_gemm_dispatch_counts(cnt, 16, 1)
     ops.conv_fwd_grouped([(x, geo, shadow, y, slabs)])
+    torch.cuda.synchronize()
+    _lib.lib.ph_gemm_dispatch_counts(cnt, 16, 0)
+    # round 4: >= 256 rows and K >= 128 take the 256x128 LDS-DMA kernel (gather in the DMA source address), the rest the register-staged one
+    assert (cnt[4], cnt[5]) == ((1, 0) if M >= 256 and Kp >= 128 else (0, 1)), list(cnt)[:7]
     stats = slabs.sum(0)
     xr = x.float().permute(0, 3, 1, 2).requires_grad_(False)
     wr = shadow[:, :ks * ks * C].float().view(Cout, ks, ks, C).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
@@ -613,7 +621,8 @@ def test_implicit_gemm_conv_forward_stats_and_wgrad(ops, B, H, C, Cout, stride, 
     assert float(ds[:, ks * ks * C:].abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize('B,H,C,Cout,stride', [(2, 16, 24, 40, 2), (3, 12, 96, 64, 1), (2, 28, 96, 192, 2), (1, 8, 8, 16, 2), (4, 56, 96, 192, 2)])
+@pytest.mark.parametrize('B,H,C,Cout,stride', [(2, 16, 24, 40, 2), (3, 12, 96, 64, 1), (2, 28, 96, 192, 2), (1, 8, 8, 16, 2), (4, 56, 96, 192, 2),
+                                               (8, 28, 200, 384, 2), (5, 14, 384, 768, 1)])
 def test_implicit_conv_data_gradient(ops, B, H, C, Cout, stride):
     """round 3: dX of a 3x3 pad-1 convolution as implicit GEMMs gathered from dY (stride 1: one flipped-tap convolution; stride 2: one
     problem per parity class of the input pixel, rows scattered through the output row map) -- against F.conv2d autograd in fp32 and
