@@ -132,11 +132,11 @@ def kernel_family_pass(tr, steps):
 
 
 def pmc_traffic():
-    """HBM bytes per GEMM launch from the committed PMC passes (profiles/r2_pmc_gemm.json: rocprofv3 --pmc FETCH_SIZE and
-    WRITE_SIZE in separate runs of this bench, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md; tools/run13.sh is the
+    """HBM bytes per GEMM launch from the committed PMC passes (profiles/rN_pmc_gemm.json, newest round first: rocprofv3 --pmc FETCH_SIZE and
+    WRITE_SIZE in separate runs of this bench, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md; tools/profile_round4.sh is the
     recipe); counters cannot be read from inside the process, so this is (None, None) when the file is absent.  Returns the
     per-launch bytes and the launch count the passes saw, so that a stale file shows next to the live launch count."""
-    for name in ('r3_pmc_gemm.json', 'r2_pmc_gemm.json', 'r1_pmc_gemm.json'):
+    for name in ('r4_pmc_gemm.json', 'r3_pmc_gemm.json', 'r2_pmc_gemm.json', 'r1_pmc_gemm.json'):
         p = os.path.join(ROOT, 'profiles', name)
         if os.path.isfile(p):
             d = json.load(open(p))
