@@ -58,6 +58,7 @@ class Trainer:
         self.it = 0
         self.graphs = None
         self.static = None
+        self.staging = None                    # second input buffer set of prefetch_batch / commit_prefetched
         self.enc.train(); self.dec.train()
         self.enc_prog, self.dec_prog = self.enc._program(), self.dec._program()
         self.stores = [self.enc._store, self.dec._store]
@@ -566,6 +567,12 @@ class Trainer:
                                weights=None if weights is None else torch.zeros(B, dtype=F32, device=self.device),
                                dloss=torch.full((B,), 1.0 / B, dtype=F32, device=self.device))      # d(total) / d(loss_b): 1/B or weights_b / B
 
+        self._bind(self.static, experts, input_ids, attention_mask, labels, weights)
+
+    def _bind(self, s, experts, input_ids, attention_mask, labels, weights):
+        """copies one batch into the buffer set `s` (the static inputs of the captured step, or the staging set of prefetch_batch)"""
+        pad = self.dec.config.pad_token_id
+
         def copy(dst, src, what):
             if isinstance(dst, dict):
                 if not isinstance(src, dict) or set(src) != set(dst):
@@ -586,7 +593,6 @@ class Trainer:
             if src.shape[1] < T:
                 dst.fill_(fill)
             dst[:, :src.shape[1]].copy_(src, non_blocking=True)
-        s = self.static
         copy(s['experts'], experts, 'experts')
         copy_text(s['input_ids'], input_ids, pad, 'input_ids'); copy_text(s['attention_mask'], attention_mask, 0, 'attention_mask')
         copy_text(s['labels'], labels, -100, 'labels')
@@ -596,6 +602,39 @@ class Trainer:
         if weights is not None:
             copy(s['weights'], weights.to(F32), 'weights')
             torch.div(s['weights'], s['weights'].shape[0], out=s['dloss'])       # (outside the captured step, like the copies above)
+
+    # ---- input pipeline overlap (round 4): the reference's DataLoader(pin_memory=True) + .to(device, non_blocking=True) hides the
+    # host-to-device copy of batch i+1 behind step i (train_caption.py:121-125).  The captured step reads FIXED buffers, so the next batch
+    # is staged: prefetch_batch() copies it from (pinned) host memory into a second buffer set on a copy stream, commit_prefetched() moves
+    # it into the static buffers with device-to-device copies (56 MB: tens of microseconds) on the compute stream.
+    def prefetch_batch(self, experts, input_ids, attention_mask, labels, weights=None):
+        if self.static is None:
+            raise RuntimeError('prefetch_batch: bind the first batch with set_batch (it fixes the shapes of the captured program)')
+        if self.staging is None:
+            def clone(t):
+                return {k: clone(v) for k, v in t.items()} if isinstance(t, dict) else (None if t is None else t.clone())
+            self.staging = {k: clone(v) for k, v in self.static.items()}          # (clone, not empty: dloss = 1/B carries over when no weights are bound)
+            self.copy_stream = torch.cuda.Stream(device=self.device)
+            self._staging_ready, self._staging_free = torch.cuda.Event(), torch.cuda.Event()
+            self._staging_free.record(torch.cuda.current_stream())
+        self.copy_stream.wait_event(self._staging_free)           # the previous commit has finished reading the staging set
+        with torch.cuda.stream(self.copy_stream):
+            self._bind(self.staging, experts, input_ids, attention_mask, labels, weights)
+            self._staging_ready.record(self.copy_stream)
+
+    def commit_prefetched(self):
+        """static inputs <- the batch staged by prefetch_batch (enqueued on the current stream, behind the staging copies)"""
+        cur = torch.cuda.current_stream()
+        cur.wait_event(self._staging_ready)
+
+        def move(dst, src):
+            if isinstance(dst, dict):
+                for k in dst:
+                    move(dst[k], src[k])
+            elif dst is not None:
+                dst.copy_(src, non_blocking=True)
+        move(self.static, self.staging)
+        self._staging_free.record(cur)
 
     def _snapshot(self):
         """everything a training step mutates: masters (+ bf16 shadows and derived conv shadows follow from them), Adam moments,

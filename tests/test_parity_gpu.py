@@ -684,6 +684,44 @@ def test_set_batch_pads_text_and_rejects_other_shapes():
         tr.set_batch(to_dev(x), ids, mask, labels, torch.ones(2).cuda())
 
 
+def test_prefetched_batches_equal_bound_batches():
+    """Trainer.prefetch_batch + commit_prefetched (host batch i+1 staged on a copy stream while step i runs, moved into the static
+    buffers device-to-device) leaves exactly the inputs set_batch would have bound, for pinned host tensors, shorter captions and
+    repeated use; the loss of the following step is the loss of the bound batch."""
+    case = C.Case('tiny_caption')
+    tr, _ = _pinned_trainer(case, use_graph=False, max_text_len=16)
+    x, ids, mask, labels, _ = case.inputs()
+    xd = to_dev(x)
+
+    def host(t):
+        return {k: host(v) for k, v in t.items()} if isinstance(t, dict) else t.cpu().pin_memory()
+
+    def leaves(t):
+        if isinstance(t, dict):
+            for k in sorted(t):
+                yield from leaves(t[k])
+        elif t is not None:
+            yield t
+    x2 = {k: (v.flip(0) if not isinstance(v, dict) else {kk: vv.flip(0) for kk, vv in v.items()}) for k, v in xd.items()}     # another batch: rows swapped
+    want = []
+    for bx, n in ((x2, 10), (xd, 16), (x2, 12)):
+        tr.set_batch(bx, ids[:, :n], mask[:, :n], labels[:, :n])
+        torch.cuda.synchronize()
+        want.append(([t.clone() for t in leaves(tr.static)], tr.step().item()))
+    tr2, _ = _pinned_trainer(case, use_graph=False, max_text_len=16)
+    with pytest.raises(RuntimeError):
+        type(tr2).prefetch_batch(type('T', (), {'static': None})(), None, None, None, None)
+    tr2.prefetch_batch(host(x2), ids[:, :10].cpu().pin_memory(), mask[:, :10].cpu().pin_memory(), labels[:, :10].cpu().pin_memory())
+    for i, (bx, n) in enumerate(((xd, 16), (x2, 12), (xd, 16))):
+        tr2.commit_prefetched()
+        tr2.prefetch_batch(host(bx), ids[:, :n].cpu().pin_memory(), mask[:, :n].cpu().pin_memory(), labels[:, :n].cpu().pin_memory())      # travels while the step runs
+        torch.cuda.synchronize()
+        for a, b in zip(leaves(tr2.static), want[i][0]):
+            assert torch.equal(a, b)
+        loss = tr2.step().item()
+        assert math_close(loss, want[i][1], 2e-3), (i, loss, want[i][1])
+
+
 def _head(cls, case, train_enc=True):
     m = cls.__new__(cls)
     torch.nn.Module.__init__(m)
