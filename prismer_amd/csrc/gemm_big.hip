@@ -26,8 +26,9 @@ typedef __attribute__((address_space(3))) void lptr_t;
 
 // CONV = 1 (round 4, the stems' 3x3 convolutions and their data gradients): the A operand is the im2col VIEW of an NHWC activation
 // (gemm_common.h, ConvGather).  LDS-DMA takes a per-lane global address, so the gather is nothing but a different source address per
-// 16-B chunk: (tap, channel) of the lane's k chunk once per k-tile, the pixel of each of its 4 rows from the loop-invariant PixRow; a
-// chunk that falls outside the image, or beyond the real K, reads the library's ZERO PAGE instead (p.zero16).  K need not be a multiple
+// 16-B chunk: (tap, channel) of the lane's k chunk once per k-tile, the pixel of each of its 4 rows from loop-invariant per-row state
+// (element offset of tap (0,0) + a bit mask of the taps inside the image); a chunk that falls outside the image, or beyond the real K, reads
+// the library's ZERO PAGE instead (p.zero16).  K need not be a multiple
 // of 64 here (K = 9 * 96 = 864): the chunks of B beyond K read the zero page as well.
 template <int VARIANT, bool TA, bool TB, bool XCD_REMAP, int CONV = 0>
 __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id) {
