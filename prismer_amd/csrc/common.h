@@ -157,10 +157,19 @@ __device__ __forceinline__ void act_fwd_grad(int act, float x, float& y, float& 
   }
 }
 
-// ---- Philox4x32-10 (dropout masks are a pure function of (seed, stream, element index)) -------------
+// ---- Philox4x32-7 (dropout masks are a pure function of (seed, stream, element index)) -------------
+// Seven rounds (round 4; ten before): Philox4x32 passes BigCrush from 7 rounds on (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3",
+// SC'11, table 2; 10 is Random123's safety margin), and a round is four quarter-rate 32-bit multiplies -- ~90 cycles per wave.  At ten rounds the
+// generator was 85 % of the decoder's attention kernels (one call per 4 keys and query: 3500 of ~4000 cycles per 64-key tile; timeline:
+// 1.9 us per tile for 30 live queries).  tests/util.py mirrors the function; the masks are never compared with the reference's (its generator
+// is torch's, a different stream), only their statistics and their forward / backward consistency are tested.
+#ifndef PH_PHILOX_ROUNDS_N
+#define PH_PHILOX_ROUNDS_N 7
+#endif
+constexpr int PH_PHILOX_ROUNDS = PH_PHILOX_ROUNDS_N;      // (-DPH_PHILOX_ROUNDS_N=10: the A/B build of profiles/r4_ab_philox_rounds.txt)
 __device__ __forceinline__ u32x4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < PH_PHILOX_ROUNDS; ++r) {
     uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
     uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
     uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;

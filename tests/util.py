@@ -1,4 +1,4 @@
-"""Test helpers: error metrics and a numpy Philox4x32-10 mirror of csrc/common.h (dropout masks)."""
+"""Test helpers: error metrics and a numpy Philox4x32-7 mirror of csrc/common.h (dropout masks)."""
 import numpy as np
 import torch
 
@@ -21,13 +21,17 @@ def _mulhilo(a, b):
     return (p >> np.uint64(32)).astype(np.uint32), (p & np.uint64(0xFFFFFFFF)).astype(np.uint32)
 
 
+PHILOX_ROUNDS = 7
+
+
 def philox4x32(c0, c1, c2, c3, k0, k1):
-    """vectorised Philox4x32-10; counters are numpy uint32 arrays, keys python ints. Returns 4 uint32 arrays."""
+    """vectorised Philox4x32 with PHILOX_ROUNDS rounds (= PH_PHILOX_ROUNDS of csrc/common.h); counters are numpy uint32 arrays, keys python ints.
+    Returns 4 uint32 arrays."""
     c0 = c0.astype(np.uint32); c1 = np.broadcast_to(np.uint32(c1), c0.shape).copy() if np.isscalar(c1) else c1.astype(np.uint32)
     c2 = np.broadcast_to(np.uint32(c2), c0.shape).copy() if np.isscalar(c2) else c2.astype(np.uint32)
     c3 = np.broadcast_to(np.uint32(c3), c0.shape).copy() if np.isscalar(c3) else c3.astype(np.uint32)
     k0 = np.uint32(k0 & 0xFFFFFFFF); k1 = np.uint32(k1 & 0xFFFFFFFF)
-    for _ in range(10):
+    for _ in range(PHILOX_ROUNDS):
         hi0, lo0 = _mulhilo(c0, 0xD2511F53)
         hi1, lo1 = _mulhilo(c2, 0xCD9E8D57)
         n0 = hi1 ^ c1 ^ k0; n1 = lo1; n2 = hi0 ^ c3 ^ k1; n3 = lo0
