@@ -617,6 +617,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
   }
 }
 
+// word j of the 4-word value held by lane R of this lane's quad (DPP quad_perm broadcast: no LDS, no wait)
+template <int R>
+__device__ __forceinline__ uint32_t quad_word(const u32x4& v, int j) {
+  constexpr int ctrl = R | (R << 2) | (R << 4) | (R << 6);
+  const uint32_t w0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)v[0], ctrl, 0xf, 0xf, true);
+  const uint32_t w1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)v[1], ctrl, 0xf, 0xf, true);
+  const uint32_t w2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)v[2], ctrl, 0xf, 0xf, true);
+  const uint32_t w3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)v[3], ctrl, 0xf, 0xf, true);
+  return j == 0 ? w0 : (j == 1 ? w1 : (j == 2 ? w2 : w3));
+}
+
 // =====================================================================================================
 // backward: dK, dV  (one key per lane and sub-tile; Q / dO streamed in 64-query tiles)
 // =====================================================================================================
@@ -747,7 +758,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
               }
           } else {
 #pragma unroll
-            for (int t = 0; t < QT; ++t)
+            for (int t = 0; t < QT; ++t) {
+              // Dropout words of this lane's 4 elements (one key, queries g*4 .. g*4+3).  The mask is defined per ROW: word (key & 3) of
+              // philox(counter = (key >> 2, row id)), which suits the forward / dQ layout (one query, 4 consecutive keys per lane: one call).
+              // Here the four lanes of a quad hold keys 4j .. 4j+3 of the same four rows, i.e. they need the SAME four calls and one word of
+              // each: lane q of the quad generates the call of row q, the words travel by DPP quad broadcast (round 4: one call per lane and
+              // 4 elements instead of four -- the generator was most of this kernel's time in the decoder).
+              uint32_t rr4[4] = {0u, 0u, 0u, 0u};
+              if (drop) {
+                const uint32_t row_me = (uint32_t)((b * f.H + h) * f.Sq + qbase + qt * 16 + g * 4 + (lane & 3));
+                const u32x4 mine = philox4x32((uint32_t)(ki[t] >> 2), row_me, dc.stream, 0xa77eu, dc.k0, dc.k1);
+                const int j = lane & 3;                                            // = key & 3 (the tile's key base is a multiple of 16)
+                rr4[0] = quad_word<0>(mine, j); rr4[1] = quad_word<1>(mine, j); rr4[2] = quad_word<2>(mine, j); rr4[3] = quad_word<3>(mine, j);
+              }
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 int qi = qbase + qt * 16 + g * 4 + r;         // C layout here: row = query, col (lane & 15) = key
@@ -757,9 +780,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
                   p = __expf(sc - l4[r]);
                   float pdrop = p;
                   if (drop) {
-                    uint32_t rowid = (uint32_t)((b * f.H + h) * f.Sq + qi);
-                    u32x4 rnd = philox4x32((uint32_t)(ki[t] >> 2), rowid, dc.stream, 0xa77eu, dc.k0, dc.k1);
-                    uint32_t rr = rnd[ki[t] & 3];
+                    const uint32_t rr = rr4[r];
                     pdrop = drop_apply(dc, rr, p);
                     dpe = drop_apply(dc, rr, dp[t][r]);
                   }
@@ -770,6 +791,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
                   ds[t][qt][r] = 0.f;
                 }
               }
+            }
           }
         } else {
 #pragma unroll
