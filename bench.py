@@ -21,6 +21,7 @@ Extra legs (rank 0, N = 1 only):
 import argparse
 import ctypes
 import json
+import math
 import os
 import sys
 import time
@@ -227,7 +228,8 @@ def dropin_leg(steps=10, warmup=3, batch=32):
         loss.backward()
         opt.step()
         return loss
-    for _ in range(warmup):
+    first = step().item()
+    for _ in range(warmup - 1):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -235,8 +237,9 @@ def dropin_leg(steps=10, warmup=3, batch=32):
         loss = step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    check_loss('dropin', first, loss.item())
     return dict(value=round(batch * steps / dt, 2), unit='images/sec', batch=batch, steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 3),
-                hip_graph=False, final_loss=round(float(loss.item()), 4),
+                hip_graph=False, first_loss=round(float(first), 4), final_loss=round(float(loss.item()), 4),
                 config='Prismer-BASE caption fine-tune through the drop-in nn.Modules: model(experts, caption) -> loss.backward() -> torch.optim.AdamW '
                        '(reference loop train_caption.py:126-135), eager launches')
 
@@ -254,22 +257,36 @@ def loader_leg(steps=10, warmup=3, batch=32):
         x, ids, mask, labels = make_inputs(dims, batch, 30, 4321 + i, torch.device('cuda'), True)
         batches.append((pin(x), ids.cpu().pin_memory(), mask.cpu().pin_memory(), labels.cpu().pin_memory()))
     nbytes = sum(t.numel() * t.element_size() for t in _leaves(batches[0][0])) + sum(t.numel() * t.element_size() for t in batches[0][1:])
-    tr.set_batch(*batches[0]); tr.step()
+    tr.set_batch(*batches[0])
+    first = tr.step().item()
     tr.prefetch_batch(*batches[1])
     for i in range(1, warmup):
         tr.commit_prefetched(); tr.prefetch_batch(*batches[(i + 1) % 3]); tr.step()
     torch.cuda.synchronize()
+    losses = []
     t0 = time.perf_counter()
     for i in range(steps):                                  # batch i+1 travels over PCIe while step i runs (Trainer.prefetch_batch)
         tr.commit_prefetched()
         tr.prefetch_batch(*batches[(warmup + i + 1) % 3])
         loss = tr.step()
+        losses.append(loss.clone())                         # (device-side copy: no host synchronisation inside the timed loop)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    for l in losses:
+        check_loss('loader', first, l.item())               # EVERY timed step, not only the last one
     return dict(value=round(batch * steps / dt, 2), unit='images/sec', batch=batch, steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 3),
-                h2d_mbytes_per_step=round(nbytes / 1e6, 1), hip_graph=bool(tr.graphs is not None), final_loss=round(float(loss.item()), 4),
+                h2d_mbytes_per_step=round(nbytes / 1e6, 1), hip_graph=bool(tr.graphs is not None), first_loss=round(float(first), 4),
+                final_loss=round(float(loss.item()), 4),
                 config='Prismer-BASE caption fine-tune, native Trainer, a new batch from pinned host memory every step (prefetch_batch on a copy stream + commit_prefetched + step), '
                        'compact label experts in-painted on the device')
+
+
+def check_loss(leg, first, last):
+    """A leg whose loss is not a sane training loss must not publish a throughput (round 4: the loader leg reported 1e8..1e18 and nobody
+    looked).  Sane = finite, positive and below twice the loss of the leg's FIRST step (synthetic batches: the loss falls or stays)."""
+    first, last = float(first), float(last)
+    if not (math.isfinite(first) and math.isfinite(last)) or last <= 0.0 or last >= 2.0 * max(first, 1e-6):
+        raise RuntimeError(f'{leg}: loss check failed (first step {first:.6g}, last step {last:.6g}): the timed steps did not run on valid data')
 
 
 def _leaves(t):
@@ -357,8 +374,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        tr.step()
+    first_loss = None
+    for i in range(args.warmup):
+        l = tr.step()
+        if i == 0:
+            first_loss = float(l.item())
     barrier()
     if world > 1 and tr.exchange is not None:
         tr.exchange.timing = True                          # events on the communication stream + around the join (a few us per step)
@@ -378,6 +398,8 @@ def main():
         comm['rccl_env'] = {k: os.environ[k] for k in ('NCCL_ALGO', 'NCCL_PROTO', 'NCCL_MIN_NCHANNELS', 'NCCL_MAX_NCHANNELS', 'NCCL_NCHANNELS_PER_PEER',
                                                         'RCCL_MSCCL_ENABLE', 'HSA_ENABLE_IPC_MODE_LEGACY') if k in os.environ}
     final_loss = float(loss.item())
+    if first_loss is not None:
+        check_loss('headline', first_loss, final_loss)       # raises: no line is printed for a step that did not compute a sane loss
     if not args.no_graph and not (tr.use_graph and tr.graphs is not None):
         raise SystemExit('bench.py: hipGraph replay was requested but the Trainer is running eager launches')
 
@@ -398,7 +420,7 @@ def main():
                    'parallelism': f'dp{world}', 'ranks_in_collective': ranks_seen, 'collective_backend': ('rccl' if backend == 'nccl' else backend) if world > 1 else None,
                    'grad_exchange': dict(tr.exchange_desc() or {}, **(comm or {})) if world > 1 else None,
                    'trainable_params': n_train, 'hip_graph': bool(tr.use_graph and tr.graphs is not None),
-                   'final_loss': round(final_loss, 4)},
+                   'first_loss': None if first_loss is None else round(first_loss, 4), 'final_loss': round(final_loss, 4)},
         'step_tflops': round(value / world * gf_img / 1e3, 2),
         'step_mfma_frac': round(value / world * gf_img / 1e3 / PEAK_TFLOPS, 4),
     }
@@ -428,7 +450,8 @@ def main():
             for wl, bs, gf in (('z_base_caption', 32, 134.30), ('large_vqa', 16, 2987.8)):
                 try:
                     tr2, d2, _ = build_trainer(bs, True, 0, workload=wl)
-                    for _ in range(3):
+                    f2 = tr2.step().item()
+                    for _ in range(2):
                         tr2.step()
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
@@ -436,10 +459,11 @@ def main():
                         l2 = tr2.step()
                     torch.cuda.synchronize()
                     dt2 = time.perf_counter() - t1
+                    check_loss(wl, f2, l2.item())
                     v2 = bs * 10 / dt2
                     sec[wl] = dict(value=round(v2, 2), unit='images/sec', batch=bs, steps=10, warmup=3, ms_per_step=round(dt2 / 10 * 1e3, 3),
                                    step_mfma_frac=round(v2 * gf / 1e3 / PEAK_TFLOPS, 4), hip_graph=bool(tr2.graphs is not None),
-                                   final_loss=round(float(l2.item()), 4),
+                                   first_loss=round(float(f2), 4), final_loss=round(float(l2.item()), 4),
                                    config='PrismerZ-BASE caption fine-tune, 224^2, rgb only (BASELINE config 2)' if wl == 'z_base_caption' else
                                           'Prismer-LARGE VQAv2 fine-tune, 480^2, 6 experts, T=35+5, weighted loss (BASELINE config 5, one GPU)')
                     del tr2

@@ -31,8 +31,8 @@ typedef struct ihipStream_t* hipStream_t;
 #endif
 
 /* ABI revision: bumped whenever an argument struct or a signature changes (101: ph_conv_gather window fields, ph_gemm_args row map +
- * defer_reduce; 102: round 4).  A host built against another revision must refuse to run: ph_version() != PH_VERSION. */
-#define PH_VERSION 102
+ * defer_reduce; 102: round 4; 103: round 5 -- ph_ce_fwd takes a row_loss scratch, no memset nodes anywhere).  A host built against another revision must refuse to run: ph_version() != PH_VERSION. */
+#define PH_VERSION 103
 
 enum { PH_OK = 0, PH_ERR_BAD_ARG = -1, PH_ERR_UNSUPPORTED = -2, PH_ERR_LAUNCH = -3 };
 enum { PH_ACT_NONE = 0, PH_ACT_QUICKGELU = 1, PH_ACT_RELU2 = 2, PH_ACT_GELU = 3, PH_ACT_RELU = 4,
@@ -298,7 +298,9 @@ int ph_embed_bwd(const ph_embed_bwd_args* args, hipStream_t stream);
  * dloss[b] * (softmax - (1-eps)*onehot - eps/V) for scored tokens, 0 elsewhere (incl. row T-1 and pad columns).
  * ---------------------------------------------------------------------------------------------- */
 int ph_ce_fwd(const void* logits, int ld, const int64_t* labels, int B, int T, int V, float eps, float* loss,
-              float* row_lse, hipStream_t stream);
+              float* row_lse, float* row_loss /* fp32 [B*T] scratch, fully overwritten: per-token losses; loss[b] is their fixed-order
+              sum (no atomics, no memset in front: a captured memset node does not replay correctly on ROCm 7.0, revision 103) */,
+              hipStream_t stream);
 int ph_ce_bwd(void* logits, int ld, const int64_t* labels, int B, int T, int V, int Vpad, float eps,
               const float* row_lse, const float* dloss, hipStream_t stream);
 

@@ -152,7 +152,7 @@ _SIGS = {
     'ph_scatter_taps': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'ph_embed_fwd': (c_int, [C.POINTER(EmbedFwdArgs), c_void_p]),
     'ph_embed_bwd': (c_int, [C.POINTER(EmbedBwdArgs), c_void_p]),
-    'ph_ce_fwd': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    'ph_ce_fwd': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ph_ce_bwd': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     'ph_adamw': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_float, c_float, c_float,
                          c_float, c_float, c_int, c_void_p]),
@@ -209,7 +209,7 @@ def _load():
 
 lib, LIB_PATH = _load()
 GEMM_BIG_DEFAULT = (6, 128)    # ph_gemm_tuning(mode, min_tiles) values of the product dispatch (tests / probes restore them after an override)
-ABI_VERSION = 102          # PH_VERSION of include/prismer_hip.h these ctypes structures mirror
+ABI_VERSION = 103          # PH_VERSION of include/prismer_hip.h these ctypes structures mirror
 if lib.ph_version() != ABI_VERSION:
     raise ImportError(f'{LIB_PATH} reports ABI revision {lib.ph_version()}, this binding was written for {ABI_VERSION} '
                       '(stale build? run `python -m prismer_amd.build --force`)')

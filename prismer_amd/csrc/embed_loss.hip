@@ -190,14 +190,20 @@ __device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max) {
   return r;
 }
 
+// Per-row loss into row_loss[row] (0 for ignored / last positions), summed per sample by ce_sample_sum_kernel: no atomics and -- the round-5
+// finding -- NO hipMemsetAsync in front of the kernel: a small memset NODE of a captured hipGraph does not replay correctly on this ROCm
+// (tools/graph_memset_probe.py, profiles/r5_graph_memset_order.txt: from the second replay on it leaves junk instead of zeros), which is what
+// made the loader leg of round 4 report 1e8..1e18 losses while the training state itself stayed healthy.
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const bf16* __restrict__ logits, int ld, const int64_t* __restrict__ labels, int B,
-                                                     int T, int V, float eps, float* __restrict__ loss, float* __restrict__ row_lse) {
+                                                     int T, int V, float eps, float* __restrict__ row_loss, float* __restrict__ row_lse) {
   __shared__ float sh[4];
   int row = blockIdx.x;                 // row = b*T + t
   int b = row / T, t = row % T;
-  if (t >= T - 1) return;
-  int64_t lab = labels[(int64_t)b * T + t + 1];
-  if (lab < 0) return;                  // ignore_index = -100
+  int64_t lab = (t < T - 1) ? labels[(int64_t)b * T + t + 1] : -100;
+  if (lab < 0) {                        // ignore_index = -100 (and the last position, which has no next token)
+    if (threadIdx.x == 0) row_loss[row] = 0.f;
+    return;
+  }
   const bf16* x = logits + (int64_t)row * ld;
   float mx = -FLT_MAX, se = 0.f, sl = 0.f;
   const int nch = (V + 7) / 8;
@@ -222,8 +228,18 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const bf16* __restrict__ lo
     row_lse[row] = lse;
     float nll = lse - bf2f(x[lab]);
     float smooth = lse - gl / (float)V;
-    atomicAdd(loss + b, (1.f - eps) * nll + eps * smooth);
+    row_loss[row] = (1.f - eps) * nll + eps * smooth;
   }
+}
+
+// loss[b] = sum_t row_loss[b, t]: one wave per sample, fixed summation order (run-to-run reproducible, unlike the atomics it replaces)
+__global__ __launch_bounds__(256) void ce_sample_sum_kernel(const float* __restrict__ row_loss, int B, int T, float* __restrict__ loss) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;
+  float s = 0.f;
+  for (int t = lane; t < T; t += 64) s += row_loss[(int64_t)b * T + t];
+  s = wave_sum(s);
+  if (lane == 0) loss[b] = s;
 }
 
 __global__ __launch_bounds__(256) void ce_bwd_kernel(bf16* __restrict__ logits, int ld, const int64_t* __restrict__ labels, int B, int T, int V,
@@ -276,11 +292,11 @@ extern "C" int ph_embed_bwd(const ph_embed_bwd_args* a, hipStream_t stream) {
 }
 
 extern "C" int ph_ce_fwd(const void* logits, int ld, const int64_t* labels, int B, int T, int V, float eps, float* loss,
-                         float* row_lse, hipStream_t stream) {
-  PH_CHECK_ARG(logits && labels && loss && row_lse && ld % 8 == 0 && ld >= V && B > 0 && T > 1, "ph_ce_fwd: bad args");
+                         float* row_lse, float* row_loss, hipStream_t stream) {
+  PH_CHECK_ARG(logits && labels && loss && row_lse && row_loss && ld % 8 == 0 && ld >= V && B > 0 && T > 1, "ph_ce_fwd: bad args");
   ProfScope prof__(PH_FAM_EMBED_CE, 0.0, 2.0 * B * (double)T * V, stream);
-  (void)hipMemsetAsync(loss, 0, sizeof(float) * B, stream);
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3(B * T), dim3(256), 0, stream, (const bf16*)logits, ld, labels, B, T, V, eps, loss, row_lse);
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(B * T), dim3(256), 0, stream, (const bf16*)logits, ld, labels, B, T, V, eps, row_loss, row_lse);
+  hipLaunchKernelGGL(ce_sample_sum_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, stream, (const float*)row_loss, B, T, loss);
   PH_LAUNCH_CHECK("ce_fwd_kernel");
   return PH_OK;
 }

@@ -654,6 +654,14 @@ extern "C" int ph_col2im_nhwc(const void* dcol, void* dx, int B, int H, int W, i
 
 // Every bn_reduce block ends with 2*C fp32 global atomics (~35/ns chip-wide): with 1024 blocks they cost more than the loads
 // (A/B: 100352x192 stats 40.8 us at 1024 blocks, 21.8 us at 256).  Budget ~100k atomics per launch.
+// (a kernel, not hipMemsetAsync: a small memset NODE of a captured hipGraph does not replay correctly on ROCm 7.0 -- tools/graph_memset_probe.py)
+__global__ void zero_floats_kernel(float* __restrict__ p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+static void zero_floats(float* p, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(zero_floats_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, p, n);
+}
 static int bn_reduce_blocks(int C) { return std::max(64, 49152 / C); }
 
 extern "C" int ph_bn_stats(const void* y, int M, int C, const float* gamma, const float* beta, float* running_mean,
@@ -667,7 +675,7 @@ extern "C" int ph_bn_stats(const void* y, int M, int C, const float* gamma, cons
   PH_CHECK_ARG(shift == scale + C, "ph_bn_stats: scale/shift must be one contiguous [2*C] block");
   if (training) {
     PH_CHECK_ARG(y, "ph_bn_stats: null y");
-    if (!prezeroed) (void)hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, stream);
+    if (!prezeroed) zero_floats(sums, 2 * C, stream);
     int rpp = 256 / (C / 8);
     int grid = (int)std::min<int64_t>(ceil_div64(M, (int64_t)rpp * 8), bn_reduce_blocks(C));
     hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(grid), dim3(256), sizeof(float) * 2 * C, stream, (const bf16*)y, (const bf16*)nullptr, M,
@@ -685,7 +693,7 @@ extern "C" int ph_bn_relu_bwd(const void* da, const void* y, void* dy, int M, in
   PH_CHECK_ARG(da && y && dy && gamma && beta && mean && rstd && sums, "ph_bn_relu_bwd: null pointer");
   ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream, "ph_bn_relu_bwd");
   PH_CHECK_ARG(C % 8 == 0 && C <= 2048 && M > 0, "ph_bn_relu_bwd: C=%d unsupported", C);
-  if (!prezeroed) (void)hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, stream);
+  if (!prezeroed) zero_floats(sums, 2 * C, stream);
   int rpp = 256 / (C / 8);
   int grid = (int)std::min<int64_t>(ceil_div64(M, (int64_t)rpp * 8), bn_reduce_blocks(C));
   hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(grid), dim3(256), sizeof(float) * 2 * C, stream, (const bf16*)y, (const bf16*)da, M, C, mean,

@@ -661,9 +661,10 @@ def embed_bwd(dout, ids, word, pos, typ, gamma, beta, eps, pad_id, xhat, rstd, d
 
 def ce_fwd(logits, labels, B, T, V, eps):
     loss = torch.empty((B,), dtype=F32, device=logits.device)
-    row_lse = torch.empty((B * T,), dtype=F32, device=logits.device)
-    check(lib.ph_ce_fwd(logits.data_ptr(), logits.stride(0), labels.data_ptr(), B, T, V, eps, loss.data_ptr(), row_lse.data_ptr(),
-                        _stream()), 'ph_ce_fwd')
+    row_lse = torch.empty((2, B * T), dtype=F32, device=logits.device)           # [0]: log-sum-exp per token (kept for the backward), [1]: per-token loss scratch
+    check(lib.ph_ce_fwd(logits.data_ptr(), logits.stride(0), labels.data_ptr(), B, T, V, eps, loss.data_ptr(), row_lse[0].data_ptr(),
+                        row_lse[1].data_ptr(), _stream()), 'ph_ce_fwd')
+    row_lse = row_lse[0]
     return loss, row_lse
 
 

@@ -59,6 +59,7 @@ class Trainer:
         self.graphs = None
         self.static = None
         self.staging = None                    # second input buffer set of prefetch_batch / commit_prefetched
+        self._staged = False                   # a batch sits in the staging set, not yet committed
         self.enc.train(); self.dec.train()
         self.enc_prog, self.dec_prog = self.enc._program(), self.dec._program()
         self.stores = [self.enc._store, self.dec._store]
@@ -610,6 +611,8 @@ class Trainer:
     def prefetch_batch(self, experts, input_ids, attention_mask, labels, weights=None):
         if self.static is None:
             raise RuntimeError('prefetch_batch: bind the first batch with set_batch (it fixes the shapes of the captured program)')
+        if self._staged:
+            raise RuntimeError('prefetch_batch: a staged batch is waiting for commit_prefetched() (one staging set: a second prefetch would overwrite it)')
         if self.staging is None:
             def clone(t):
                 return {k: clone(v) for k, v in t.items()} if isinstance(t, dict) else (None if t is None else t.clone())
@@ -618,12 +621,22 @@ class Trainer:
             self._staging_ready, self._staging_free = torch.cuda.Event(), torch.cuda.Event()
             self._staging_free.record(torch.cuda.current_stream())
         self.copy_stream.wait_event(self._staging_free)           # the previous commit has finished reading the staging set
+
+        def on_device(t):
+            return any(on_device(v) for v in t.values()) if isinstance(t, dict) else (t is not None and t.is_cuda)
+        if any(on_device(t) for t in (experts, input_ids, attention_mask, labels, weights)):
+            # device-resident sources were produced on the caller's stream: the copy stream must not read them early (pinned host
+            # sources -- the loader contract this path is built for, train_caption.py:121-125 -- need no such edge)
+            self.copy_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.copy_stream):
             self._bind(self.staging, experts, input_ids, attention_mask, labels, weights)
             self._staging_ready.record(self.copy_stream)
+        self._staged = True
 
     def commit_prefetched(self):
         """static inputs <- the batch staged by prefetch_batch (enqueued on the current stream, behind the staging copies)"""
+        if not self._staged:
+            raise RuntimeError('commit_prefetched: nothing is staged (call prefetch_batch first; every staged batch is committed exactly once)')
         cur = torch.cuda.current_stream()
         cur.wait_event(self._staging_ready)
 
@@ -635,6 +648,7 @@ class Trainer:
                 dst.copy_(src, non_blocking=True)
         move(self.static, self.staging)
         self._staging_free.record(cur)
+        self._staged = False
 
     def _snapshot(self):
         """everything a training step mutates: masters (+ bf16 shadows and derived conv shadows follow from them), Adam moments,

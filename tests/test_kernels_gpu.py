@@ -767,6 +767,42 @@ def test_cross_entropy(ops, V):
     assert logits[:, V:].abs().max() == 0
 
 
+def test_cross_entropy_under_graph_replay_needs_no_zeroed_buffers(ops):
+    """Round 5: ph_ce_fwd used to zero its accumulator with hipMemsetAsync; captured, that is a 128-byte memset NODE, and such a node does
+    not replay correctly on ROCm 7.0 (tools/graph_memset_probe.py) -- the replayed step's loss was garbage while everything else was
+    healthy (round-4 loader leg).  Now: per-token losses + a fixed-order sum, every output word overwritten.  Captured with the B = 32
+    geometry of the benchmark, replayed over buffers that hold junk, against new logits each replay."""
+    B, T, V = 32, 30, 1003
+    Vp = (V + 63) // 64 * 64
+    logits = torch.zeros(B * T, Vp, dtype=BF, device='cuda')
+    labels = torch.randint(0, V, (B, T), device='cuda')
+    labels[:, :4] = -100
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.ce_fwd(logits, labels, B, T, V, 0.1)                          # warm-up outside capture
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        junk = torch.empty(B, device='cuda')                              # the block the loss vector will take
+        junk.fill_(-1.0e30)
+        del junk
+        loss, lse = ops.ce_fwd(logits, labels, B, T, V, 0.1)
+        loss.mul_(1.0)                                                    # a kernel node behind it
+    for i in range(6):
+        logits[:, :V] = rnd(B * T, V, scale=2.0, seed=90 + i)
+        g.replay()
+        torch.cuda.synchronize()
+        ref = F.cross_entropy(logits[:, :V].float().reshape(B, T, V)[:, :-1].reshape(-1, V), labels[:, 1:].reshape(-1), reduction='none',
+                              label_smoothing=0.1).view(B, -1).sum(1)
+        assert rel_fro(loss, ref) < 1e-4, (i, loss[:4], ref[:4])
+    # the sum is a fixed-order reduction: bit-identical from run to run (the atomics it replaced were not)
+    first = loss.clone()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(first, loss)
+
+
 # ---------------------------------------------------------------------------------------------- optimizer / utils
 def test_adamw_matches_torch(ops):
     n = 10007
