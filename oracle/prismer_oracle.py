@@ -15,6 +15,11 @@ from /root/reference in the build container, feeds them the synthetic weights/in
 prismer_amd/synth.py and commits the outputs under tests/golden/; tests/test_oracle_golden.py checks this
 file against those fixtures (and against the live reference when /root/reference is present).
 
+Training-mode dropout (round 5): the decoder functions take `drop(site, x)`; the masks are the caller's.  Pinned the same way: with the
+reference's nn.Dropout modules replaced by the same callable the reference classes and this file agree to fp32 round-off
+(tests/test_oracle_golden.py::test_oracle_dropout_sites_match_reference_with_identical_masks), and the committed fixtures
+tests/golden/*_drop.npz hold the reference's outputs under the masks the HIP library draws for a fixed seed.
+
 Each function cites the reference lines it follows (paths relative to /root/reference).
 """
 import math
@@ -236,8 +241,15 @@ def extended_attention_mask(attention_mask, dtype):
     return torch.zeros(B, 1, T, T, dtype=dtype).masked_fill(~keep, torch.finfo(dtype).min)
 
 
-def roberta_attention(h, kv_src, sd, p, heads, add_mask):
-    """RobertaSelfAttention + RobertaSelfOutput, roberta.py:95-126,136-140 (dropout off)."""
+def _no_dropout(site, x):
+    return x
+
+
+def roberta_attention(h, kv_src, sd, p, heads, add_mask, drop=_no_dropout, site=(0, 'self')):
+    """RobertaSelfAttention + RobertaSelfOutput, roberta.py:95-126,136-140.
+    Training-mode dropout (roberta.py:123 on the attention probabilities, roberta.py:138 on the output projection) is applied through
+    `drop(site, x)`: the caller decides the masks, so the oracle can be run with EXACTLY the masks another implementation drew
+    (site = (layer, 'self_probs' | 'self_out' | 'cross_probs' | 'cross_out')).  Default: identity = eval mode."""
     B, T, H = h.shape
     dh = H // heads
     q = linear(h, sd, p + 'self.query').reshape(B, T, heads, dh).transpose(1, 2)
@@ -246,20 +258,25 @@ def roberta_attention(h, kv_src, sd, p, heads, add_mask):
     s = q @ k.transpose(-1, -2) / math.sqrt(dh)
     if add_mask is not None:
         s = torch.clamp(s + add_mask, min=torch.finfo(s.dtype).min)              # roberta.py:113-115
-    o = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, T, H)
-    o = linear(o, sd, p + 'output.dense')
+    pr = drop((site[0], site[1] + '_probs'), torch.softmax(s, dim=-1))           # roberta.py:123
+    o = (pr @ v).transpose(1, 2).reshape(B, T, H)
+    o = drop((site[0], site[1] + '_out'), linear(o, sd, p + 'output.dense'))     # roberta.py:137-138
     return layer_norm(o + h, sd[p + 'output.LayerNorm.weight'], sd[p + 'output.LayerNorm.bias'])
 
 
-def roberta_mlp(h, sd, p):
-    """RobertaIntermediate + RobertaOutput, roberta.py:160-183."""
-    o = linear(gelu_erf(linear(h, sd, p + 'intermediate.dense')), sd, p + 'output.dense')
+def roberta_mlp(h, sd, p, drop=_no_dropout, site=(0, 'mlp')):
+    """RobertaIntermediate + RobertaOutput, roberta.py:160-183 (dropout on the output projection: roberta.py:180-181, site (layer, 'mlp_out'))."""
+    o = drop((site[0], site[1] + '_out'), linear(gelu_erf(linear(h, sd, p + 'intermediate.dense')), sd, p + 'output.dense'))
     return layer_norm(o + h, sd[p + 'output.LayerNorm.weight'], sd[p + 'output.LayerNorm.bias'])
 
 
-def text_decoder(sd, input_ids, attention_mask, enc, heads, labels=None, pad=1, label_smoothing=0.1):
-    """RobertaForCausalLMModified.forward, roberta.py:358-399 (eval mode: dropout off).
+def text_decoder(sd, input_ids, attention_mask, enc, heads, labels=None, pad=1, label_smoothing=0.1, drop=None):
+    """RobertaForCausalLMModified.forward, roberta.py:358-399.  drop=None: eval mode (dropout off).  drop=callable(site, x): training-mode
+    dropout with caller-supplied masks at every nn.Dropout of the reference decoder -- ('emb',) after the embedding LayerNorm
+    (roberta.py:74-75), (l, 'self_probs' / 'self_out' / 'cross_probs' / 'cross_out' / 'mlp_out') in layer l (roberta.py:123,138,181), the
+    output_layer counted as layer num_hidden_layers; the Adaptor and the LM head have no dropout (utils.py:47-65, roberta.py:415-430).
     sd: decoder state dict (no prefix); enc [B,S,Dv]. Returns (logits [B,T,V], loss [B] or None)."""
+    drop = drop or _no_dropout
     e = 'roberta.embeddings.'
     dtype = sd[e + 'word_embeddings.weight'].dtype
     if attention_mask is None:
@@ -270,18 +287,18 @@ def text_decoder(sd, input_ids, attention_mask, enc, heads, labels=None, pad=1, 
     # lookup (it matters when a pad sits inside a row, e.g. between question and answer: prismer_vqa.py:22-30)
     h = F.embedding(input_ids, sd[e + 'word_embeddings.weight'], padding_idx=pad) + sd[e + 'token_type_embeddings.weight'][0] \
         + F.embedding(pos_ids, sd[e + 'position_embeddings.weight'], padding_idx=pad)      # roberta.py:66-73
-    h = layer_norm(h, sd[e + 'LayerNorm.weight'], sd[e + 'LayerNorm.bias'])
+    h = drop(('emb',), layer_norm(h, sd[e + 'LayerNorm.weight'], sd[e + 'LayerNorm.bias']))     # roberta.py:74-75
     l = 0
     while f'roberta.encoder.layer.{l}.0.attention.self.query.weight' in sd:      # roberta.py:223-227
         p = f'roberta.encoder.layer.{l}.'
-        h = roberta_attention(h, h, sd, p + '0.attention.', heads, am)
-        h = roberta_attention(h, enc, sd, p + '1.', heads, None)
+        h = roberta_attention(h, h, sd, p + '0.attention.', heads, am, drop, (l, 'self'))
+        h = roberta_attention(h, enc, sd, p + '1.', heads, None, drop, (l, 'cross'))
         h = adaptor(h, sd, p + '2.', norm_late=True)
-        h = roberta_mlp(h, sd, p + '0.')
+        h = roberta_mlp(h, sd, p + '0.', drop, (l, 'mlp'))
         l += 1
     p = 'roberta.encoder.output_layer.'                                          # roberta.py:229-231
-    h = roberta_attention(h, h, sd, p + 'attention.', heads, am)
-    h = roberta_mlp(h, sd, p)
+    h = roberta_attention(h, h, sd, p + 'attention.', heads, am, drop, (l, 'self'))
+    h = roberta_mlp(h, sd, p, drop, (l, 'mlp'))
     t = layer_norm(gelu_erf(linear(h, sd, 'lm_head.dense')),
                    sd['lm_head.layer_norm.weight'], sd['lm_head.layer_norm.bias'])   # roberta.py:421-425
     logits = F.linear(t, sd['lm_head.decoder.weight'], sd['lm_head.bias'])
@@ -307,20 +324,21 @@ def shifted_smoothed_ce(logits, labels, eps=0.1):
 # ------------------------------------------------------------------ heads (training branches)
 
 def caption_loss(enc_sd, dec_sd, experts, input_ids, attention_mask, labels, dims, train_bn=False,
-                 instance_table=None, bn_updates=None):
+                 instance_table=None, bn_updates=None, drop=None):
     """PrismerCaption.forward(train=True), model/prismer_caption.py:17-34, from token ids."""
     enc = vision_encoder(enc_sd, experts, dims.patch_size, dims.vit_heads, train_bn, instance_table, bn_updates)
     enc = enc.transpose(0, 1)                                                    # 'l b d -> b l d'
     logits, loss = text_decoder(dec_sd, input_ids, attention_mask, enc, dims.num_attention_heads, labels,
-                                dims.pad_token_id, dims.label_smoothing)
+                                dims.pad_token_id, dims.label_smoothing, drop)
     return loss.mean(), logits, enc
 
 
 def vqa_loss(enc_sd, dec_sd, experts, input_ids, attention_mask, labels, weights, dims, **kw):
     """PrismerVQA.forward(train=True), model/prismer_vqa.py:22-42: (weights * per-sample loss).mean()."""
+    drop = kw.pop('drop', None)
     enc = vision_encoder(enc_sd, experts, dims.patch_size, dims.vit_heads, **kw).transpose(0, 1)
     logits, loss = text_decoder(dec_sd, input_ids, attention_mask, enc, dims.num_attention_heads, labels,
-                                dims.pad_token_id, dims.label_smoothing)
+                                dims.pad_token_id, dims.label_smoothing, drop)
     return (weights * loss).mean(), logits, enc
 
 

@@ -65,3 +65,40 @@ def reference_freeze(enc, dec, mode):
     h.text_decoder = dec
     Prismer.prepare_to_train(h, mode)
     return h
+
+
+def dropout_sites(dec):
+    """{module name: oracle dropout site} for EVERY nn.Dropout of the reference decoder (roberta.py:57,93,134,177): the site naming of
+    oracle.prismer_oracle.text_decoder.  Raises when the reference has a Dropout this mapping does not know."""
+    import re
+    import torch.nn as nn
+    nl = dec.config.num_hidden_layers
+    kinds = {'0.attention.self': 'self_probs', '0.attention.output': 'self_out', '1.self': 'cross_probs', '1.output': 'cross_out',
+             '0.output': 'mlp_out'}
+    final = {'attention.self': 'self_probs', 'attention.output': 'self_out', 'output': 'mlp_out'}
+    sites = {}
+    for name, mod in dec.named_modules():
+        if not isinstance(mod, nn.Dropout):
+            continue
+        m = re.fullmatch(r'roberta\.encoder\.layer\.(\d+)\.(.+)\.dropout', name)
+        f = re.fullmatch(r'roberta\.encoder\.output_layer\.(.+)\.dropout', name)
+        if name == 'roberta.embeddings.dropout':
+            sites[name] = ('emb',)
+        elif m and m.group(2) in kinds:
+            sites[name] = (int(m.group(1)), kinds[m.group(2)])
+        elif f and f.group(1) in final:
+            sites[name] = (nl, final[f.group(1)])
+        else:
+            raise KeyError(f'reference decoder has an nn.Dropout the oracle does not model: {name}')
+    return sites
+
+
+def patch_dropout(dec, drop):
+    """Replaces the forward of every nn.Dropout of the reference decoder by `drop(site, x)` (training-mode dropout with the caller's
+    masks) and puts the decoder in train() mode.  Returns the site map."""
+    sites = dropout_sites(dec)
+    mods = dict(dec.named_modules())
+    for name, site in sites.items():
+        mods[name].forward = (lambda x, _s=site: drop(_s, x))
+    dec.train()
+    return sites

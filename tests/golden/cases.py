@@ -52,6 +52,8 @@ LOGIT_STRIDE = {'base_caption': 97, 'base_b8': 97, 'zbase_b4': 97, 'large_vqa_b1
 ENC_STRIDE = {'base_b8': 16, 'zbase_b4': 8, 'large_vqa_b1': 16, 'base_b32': 16, 'large_vqa_b4': 16}                             # every n-th feature of the encoder output
 VQA_CASES = ('tiny_vqa', 'large_vqa_b1', 'large_vqa_b4')
 VQA_HEAD_TQ, VQA_HEAD_TA = 9, 5
+DROP_CASES = ('tiny_caption', 'base_b8')     # <case>_drop.npz: reference outputs in full training mode under the library's dropout masks (round 5)
+DROP_SEED = 0x5EED0123456789AB              # device dropout seed of step 1; step 2 uses splitmix64 of it (csrc/optim.hip advance_seed_kernel)
 
 
 class Case:

@@ -104,8 +104,85 @@ def run_case(name):
           f'total_train={out["total_train"]}  trainable={len(names)}')
 
 
+def run_drop_case(name):
+    """<case>_drop.npz (round 5): the reference classes in FULL training mode -- BatchNorm batch statistics AND the decoder's dropout
+    (configs/prismer.json: 0.1 / 0.1, the arithmetic every benchmarked step runs) -- with every nn.Dropout replaced by the masks
+    libprismer_hip draws for C.DROP_SEED (step 1) and splitmix64(C.DROP_SEED) (step 2: the library advances its device seed after every
+    step); oracle.ref_harness.patch_dropout + tests/util.LibraryDropout.  Keys: s<k>.total_train, s<k>.loss_train, s<k>.gnorm.* / gsamp.* /
+    gproj.* and the autocast yardsticks s<k>.ac_* measured under the same masks."""
+    from tests.util import LibraryDropout, splitmix64
+    case = C.Case(name)
+    d = case.dims
+    esd, dsd = case.weights()
+    x, ids, mask, labels, weights = case.inputs()
+    enc, dec = RH.build_reference(d, esd, dsd)
+    holder = RH.reference_freeze(enc, dec, 'freeze_vision')
+    enc.train()
+    out = {}
+    cur = {}
+    RH.patch_dropout(dec, lambda site, t: cur['drop'](site, t))
+
+    def fwd():
+        random.seed(C.INSTANCE_SEED)
+        e = enc(x)
+        return e, dec(ids, attention_mask=mask, encoder_hidden_states=e.permute(1, 0, 2), labels=labels, return_dict=True)
+
+    def reset():
+        for p in holder.parameters():
+            p.grad = None
+        for k, v in case.weights()[0].items():
+            if 'running_' in k or 'num_batches' in k:
+                enc.state_dict()[k].copy_(v)
+    seeds = [C.DROP_SEED, splitmix64(C.DROP_SEED)]
+    names, ref_full = [], {}
+    for si, seed in enumerate(seeds, 1):
+        reset()
+        cur['drop'] = LibraryDropout(seed, d.hidden_dropout_prob, d.attention_probs_dropout_prob)
+        e, o = fwd()
+        total = (o.loss if weights is None else weights * o.loss).mean()
+        total.backward()
+        pre = f's{si}.'
+        out[pre + 'loss_train'] = o.loss.detach().numpy()
+        out[pre + 'total_train'] = total.detach().numpy()
+        names = []
+        for n, p in holder.named_parameters():
+            if not p.requires_grad:
+                continue
+            names.append(n)
+            g = p.grad.detach()
+            out[pre + 'gnorm.' + n] = np.float64(g.double().norm().item())
+            out[pre + 'gsamp.' + n] = g.flatten()[C.sample_idx(n, g.numel())].numpy()
+            out[pre + 'gproj.' + n] = C.grad_projections(n, g)
+        ref_full[si] = {n: p.grad.detach().clone() for n, p in holder.named_parameters() if p.requires_grad}
+    out['requires_grad'] = np.array('\n'.join(names))
+    out['seeds'] = np.array(seeds, dtype=np.uint64)
+    for si, seed in enumerate(seeds, 1):                     # autocast yardsticks under the SAME masks, per step
+        pre = f's{si}.'
+        reset()
+        cur['drop'] = LibraryDropout(seed, d.hidden_dropout_prob, d.attention_probs_dropout_prob)
+        with torch.autocast('cpu', dtype=torch.bfloat16):
+            e2, o2 = fwd()
+            total2 = (o2.loss.float() if weights is None else weights * o2.loss.float()).mean()
+        total2.backward()
+        for n, p in holder.named_parameters():
+            if not p.requires_grad:
+                continue
+            ref_s = out[pre + 'gsamp.' + n]
+            gn = float(out[pre + 'gnorm.' + n])
+            sm = p.grad.detach().flatten()[C.sample_idx(n, p.numel())].float().numpy()
+            out[pre + 'ac_samp.' + n] = np.float64(np.linalg.norm(sm - ref_s) / (np.linalg.norm(ref_s) + 1e-30))
+            out[pre + 'ac_norm.' + n] = np.float64(abs(p.grad.double().norm().item() - gn) / (gn + 1e-30))
+            out[pre + 'ac_rel.' + n] = np.float64((p.grad.double() - ref_full[si][n].double()).norm().item() / (gn + 1e-30))
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), name + '_drop.npz')
+    np.savez_compressed(path, **out)
+    print(f'{name}_drop: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)  total_train s1={out["s1.total_train"]} s2={out["s2.total_train"]}')
+
+
 if __name__ == '__main__':
     assert RH.available(), 'reference not mounted'
     torch.set_num_threads(os.cpu_count())
-    for name in (sys.argv[1:] or list(C.CASES)):
-        run_case(name)
+    for name in (sys.argv[1:] or list(C.CASES) + [n + '+drop' for n in C.DROP_CASES]):
+        if name.endswith('+drop'):
+            run_drop_case(name[:-5])
+        else:
+            run_case(name)

@@ -212,3 +212,87 @@ def test_oracle_rank_matches_live_reference(head):
         eo = O.vision_encoder(esd, x, d.patch_size, d.vit_heads, False, tab)
         best, topk, lp = O.rank_answers(dsd, eo.transpose(0, 1), start_ids, start_att, a_ids, a_att, k, d.num_attention_heads, pad=d.pad_token_id)
     assert best.tolist() == want.tolist(), (best, want, lp)
+
+
+@pytest.mark.skipif(not RH.available(), reason='reference not mounted')
+@pytest.mark.parametrize('name', ['tiny_caption', 'tiny_vqa'])
+def test_oracle_dropout_sites_match_reference_with_identical_masks(name):
+    """Training-mode dropout (the benchmarked arithmetic: configs/prismer.json dropout 0.1): the reference decoder with every nn.Dropout
+    (roberta.py:57-75,93-123,134-138,177-181) replaced by `drop(site, x)` and the oracle called with the same callable agree to fp32
+    round-off in loss AND gradients -- the oracle's site placement is the reference's.  The masks are the ones libprismer_hip draws
+    (tests/util.LibraryDropout), so this also shows the whole chain the GPU test relies on."""
+    from tests.util import LibraryDropout
+    case = C.Case(name)
+    d = case.dims
+    x, ids, mask, labels, weights = case.inputs()
+    seed = 0x5EED0123456789AB
+    esd, dsd = case.weights()
+    enc, dec = RH.build_reference(d, esd, dsd)
+    holder = RH.reference_freeze(enc, dec, 'freeze_vision')
+    drop_ref = LibraryDropout(seed, 0.1, 0.1)
+    sites = RH.patch_dropout(dec, drop_ref)
+    assert len(sites) == 1 + 5 * d.num_hidden_layers + 3
+    enc.train()
+    random.seed(C.INSTANCE_SEED)
+    e = enc(x)
+    o = dec(ids, attention_mask=mask, encoder_hidden_states=e.permute(1, 0, 2), labels=labels, return_dict=True)
+    total = (o.loss if weights is None else weights * o.loss).mean()
+    total.backward()
+    # oracle, same masks
+    esd2, dsd2, _, _, _, _, _ = oracle_forward(case, True, requires_grad=True)            # (marks the leaves; its own forward has no dropout)
+    drop_o = LibraryDropout(seed, 0.1, 0.1)
+    tab = case.instance_table(x)
+    eo = O.vision_encoder(esd2, x, d.patch_size, d.vit_heads, True, tab, {})
+    logits, loss = O.text_decoder(dsd2, ids, mask, eo.transpose(0, 1), d.num_attention_heads, labels, d.pad_token_id, d.label_smoothing, drop=drop_o)
+    tot_o = (loss if weights is None else weights * loss).mean()
+    for v in list(esd2.values()) + list(dsd2.values()):
+        v.grad = None
+    tot_o.backward()
+    assert drop_o.calls == drop_ref.calls                                                  # same sites in the same order
+    assert abs(tot_o.item() - total.item()) < 2e-5 * abs(total.item())
+    with torch.no_grad():
+        _, _, _, _, _, tot_eval, _ = oracle_forward(case, True)
+    assert abs(tot_eval.item() - total.item()) > 1e-3 * abs(total.item())                  # the masks do something
+    n_checked = 0
+    for n, p_ in holder.named_parameters():
+        if not p_.requires_grad:
+            continue
+        sd, k = (esd2, n[len('expert_encoder.'):]) if n.startswith('expert_encoder.') else (dsd2, n[len('text_decoder.'):])
+        if k.startswith('lm_head.decoder.'):
+            continue
+        g = sd[k].grad
+        assert g is not None, n
+        if p_.grad.norm() < 1e-6:
+            continue
+        assert rel(g, p_.grad) < 5e-4, (n, rel(g, p_.grad))
+        n_checked += 1
+    assert n_checked > 20
+
+
+def test_oracle_matches_dropout_golden_tiny():
+    """no reference needed: the committed full-training-mode fixture (reference classes under the library's masks, two consecutive seeds)
+    against the oracle with the same masks"""
+    from tests.util import LibraryDropout
+    g = load('tiny_caption_drop')
+    case = C.Case('tiny_caption')
+    d = case.dims
+    x, ids, mask, labels, weights = case.inputs()
+    for si, seed in enumerate([int(v) for v in g['seeds']], 1):
+        esd, dsd, _, _, _, _, _ = oracle_forward(case, True, requires_grad=True)
+        eo = O.vision_encoder(esd, x, d.patch_size, d.vit_heads, True, case.instance_table(x), {})
+        _, loss = O.text_decoder(dsd, ids, mask, eo.transpose(0, 1), d.num_attention_heads, labels, d.pad_token_id, d.label_smoothing,
+                                 drop=LibraryDropout(seed, 0.1, 0.1))
+        assert rel(loss.detach(), g[f's{si}.loss_train']) < TOL
+        for v in list(esd.values()) + list(dsd.values()):
+            v.grad = None
+        loss.mean().backward()
+        n_checked = 0
+        for n in str(g['requires_grad']).split('\n'):
+            sd, k = (esd, n[len('expert_encoder.'):]) if n.startswith('expert_encoder.') else (dsd, n[len('text_decoder.'):])
+            if k.startswith('lm_head.decoder.') or float(g[f's{si}.gnorm.{n}']) < 1e-6:
+                continue
+            gr = sd[k].grad
+            assert abs(gr.double().norm().item() - float(g[f's{si}.gnorm.{n}'])) < 5e-4 * float(g[f's{si}.gnorm.{n}']), n
+            assert rel(gr.flatten()[C.sample_idx(n, gr.numel())], g[f's{si}.gsamp.{n}']) < 2e-3, n
+            n_checked += 1
+        assert n_checked > 20

@@ -412,9 +412,9 @@ class _Holder(torch.nn.Module):
     pass
 
 
-def _pinned_trainer(case, use_graph, lr=1e-3, **kw):
+def _pinned_trainer(case, use_graph, lr=1e-3, p_drop=0.0, **kw):
     from prismer_amd.trainer import Trainer
-    enc, dec, _, _ = build(case, p_drop=0.0)
+    enc, dec, _, _ = build(case, p_drop=p_drop)
     set_freeze(enc, dec)
     m = _Holder(); m.expert_encoder, m.text_decoder = enc, dec
     x, ids, mask, labels, weights = case.inputs()
@@ -555,6 +555,45 @@ def _hipgraph_step_vs_golden(name, force_big=False):
     loss2 = tr.step()
     torch.cuda.synchronize()
     assert np.isfinite(loss2.item()) and tr.it == 2
+
+
+@pytest.mark.parametrize('name', list(C.DROP_CASES))
+def test_trainer_hipgraph_dropout_steps_match_reference_golden(name):
+    """Deterministic REFERENCE parity at dropout 0.1 -- the arithmetic every benchmarked step runs (configs/prismer.json:4,8;
+    roberta.py:75,123,138,181).  tests/golden/<case>_drop.npz holds the reference classes' loss and gradients in full training mode with
+    every nn.Dropout replaced by the masks this library draws for a given device seed (pure functions of (seed, call site, element):
+    tests/util.LibraryDropout, pinned to Random123 vectors in test_philox_kat_cpu.py; minted by tests/golden/make_golden.py <case>+drop).
+    Here: the native Trainer under hipGraph REPLAY, learning rate 0 so that step 2 sees the same weights with the NEXT seed (the device
+    seed is advanced by a kernel inside the graph: fresh masks per replay).  Same bars as the dropout-free test.  Pins the Philox-7
+    generator, the embedding / GEMM-epilogue / LayerNorm-backward mask regeneration and the quad-cooperative dK/dV dropout words end to end."""
+    from tests.util import splitmix64
+    g = np.load(os.path.join(GOLD, name + '_drop.npz'))
+    case = C.Case(name)
+    tr, m = _pinned_trainer(case, use_graph=True, lr=0.0, p_drop=0.1)
+    assert case.dims.hidden_dropout_prob == case.dims.attention_probs_dropout_prob == 0.1
+    seeds = [int(v) for v in g['seeds']]
+    assert seeds == [C.DROP_SEED, splitmix64(C.DROP_SEED)]
+    tr.seed.copy_(torch.tensor([C.DROP_SEED - (1 << 64) if C.DROP_SEED >= (1 << 63) else C.DROP_SEED], dtype=torch.int64))
+    p0 = [st.master.clone() for st in tr.stores]
+    for si in (1, 2):
+        assert int(tr.seed.item()) & 0xFFFFFFFFFFFFFFFF == seeds[si - 1]
+        loss = tr.step()
+        torch.cuda.synchronize()
+        assert tr.use_graph and tr.graphs is not None and tr.it == si
+        want = float(g[f's{si}.total_train'])
+        print(name, 'step', si, 'loss', loss.item(), 'reference under the same masks', want)
+        assert math_close(loss.item(), want, TOL_LOSS), (si, loss.item(), want)
+        gv = {k[3:]: g[k] for k in g.files if k.startswith(f's{si}.')}
+        gv['requires_grad'] = g['requires_grad']
+        named = {}
+        for pref, st in (('expert_encoder.', tr.stores[0]), ('text_decoder.', tr.stores[1])):
+            for nm in st.names:
+                if st.is_trainable(nm):
+                    named[pref + nm] = st.g(nm).detach()
+        _check_grads_against_golden(gv, named, f'{name} dropout step {si}')
+    for st, before in zip(tr.stores, p0):                     # lr = 0: the weights did not move (step 2 is the same model, other masks)
+        assert torch.equal(st.master, before)
+    assert abs(float(g['s1.total_train']) - float(g['s2.total_train'])) > 1e-4 * float(g['s1.total_train'])
 
 
 def test_bench_gradient_handling_equals_the_pinned_one():

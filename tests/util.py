@@ -62,3 +62,44 @@ def dropout_keep_attention(BH, Sq, Sk, seed, stream, p):
     r = np.stack(r, axis=1).reshape(BH * Sq, k4 * 4)[:, :Sk]
     thr = np.uint32(int(np.float32(p) * np.float32(16777216.0)))
     return torch.from_numpy((r >> np.uint32(8)) >= thr).reshape(BH, Sq, Sk)
+
+
+SITE_STREAM = {'self_probs': 1, 'self_out': 2, 'cross_probs': 3, 'cross_out': 4, 'mlp_out': 5}     # programs/decoder.py: li * 16 + k; embeddings: 9000
+
+
+class LibraryDropout:
+    """`drop(site, x)` for oracle.text_decoder / the patched reference modules with EXACTLY the masks libprismer_hip draws for `seed`:
+    hidden-state sites use the linear scheme (element i of the [B*T, H] matrix -> word i % 4 of philox(i / 4, stream)), attention-probability
+    sites the (row = (b * heads + h) * Sq + q, key / 4) scheme; stream = layer * 16 + k (programs/decoder.py), 9000 for the embeddings.
+    Scaling 1 / (1 - p) with p rounded like the kernels do (threshold = int(p * 2^24))."""
+
+    def __init__(self, seed, p_hidden, p_attn, site_base=0):
+        self.seed, self.p_hidden, self.p_attn, self.site_base = int(seed) & 0xFFFFFFFFFFFFFFFF, float(p_hidden), float(p_attn), site_base
+        self.calls = []
+
+    def __call__(self, site, x):
+        self.calls.append(site)
+        if site == ('emb',):
+            stream, p, attn = 9000, self.p_hidden, False
+        else:
+            layer, kind = site
+            stream, attn = layer * 16 + SITE_STREAM[kind], kind.endswith('_probs')
+            p = self.p_attn if attn else self.p_hidden
+        if p <= 0.0:
+            return x
+        stream += self.site_base
+        if attn:
+            B, H, Sq, Sk = x.shape
+            keep = dropout_keep_attention(B * H, Sq, Sk, self.seed, stream, p).reshape(B, H, Sq, Sk)
+        else:
+            keep = dropout_keep_linear(x.numel(), self.seed, stream, p).reshape(x.shape)
+        return x * keep.to(x.dtype) / (1.0 - p)
+
+
+def splitmix64(z):
+    """csrc/optim.hip advance_seed_kernel: the dropout seed of step k+1 from the seed of step k"""
+    m = 0xFFFFFFFFFFFFFFFF
+    z = (z + 0x9E3779B97F4A7C15) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    return z ^ (z >> 31)
