@@ -196,6 +196,11 @@ typedef struct {
   float* delta;                   /* workspace fp32 [B*H*Sq] */
 } ph_attn_bwd_args;
 int ph_attention_bwd(const ph_attn_bwd_args* args, hipStream_t stream);
+/* Kernel family selection (revision 103).  Launches with head dim 64, Sq <= 64 and Sk <= 320 -- the decoder's self- and cross-attention
+ * (roberta.py:95-126 at T = 30 text tokens, 260 image tokens) -- run on the small-query kernels: one block per (batch, head), the keys split
+ * over the waves, forward merged like split-K decoding, dQ + dK + dV in ONE launch (args.delta is not touched).  small_query_kernels = 0
+ * forces the streaming kernels for every launch (A/B, tests), 1 restores the default, < 0 only queries.  Returns the previous setting. */
+int ph_attention_tuning(int small_query_kernels);
 
 /* ------------------------------------------------------------------------------------------------
  * Encoder front end (vit.py:86-160).

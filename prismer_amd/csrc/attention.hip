@@ -844,6 +844,505 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
   }
 }
 
+// =====================================================================================================
+// Small-query attention (round 5): the DECODER's launches.  Sq = T <= 32 text tokens per (batch, head) against Sk = T keys (causal cut, key
+// mask, probability dropout: roberta.py:101-126 self-attention) or against the Sk = 260 image tokens (cross-attention), head dim 64.  With the
+// streaming kernels above such a launch is a latency chain: 64-query blocks of which two waves hold nothing, the 64-key tiles of a head
+// walked one after the other (cross-attention: 5 tiles forward, 10 tile steps in the dQ kernel, then a second launch for dK / dV that
+// re-reads everything), 12-17 us per launch for a few MFLOP (0.016-0.028 of the MFMA peak, 75 launches = 1.08 ms per step).
+// Here ONE block owns a (batch, head) pair and EVERY wave owns ALL queries (QT 16-query sub-tiles): the four waves split the KEYS in 32-key
+// units (unit u -> wave u % 4), so the key sequence is walked four units at a time, and the partial results are merged through LDS:
+//   forward : per wave running (max, sum, O^T) over its units, merged like split-K flash decoding;
+//   backward: ONE launch for dQ, dK and dV.  Sweep 0 = delta (fp32, from the same recomputed P / dP as sweep 1, see attn_bwd_dq_kernel),
+//             merged over the waves; sweep 1 per unit = the dQ role (S^T = K Q^T orientation, dQ^T += K^T dS^T, merged at the end) and
+//             the dK / dV role (mirror orientation S = Q K^T with one key per lane: every wave sees all queries, so dK / dV of its keys
+//             are complete when the unit is done -- no second kernel, no delta round trip through HBM).
+// K / V row fragments (MFMA A / B operands) come straight from global memory; only what is read TRANSPOSED (ds_read_b64_tr_b16) is staged
+// in LDS: V forward; K, Q and dO backward.  Same arithmetic, same dropout words (pure functions of (seed, stream, row, key)), same finfo.min
+// mask semantics as the streaming kernels: tests/test_kernels_gpu.py runs both against the torch reference on the same cases.
+// =====================================================================================================
+constexpr int SM_MAX_UNITS = 10;                     // Sk <= 320
+constexpr int SM_MAXU = 3;                           // units per wave: ceil(SM_MAX_UNITS / 4)
+constexpr int SM_TS = 36;                            // bf16 row stride of the backward's transposition scratch (32 queries + 4: conflict-free b16 writes)
+constexpr int SM_OS = 68;                            // fp32 row stride of the merge images (64 + 4: conflict-free 16-B lane stores)
+__host__ __device__ constexpr int sm_max(int x, int y) { return x > y ? x : y; }
+template <int QT> __host__ __device__ constexpr int sm_merge_bytes() { return 4 * QT * 16 * SM_OS * 4 + 2 * 4 * QT * 16 * 4; }
+__host__ __device__ inline int sm_fwd_bytes(int rows_pad, int merge) { return sm_max(rows_pad * Cfg<64>::RS * 2 + rows_pad * 4, merge); }
+template <int QT> __host__ __device__ inline int sm_bwd_bytes(int rows_pad) {          // region A + Q, dO images + 4 scratch pairs + key states + delta + partials
+  return sm_max(rows_pad * Cfg<64>::RS * 2, 4 * QT * 16 * SM_OS * 4) + 2 * QT * 16 * Cfg<64>::RS * 2 + 4 * 2 * 32 * 36 * 2 + rows_pad * 4 + (1 + 4) * QT * 16 * 4;
+}
+
+// cooperative staging of `rows` rows x 64 channels (strided [token][head*dh] source) into a [rows][RS] LDS image; rows beyond n_valid
+// read as zeros (buffer bounds check), so every product with an excluded probability is 0 x 0
+template <int MAXLD>
+__device__ __forceinline__ void sm_stage(bf16* img, const bf16* src, int64_t ts, int n_valid, int rows) {
+  const rsrc_t rs = tile_rsrc(src, ts, n_valid, 64);
+  const int nld = (rows * 8 + 255) >> 8;
+  u32x4 r[MAXLD];
+#pragma unroll
+  for (int i = 0; i < MAXLD; ++i)
+    if (i < nld) {
+      const int id = threadIdx.x + 256 * i;
+      r[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)(((id >> 3) * ts + (id & 7) * 8) * 2), 0, 0));
+    }
+#pragma unroll
+  for (int i = 0; i < MAXLD; ++i)
+    if (i < nld) {
+      const int id = threadIdx.x + 256 * i;
+      if (id < rows * 8) *reinterpret_cast<u32x4*>(img + (id >> 3) * Cfg<64>::RS + (id & 7) * 8) = r[i];
+    }
+}
+
+template <int QT>
+__global__ __launch_bounds__(256) void attn_fwd_small_kernel(ph_attn_fwd_args a) {
+  constexpr int DH = 64;
+  using C = Cfg<DH>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int nunits = (a.Sk + 31) >> 5, rows_pad = nunits * 32;
+  bf16* vimg = reinterpret_cast<bf16*>(smem_raw);
+  float* kst = reinterpret_cast<float*>(vimg + rows_pad * C::RS);
+  float* obuf = reinterpret_cast<float*>(smem_raw);                         // merge images alias the V image (two barriers apart)
+  float* mbuf = obuf + 4 * QT * 16 * SM_OS;
+  float* lbuf = mbuf + 4 * QT * 16;
+  const bf16* Q = reinterpret_cast<const bf16*>(a.q) + b * a.q_bs + (int64_t)h * DH;
+  const bf16* K = reinterpret_cast<const bf16*>(a.k) + b * a.k_bs + (int64_t)h * DH;
+  const bf16* V = reinterpret_cast<const bf16*>(a.v) + b * a.v_bs + (int64_t)h * DH;
+  const uint8_t* km = a.key_mask ? a.key_mask + (int64_t)b * a.Sk : nullptr;
+
+  int qi[QT];
+  bf16x8 qf[QT][C::KS];
+  f32x4 o[QT][C::DT];
+  float m[QT], lsum[QT];
+  uint32_t rowid[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    qi[t] = t * 16 + c;
+    const int qr = qi[t] < a.Sq ? qi[t] : a.Sq - 1;
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) qf[t][ks] = *reinterpret_cast<const bf16x8*>(Q + (int64_t)qr * a.q_ts + ks * 32 + g * 8);
+#pragma unroll
+    for (int d = 0; d < C::DT; ++d) o[t][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    m[t] = NEG_MASK; lsum[t] = 0.f;
+    rowid[t] = (uint32_t)((b * a.H + h) * a.Sq + qr);
+  }
+  // K row fragments of ALL this wave's units straight from global memory (rows beyond Sk re-read the last key; masked by index below):
+  // one round of global latency for the whole kernel
+  bf16x8 kfu[SM_MAXU][2][C::KS];
+#pragma unroll
+  for (int ui = 0; ui < SM_MAXU; ++ui)
+    if (wave + 4 * ui < nunits) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int kr = min((wave + 4 * ui) * 32 + nt * 16 + c, a.Sk - 1);
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) kfu[ui][nt][ks] = *reinterpret_cast<const bf16x8*>(K + (int64_t)kr * a.k_ts + ks * 32 + g * 8);
+      }
+    }
+  sm_stage<SM_MAX_UNITS>(vimg, V, a.v_ts, a.Sk, rows_pad);
+  for (int i = threadIdx.x; i < rows_pad; i += 256) kst[i] = key_state(key_raw(km, i, a.Sk), i, a.Sk);
+  DropCtx dc;
+  const bool drop = a.drop_p > 0.f;
+  if (drop) dc = make_drop(a.drop_seed, a.drop_stream, a.drop_p);
+#pragma unroll
+  for (int t = 0; t < QT; ++t)
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) settle(qf[t][ks]);
+  __syncthreads();
+
+#pragma unroll
+  for (int ui = 0; ui < SM_MAXU; ++ui) {
+    if (wave + 4 * ui >= nunits) break;
+    const int kbase = (wave + 4 * ui) * 32;
+    f32x4 s[QT][2];
+    float mx[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) mx[t] = -INFINITY;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      f32x4 acc[QT];
+#pragma unroll
+      for (int t = 0; t < QT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks)
+#pragma unroll
+        for (int t = 0; t < QT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfu[ui][nt][ks], qf[t][ks], acc[t], 0, 0, 0);
+      const f32x4 st = *reinterpret_cast<const f32x4*>(kst + kbase + nt * 16 + g * 4);
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ki = kbase + nt * 16 + g * 4 + r;
+          acc[t][r] = score_of(acc[t][r], a.scale, st[r], a.causal && ki > qi[t]);
+          mx[t] = fmaxf(mx[t], acc[t][r]);
+        }
+        s[t][nt] = acc[t];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      const float m_new = fmaxf(m[t], xor_max(mx[t]));
+      const float alpha = __expf(m[t] - m_new);
+      float rs = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __expf(s[t][nt][r] - m_new);
+          rs += p;
+          s[t][nt][r] = p;
+        }
+      rs = xor_sum(rs);
+      lsum[t] = lsum[t] * alpha + rs;
+      m[t] = m_new;
+#pragma unroll
+      for (int d = 0; d < C::DT; ++d) o[t][d] *= alpha;
+      if (drop) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const u32x4 rnd = philox4x32((uint32_t)((kbase + nt * 16 + g * 4) >> 2), rowid[t], dc.stream, 0xa77eu, dc.k0, dc.k1);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[t][nt][r] = drop_apply(dc, rnd[r], s[t][nt][r]);
+        }
+      }
+    }
+    bf16x8 pf[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) pf[t] = pack2(s[t][0], s[t][1]);
+#pragma unroll
+    for (int d = 0; d < C::DT; ++d) {
+      const bf16x8 vfr = frag_tr<DH>(vimg, kbase, d * 16, lane);
+#pragma unroll
+      for (int t = 0; t < QT; ++t) o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, pf[t], o[t][d], 0, 0, 0);
+    }
+  }
+  // ---- one unit (self-attention at T <= 32): wave 0 holds the whole result
+  if (nunits == 1) {
+    if (wave == 0) {
+#pragma unroll
+      for (int t = 0; t < QT; ++t)
+        if (qi[t] < a.Sq) {
+          const float inv = 1.0f / lsum[t];
+          bf16* O = reinterpret_cast<bf16*>(a.o) + b * a.o_bs + (int64_t)qi[t] * a.o_ts + (int64_t)h * DH;
+#pragma unroll
+          for (int d = 0; d < C::DT; ++d) {
+            const bf16x4 tt = {f2bf(o[t][d][0] * inv), f2bf(o[t][d][1] * inv), f2bf(o[t][d][2] * inv), f2bf(o[t][d][3] * inv)};
+            *reinterpret_cast<bf16x4*>(O + d * 16 + g * 4) = tt;
+          }
+          if (g == 0 && a.lse) a.lse[(int64_t)(b * a.H + h) * a.Sq + qi[t]] = m[t] + __logf(lsum[t]);
+        }
+    }
+    return;
+  }
+  // ---- merge the (max, sum, O^T) partials of the waves that held units
+  __syncthreads();                                          // every wave is done with the V image / key states: the merge images may overwrite them
+  if (wave < nunits) {
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      const int q = t * 16 + c;
+      if (g == 0) { mbuf[wave * QT * 16 + q] = m[t]; lbuf[wave * QT * 16 + q] = lsum[t]; }
+#pragma unroll
+      for (int d = 0; d < C::DT; ++d) *reinterpret_cast<f32x4*>(obuf + (wave * QT * 16 + q) * SM_OS + d * 16 + g * 4) = o[t][d];
+    }
+  }
+  __syncthreads();
+  const int q = threadIdx.x >> 2, col = (threadIdx.x & 3) * 16;
+  if (q < a.Sq && q < QT * 16) {
+    const int nw = nunits < 4 ? nunits : 4;
+    float M = NEG_MASK;
+    for (int w = 0; w < nw; ++w) M = fmaxf(M, mbuf[w * QT * 16 + q]);
+    float L = 0.f;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    for (int w = 0; w < nw; ++w) {
+      const float wgt = __expf(mbuf[w * QT * 16 + q] - M);
+      L += wgt * lbuf[w * QT * 16 + q];
+      const float* src = obuf + (w * QT * 16 + q) * SM_OS + col;
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + j4 * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j4 * 4 + r] += wgt * v[r];
+      }
+    }
+    const float inv = 1.0f / L;
+    bf16* O = reinterpret_cast<bf16*>(a.o) + b * a.o_bs + (int64_t)q * a.o_ts + (int64_t)h * DH + col;
+    bf16x8 o0, o1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { o0[j] = f2bf(acc[j] * inv); o1[j] = f2bf(acc[8 + j] * inv); }
+    *reinterpret_cast<bf16x8*>(O) = o0;
+    *reinterpret_cast<bf16x8*>(O + 8) = o1;
+    if ((threadIdx.x & 3) == 0 && a.lse) a.lse[(int64_t)(b * a.H + h) * a.Sq + q] = M + __logf(L);
+  }
+}
+
+
+// Backward of a (batch, head) pair in ONE launch and ONE pass of the generator / exponentials (second version, round 5: the first one
+// recomputed scores and masks three times and fetched fragments from global memory inside the unit loop -- 36 us against 42 us of the two
+// streaming kernels on the decoder's cross-attention):
+//   prologue : K, Q, dO images -> LDS (K and dO / Q are also read transposed), V row fragments of ALL this wave's units -> registers
+//   sweep 0  : per unit S^T = K Q^T and dP^T = V dO^T (lane = query column), P = exp(S - lse), dropout words, dP~ = drop(dP); P, dP~ and the
+//              16 keep bits stay in registers; delta_i = sum_j P_ij dP~_ij merged over g, the units and -- through LDS -- the waves
+//   sweep 1  : dS = P (dP~ - delta);  dQ^T += K^T dS^T (K^T by transposing LDS reads);  P~ and dS go through a per-wave LDS scratch
+//              [key][query] and come back as the B operands of dV^T += dO^T P~ and dK^T += Q^T dS (lane = key column): every wave holds all
+//              queries, so dK / dV of its keys are final -- stored at once
+//   epilogue : dQ merged over the waves through LDS.
+template <int QT>
+__global__ __launch_bounds__(256) void attn_bwd_small_kernel(ph_attn_bwd_args a) {
+  constexpr int DH = 64;
+  using C = Cfg<DH>;
+  static_assert(QT == 2, "32 queries: one MFMA k-step of the dK/dV products, one b64 pair per scratch read");
+  const ph_attn_fwd_args& f = a.f;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / f.H, h = blockIdx.x % f.H;
+  const int nunits = (f.Sk + 31) >> 5, rows_pad = nunits * 32;
+  constexpr int NQ = QT * 16;
+  // region A: K image, overwritten at the end by the dQ merge images; region B: what lives to the end
+  bf16* kimg = reinterpret_cast<bf16*>(smem_raw);
+  float* dqbuf = reinterpret_cast<float*>(smem_raw);
+  char* regb = smem_raw + sm_max(rows_pad * C::RS * 2, 4 * NQ * SM_OS * 4);
+  bf16* qimg = reinterpret_cast<bf16*>(regb);
+  bf16* doimg = qimg + NQ * C::RS;
+  bf16* tsc = doimg + NQ * C::RS + wave * (2 * 32 * SM_TS);  // this wave's scratch: P~ [32 keys][SM_TS], dS [32 keys][SM_TS]
+  float* kst = reinterpret_cast<float*>(doimg + NQ * C::RS + 4 * 2 * 32 * SM_TS);
+  float* delta_s = kst + rows_pad;
+  float* dpart = delta_s + NQ;                               // [4][NQ]
+  const bf16* Q = reinterpret_cast<const bf16*>(f.q) + b * f.q_bs + (int64_t)h * DH;
+  const bf16* K = reinterpret_cast<const bf16*>(f.k) + b * f.k_bs + (int64_t)h * DH;
+  const bf16* V = reinterpret_cast<const bf16*>(f.v) + b * f.v_bs + (int64_t)h * DH;
+  const bf16* dO = reinterpret_cast<const bf16*>(a.d_o) + b * a.do_bs + (int64_t)h * DH;
+  const uint8_t* km = f.key_mask ? f.key_mask + (int64_t)b * f.Sk : nullptr;
+  const float* lse_base = f.lse + (int64_t)(b * f.H + h) * f.Sq;
+
+  int qi[QT];
+  uint32_t ridx[QT];
+  bf16x8 qf[QT][C::KS], dof[QT][C::KS];
+  float lse[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    qi[t] = t * 16 + c;
+    const int qr = qi[t] < f.Sq ? qi[t] : f.Sq - 1;
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      qf[t][ks] = *reinterpret_cast<const bf16x8*>(Q + (int64_t)qr * f.q_ts + ks * 32 + g * 8);
+      dof[t][ks] = *reinterpret_cast<const bf16x8*>(dO + (int64_t)qr * a.do_ts + ks * 32 + g * 8);
+    }
+    ridx[t] = (uint32_t)((b * f.H + h) * f.Sq + qr);
+    lse[t] = lse_base[qr];
+  }
+  // V row fragments of all units of this wave (A operands of dP^T = V dO^T): one round of global latency for the whole kernel
+  bf16x8 vfu[SM_MAXU][2][C::KS];
+#pragma unroll
+  for (int ui = 0; ui < SM_MAXU; ++ui)
+    if (wave + 4 * ui < nunits) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int kr = min((wave + 4 * ui) * 32 + nt * 16 + c, f.Sk - 1);
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) vfu[ui][nt][ks] = *reinterpret_cast<const bf16x8*>(V + (int64_t)kr * f.v_ts + ks * 32 + g * 8);
+      }
+    }
+  sm_stage<SM_MAX_UNITS>(kimg, K, f.k_ts, f.Sk, rows_pad);
+  sm_stage<(QT * 16 * 8 + 255) / 256>(qimg, Q, f.q_ts, f.Sq, NQ);
+  sm_stage<(QT * 16 * 8 + 255) / 256>(doimg, dO, a.do_ts, f.Sq, NQ);
+  for (int i = threadIdx.x; i < rows_pad; i += 256) kst[i] = key_state(key_raw(km, i, f.Sk), i, f.Sk);
+  DropCtx dc;
+  const bool drop = f.drop_p > 0.f;
+  if (drop) dc = make_drop(f.drop_seed, f.drop_stream, f.drop_p);
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) { settle(qf[t][ks]); settle(dof[t][ks]); }
+    settle(lse[t]);
+  }
+  __syncthreads();
+
+  // ---- sweep 0
+  f32x4 pu[SM_MAXU][QT][2], du[SM_MAXU][QT][2];              // P and dropped dP of this wave's units
+  uint32_t keepu[SM_MAXU][QT];                               // bit nt*4 + r: element kept by the dropout
+  float dsum[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) dsum[t] = 0.f;
+#pragma unroll
+  for (int ui = 0; ui < SM_MAXU; ++ui) {
+    if (wave + 4 * ui < nunits) {
+      const int kbase = (wave + 4 * ui) * 32;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        f32x4 acc[QT], dp[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+          const bf16x8 kfr = frag_rows<DH>(kimg, kbase + nt * 16, ks, lane);
+#pragma unroll
+          for (int t = 0; t < QT; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[t][ks], acc[t], 0, 0, 0);
+            dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfu[ui][nt][ks], dof[t][ks], dp[t], 0, 0, 0);
+          }
+        }
+        const f32x4 st = *reinterpret_cast<const f32x4*>(kst + kbase + nt * 16 + g * 4);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          u32x4 rnd = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+          if (drop) rnd = philox4x32((uint32_t)((kbase + nt * 16 + g * 4) >> 2), ridx[t], dc.stream, 0xa77eu, dc.k0, dc.k1);
+          if (nt == 0) keepu[ui][t] = 0u;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ki = kbase + nt * 16 + g * 4 + r;
+            const float p = __expf(score_of(acc[t][r], f.scale, st[r], f.causal && ki > qi[t]) - lse[t]);
+            const bool keep = !drop || (rnd[r] >> 8) >= dc.thr;
+            const float dpe = drop ? (keep ? dp[t][r] * dc.scale : 0.f) : dp[t][r];
+            keepu[ui][t] |= keep ? (1u << (nt * 4 + r)) : 0u;
+            pu[ui][t][nt][r] = p;
+            du[ui][t][nt][r] = dpe;
+            dsum[t] += p * dpe;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const float v = xor_sum(dsum[t]);
+    if (g == 0) dpart[wave * NQ + t * 16 + c] = v;           // (0 from a wave without units)
+  }
+  __syncthreads();
+  if (threadIdx.x < NQ) delta_s[threadIdx.x] = dpart[threadIdx.x] + dpart[NQ + threadIdx.x] + dpart[2 * NQ + threadIdx.x] + dpart[3 * NQ + threadIdx.x];
+  __syncthreads();
+  float delta[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) delta[t] = delta_s[t * 16 + c];
+
+  // ---- sweep 1
+  f32x4 dq[QT][C::DT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t)
+#pragma unroll
+    for (int d = 0; d < C::DT; ++d) dq[t][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float pscale = drop ? dc.scale : 1.f;
+#pragma unroll
+  for (int ui = 0; ui < SM_MAXU; ++ui) {
+    if (wave + 4 * ui < nunits) {
+      const int kbase = (wave + 4 * ui) * 32;
+      bf16x8 dsf[QT];
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        f32x4 ds[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = pu[ui][t][nt][r];
+            const float dsv = p * (du[ui][t][nt][r] - delta[t]);
+            ds[nt][r] = dsv;
+            const float pdrop = ((keepu[ui][t] >> (nt * 4 + r)) & 1u) ? p * pscale : 0.f;
+            // scratch[key][query]: this lane owns ONE query column (t*16 + c) and the keys nt*16 + g*4 + r
+            const int key = nt * 16 + g * 4 + r;
+            tsc[key * SM_TS + t * 16 + c] = f2bf(qi[t] < f.Sq ? pdrop : 0.f);
+            tsc[32 * SM_TS + key * SM_TS + t * 16 + c] = f2bf(qi[t] < f.Sq ? dsv : 0.f);
+          }
+        dsf[t] = pack2(ds[0], ds[1]);
+      }
+#pragma unroll
+      for (int d = 0; d < C::DT; ++d) {
+        const bf16x8 kfr = frag_tr<DH>(kimg, kbase, d * 16, lane);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) dq[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, dsf[t], dq[t][d], 0, 0, 0);
+      }
+      // dK / dV of this unit's keys: lane = key column c, reduction over the 32 queries in the order frag_tr delivers dO^T / Q^T
+      // (kappa(g, j) = 16 (j >> 2) + 4 g + (j & 3)): B element j of lane (c, g) = scratch[key c][16 (j >> 2) + 4 g + (j & 3)]
+      // (the wave's own LDS writes above are ordered before these reads: same wave, in-order LDS pipe)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const int kk = kbase + kt * 16 + c;
+        const bf16* row = tsc + (kt * 16 + c) * SM_TS + 4 * g;
+        const bf16x4 p0 = *reinterpret_cast<const bf16x4*>(row), p1 = *reinterpret_cast<const bf16x4*>(row + 16);
+        const bf16x4 s0 = *reinterpret_cast<const bf16x4*>(row + 32 * SM_TS), s1 = *reinterpret_cast<const bf16x4*>(row + 32 * SM_TS + 16);
+        bf16x8 pf, sf;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pf[j] = p0[j]; pf[4 + j] = p1[j]; sf[j] = s0[j]; sf[4 + j] = s1[j]; }
+        f32x4 dk[C::DT], dv[C::DT];
+#pragma unroll
+        for (int d = 0; d < C::DT; ++d) {
+          const bf16x8 dfr = frag_tr<DH>(doimg, 0, d * 16, lane);
+          const bf16x8 qfr = frag_tr<DH>(qimg, 0, d * 16, lane);
+          dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr, pf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, sf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+        if (kk < f.Sk) {
+          bf16* dK = reinterpret_cast<bf16*>(a.dk) + b * a.dk_bs + (int64_t)kk * a.dk_ts + (int64_t)h * DH;
+          bf16* dV = reinterpret_cast<bf16*>(a.dv) + b * a.dv_bs + (int64_t)kk * a.dv_ts + (int64_t)h * DH;
+#pragma unroll
+          for (int d = 0; d < C::DT; ++d) {
+            const bf16x4 tk = {f2bf(dk[d][0] * f.scale), f2bf(dk[d][1] * f.scale), f2bf(dk[d][2] * f.scale), f2bf(dk[d][3] * f.scale)};
+            const bf16x4 tv = {f2bf(dv[d][0]), f2bf(dv[d][1]), f2bf(dv[d][2]), f2bf(dv[d][3])};
+            *reinterpret_cast<bf16x4*>(dK + d * 16 + g * 4) = tk;
+            *reinterpret_cast<bf16x4*>(dV + d * 16 + g * 4) = tv;
+          }
+        }
+      }
+    }
+  }
+  // ---- dQ: one unit -> wave 0 holds all of it; otherwise merged over the waves through LDS
+  if (nunits == 1) {
+    if (wave == 0) {
+#pragma unroll
+      for (int t = 0; t < QT; ++t)
+        if (qi[t] < f.Sq) {
+          bf16* dQ = reinterpret_cast<bf16*>(a.dq) + b * a.dq_bs + (int64_t)qi[t] * a.dq_ts + (int64_t)h * DH;
+#pragma unroll
+          for (int d = 0; d < C::DT; ++d) {
+            const bf16x4 tt = {f2bf(dq[t][d][0] * f.scale), f2bf(dq[t][d][1] * f.scale), f2bf(dq[t][d][2] * f.scale), f2bf(dq[t][d][3] * f.scale)};
+            *reinterpret_cast<bf16x4*>(dQ + d * 16 + g * 4) = tt;
+          }
+        }
+    }
+    return;
+  }
+  __syncthreads();                                           // the K image is dead: the dQ images may overwrite it
+  if (wave < nunits) {
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+      for (int d = 0; d < C::DT; ++d) *reinterpret_cast<f32x4*>(dqbuf + (wave * NQ + t * 16 + c) * SM_OS + d * 16 + g * 4) = dq[t][d];
+  }
+  __syncthreads();
+  const int q = threadIdx.x >> 2, col = (threadIdx.x & 3) * 16;
+  if (q < f.Sq && q < NQ) {
+    const int nw = nunits < 4 ? nunits : 4;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    for (int w = 0; w < nw; ++w) {
+      const float* src = dqbuf + (w * NQ + q) * SM_OS + col;
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + j4 * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j4 * 4 + r] += v[r];
+      }
+    }
+    bf16* dQ = reinterpret_cast<bf16*>(a.dq) + b * a.dq_bs + (int64_t)q * a.dq_ts + (int64_t)h * DH + col;
+    bf16x8 o0, o1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { o0[j] = f2bf(acc[j] * f.scale); o1[j] = f2bf(acc[8 + j] * f.scale); }
+    *reinterpret_cast<bf16x8*>(dQ) = o0;
+    *reinterpret_cast<bf16x8*>(dQ + 8) = o1;
+  }
+}
+
+// eligibility of the small-query kernels: head dim 64, all queries of a (batch, head) pair in QT <= 4 sub-tiles, K / V image within the LDS budget
+int attn_small_qt(const ph_attn_fwd_args* f) {
+  if (f->dh != 64 || f->Sk > 32 * SM_MAX_UNITS) return 0;
+  return f->Sq <= 32 ? 2 : 0;
+}
+
 // no causal cut, no key mask, no probability dropout -> the PLAIN kernels
 bool attn_plain_ok(const ph_attn_fwd_args* f) {
   return !f->causal && !f->key_mask && !(f->drop_p > 0.f) && f->scale > 0.f;     // (the row max is taken on raw scores: needs scale > 0)
@@ -857,6 +1356,8 @@ int set_smem(KernelT k, int bytes) {
   if (bytes > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   return bytes;
 }
+
+int g_attn_small = 1;      // ph_attention_tuning(0): force the streaming kernels (A/B and the tests that compare the two families)
 
 int check_fwd(const ph_attn_fwd_args* f, const char* who) {
   PH_CHECK_ARG(f && f->q && f->k && f->v && f->o, "%s: null pointer", who);
@@ -878,6 +1379,16 @@ extern "C" int ph_attention_fwd(const ph_attn_fwd_args* a, hipStream_t stream) {
   int rc = check_fwd(a, "ph_attention_fwd");
   if (rc) return rc;
   ProfScope prof__(PH_FAM_ATTN_FWD, 4.0 * a->B * (double)a->H * a->Sq * (double)a->Sk * a->dh, 0.0, stream);
+  // the decoder's cross-attention: one block per (batch, head), keys split over the waves.  (One or two key units -- self-attention at T <= 64 --
+  // stay on the streaming kernel in the FORWARD: 4.7 vs 5.2 us, tools/attn_small_probe.py; the fused backward wins at every size.)
+  if (const int sq = (g_attn_small && a->Sk > 64) ? attn_small_qt(a) : 0) {
+    const int rows_pad = ceil_div(a->Sk, 32) * 32;
+    (void)sq;
+    const int smem = set_smem(attn_fwd_small_kernel<2>, sm_fwd_bytes(rows_pad, sm_merge_bytes<2>()));
+    hipLaunchKernelGGL((attn_fwd_small_kernel<2>), dim3(a->B * a->H), dim3(256), smem, stream, *a);
+    PH_LAUNCH_CHECK("attn_fwd_small_kernel");
+    return PH_OK;
+  }
   const bool plain = attn_plain_ok(a);
   // 32 queries per wave (QT = 2): measured slower than 16 in the forward at every shape once the blocks of a head share an XCD
   // (ViT 26.8 vs 32.6 us, LARGE 58 vs 66 us); PH_ATTN_QT2=2 forces it for experiments
@@ -909,6 +1420,14 @@ extern "C" int ph_attention_bwd(const ph_attn_bwd_args* a, hipStream_t stream) {
   PH_CHECK_ARG(((a->do_ts | a->dq_ts | a->dk_ts | a->dv_ts | a->do_bs | a->dq_bs | a->dk_bs | a->dv_bs) % 8) == 0, "ph_attention_bwd: strides must be multiples of 8");
   PH_CHECK_ARG((int64_t)a->f.Sq * a->do_ts < (1ll << 30), "ph_attention_bwd: a (batch, head) slice of dO must span < 2 GiB");
   const ph_attn_fwd_args& f = a->f;
+  if (const int sq = g_attn_small ? attn_small_qt(&f) : 0) {                // dQ, dK and dV of the decoder's launches in ONE launch
+    const int rows_pad = ceil_div(f.Sk, 32) * 32;
+    (void)sq;
+    const int smem = set_smem(attn_bwd_small_kernel<2>, sm_bwd_bytes<2>(rows_pad));
+    hipLaunchKernelGGL((attn_bwd_small_kernel<2>), dim3(f.B * f.H), dim3(256), smem, stream, *a);
+    PH_LAUNCH_CHECK("attn_bwd_small_kernel");
+    return PH_OK;
+  }
   const bool plain = attn_plain_ok(&f);
   // backward: 32 queries / keys per wave pay from ~512 tokens on (LARGE, S = 1220: 184 vs 189 us; ViT S = 260: 91 vs 84 us)
   const int qt_mode = attn_qt2_ok();
@@ -943,6 +1462,12 @@ extern "C" int ph_attention_bwd(const ph_attn_bwd_args* a, hipStream_t stream) {
 #undef PH_BWD
   PH_LAUNCH_CHECK("attn_bwd kernels");
   return PH_OK;
+}
+
+extern "C" int ph_attention_tuning(int small_query_kernels) {
+  const int old = g_attn_small;
+  if (small_query_kernels >= 0) g_attn_small = small_query_kernels ? 1 : 0;
+  return old;
 }
 
 #ifdef PH_TIMELINE
