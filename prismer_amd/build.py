@@ -28,6 +28,25 @@ def _digest():
     return h.hexdigest()
 
 
+def comm_key():
+    """what a comm.failed marker is valid for: the digest of comm.cpp + its header and the compiler path"""
+    h = hashlib.sha256()
+    for f in (os.path.join(CSRC, 'comm.cpp'), os.path.join(HERE, '..', 'include', 'prismer_comm.h')):
+        h.update(open(f, 'rb').read())
+    h.update(os.environ.get('HIPCC', '/opt/rocm/bin/hipcc').encode())
+    return h.hexdigest()
+
+
+def comm_failed_before():
+    """(True, stderr tail) when the CURRENT comm.cpp / compiler already failed to build here; a stale marker is ignored"""
+    failed = os.path.join(LIBDIR, 'comm.failed')
+    if not os.path.isfile(failed):
+        return False, ''
+    txt = open(failed).read()
+    key, _, err = txt.partition('\n')
+    return key == comm_key(), err
+
+
 def build_comm():
     """libprismer_comm.so alone (host code, one file).  Optional: a box without <rccl/rccl.h> still gets the compute library; the
     failure is remembered in comm.failed so that later callers raise at once instead of recompiling.  Written to a temporary name and
@@ -41,10 +60,11 @@ def build_comm():
     if r.returncode != 0:
         import warnings
         warnings.warn('libprismer_comm.so (native RCCL gradient exchange) was not built: ' + r.stderr[-500:])
-        open(failed, 'w').write(r.stderr[-2000:])
-        for f in (tmp, COMM_LIB):
-            if os.path.isfile(f):
-                os.remove(f)
+        # the marker records WHAT failed (source digest + compiler): a later call retries once either changes (round-4 advisor finding:
+        # the marker was sticky, and a failed rebuild deleted a good library another rank may be loading -- it is left alone now)
+        open(failed, 'w').write(comm_key() + '\n' + r.stderr[-2000:])
+        if os.path.isfile(tmp):
+            os.remove(tmp)
         return None
     os.replace(tmp, COMM_LIB)
     if os.path.isfile(failed):

@@ -15,12 +15,13 @@ def lib():
     global _lib
     if _lib is None:
         path = _build.COMM_LIB
-        failed = os.path.join(_build.LIBDIR, 'comm.failed')
-        if not os.path.isfile(path) and not os.path.isfile(failed):
+        known_bad, err = _build.comm_failed_before()            # (a marker of another comm.cpp / compiler does not count: retry)
+        if not os.path.isfile(path) and not known_bad:
             _build.build_comm()                                 # comm.cpp only: never touches the compute library a process has loaded
+            known_bad, err = _build.comm_failed_before()
         if not os.path.isfile(path):
             raise RuntimeError('libprismer_comm.so is not available on this machine (built without <rccl/rccl.h>?); '
-                               "use transport='torch.distributed'")
+                               "use transport='torch.distributed'.  Compiler output: " + (err[-600:] or 'none recorded'))
         L = C.CDLL(path)
         L.ph_comm_last_error.restype = C.c_char_p
         L.ph_comm_unique_id.argtypes = [C.c_void_p]

@@ -154,11 +154,20 @@ extern "C" int ph_gemm_dispatch_counts(int64_t* out, int n, int reset) {
 
 // device-resident zero vector standing in for a null bias (epilogue classes, gemm_common.h): part of the code object, no allocation
 static __device__ float g_zero_bias[PH_ZERO_BIAS_FLOATS];
+// (the address of a __device__ array is PER DEVICE: cached per device id -- a process that launches on a second GPU must not hand it the first
+// GPU's address; round-4 advisor finding)
 static const float* zero_bias_ptr() {
-  static const float* ptr = [] {
+  constexpr int MAX_DEV = 64;
+  static std::atomic<const float*> cache[MAX_DEV];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  const float* ptr = cache[dev].load(std::memory_order_acquire);
+  if (!ptr) {
     void* d = nullptr;
-    return hipGetSymbolAddress(&d, HIP_SYMBOL(g_zero_bias)) == hipSuccess ? static_cast<const float*>(d) : nullptr;
-  }();
+    if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_zero_bias)) != hipSuccess) return nullptr;
+    ptr = static_cast<const float*>(d);
+    cache[dev].store(ptr, std::memory_order_release);
+  }
   return ptr;
 }
 
@@ -349,7 +358,7 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
   // ---- forward-shaped implicit convolutions with many rows and a long reduction (the stems' layers 2..4 and their data gradients): the
   // 256x128 LDS-DMA kernel with the gather in the DMA source address (round 4; the register-staged gather kernel ran them at ~410 TFLOP/s)
   if (conv && !ta && !tb && big_mode_now() > 1 && max_blocks == 0) {
-    bool ok = true;
+    bool ok = zero_bias_ptr() != nullptr;                    // the gather's padding lanes read the zero page
     for (int i = 0; i < n && ok; ++i) {
       const ph_gemm_args& a = args[i];
       ok = a.M >= big::BM && a.K >= 2 * BK && (a.N % 8) == 0 && a.N >= 8 && (a.ldb % 8) == 0 && a.split_k <= 1 &&
@@ -362,7 +371,7 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
         g.p[i].k_tiles_per_split = ceil_div(args[i].K, BK);
         g.p[i].ws = nullptr; g.p[i].ldws = 0;
         g.tile_start[i] = blocks;
-        blocks += 8 * ceil_div(g.p[i].tiles_m, 8) * g.p[i].tiles_n;          // (XCD shares, see big_tile: the blocks beyond a share exit)
+        blocks += big_xcd_grid(g.p[i].tiles_m, g.p[i].tiles_n);          // (XCD shares, see big_tile: the blocks beyond a share exit)
       }
       g.tile_start[n] = blocks;
       return big::launch_grouped_conv(g, blocks, big_mode_now() == 6 ? 5 : 4, stream);

@@ -44,14 +44,26 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
   int tm, tn;
   if constexpr (XCD_REMAP) {
     const int xcd = block_id & 7, idx = block_id >> 3;
-    const int q = p.tiles_m >> 3, r = p.tiles_m & 7;
-    const int cnt = q + (xcd < r ? 1 : 0), p0 = xcd * q + min(xcd, r);
-    if (idx >= cnt * p.tiles_n) return;
-    const int group_sz = GM * p.tiles_n;
-    const int first = (idx / group_sz) * GM;
-    const int gm = min(GM, cnt - first);
-    const int rin = idx - (idx / group_sz) * group_sz;
-    tm = p0 + first + rin % gm; tn = rin / gm;
+    if (big_xcd_panels(p.tiles_m, p.tiles_n)) {
+      const int q = p.tiles_m >> 3, r = p.tiles_m & 7;
+      const int cnt = q + (xcd < r ? 1 : 0), p0 = xcd * q + min(xcd, r);
+      if (idx >= cnt * p.tiles_n) return;
+      const int group_sz = GM * p.tiles_n;
+      const int first = (idx / group_sz) * GM;
+      const int gm = min(GM, cnt - first);
+      const int rin = idx - (idx / group_sz) * group_sz;
+      tm = p0 + first + rin % gm; tn = rin / gm;
+    } else {
+      // few or badly divisible row panels (see big_xcd_panels): XCD x takes an even run of the GM-grouped tile list instead
+      const int nt = p.tiles_m * p.tiles_n, q = nt >> 3, r = nt & 7;
+      if (idx >= q + (xcd < r ? 1 : 0)) return;
+      const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+      const int group_sz = GM * p.tiles_n;
+      const int first_m = (lin / group_sz) * GM;
+      const int gm = min(GM, p.tiles_m - first_m);
+      const int rin = lin % group_sz;
+      tm = first_m + rin % gm; tn = rin / gm;
+    }
   } else {
     const int group_sz = GM * p.tiles_n;
     const int first_m = (block_id / group_sz) * GM;
@@ -385,7 +397,7 @@ template <int VARIANT, bool TA, bool TB>
 int launch(const GemmParams& p, hipStream_t s) {
   PH_SET_SMEM_ONCE((&gemm_big_kernel<VARIANT, TA, TB>), SMEM);
   count_launch(PH_GEMM_CLS_BIG);
-  hipLaunchKernelGGL((gemm_big_kernel<VARIANT, TA, TB>), dim3(8 * ((p.tiles_m + 7) / 8) * p.tiles_n), dim3(NTHR), SMEM, s, p);      // (XCD shares, see big_tile)
+  hipLaunchKernelGGL((gemm_big_kernel<VARIANT, TA, TB>), dim3(big_xcd_grid(p.tiles_m, p.tiles_n)), dim3(NTHR), SMEM, s, p);      // (XCD shares, see big_tile)
   PH_LAUNCH_CHECK("gemm_big_kernel");
   return PH_OK;
 }

@@ -63,8 +63,22 @@ struct GemmParams {
   double* col_stats;       // optional fp64 [2][N]: += column sums / sums of squares of the (bf16-rounded) outputs (BatchNorm statistics)
   int rm_wo, rm_mul, rm_sub, rm_add; float rm_inv_wo;     // output row map (rm_wo > 0): C row of result row m = m * mul - (m % wo) * sub + add
   ConvGather cv;           // CONV kernels only: geometry of the gathered operand (A for CONV=1, B for CONV=2)
-  const bf16* zero16;      // >= 16 B of device-resident zeros: what an LDS-DMA lane reads for a padding tap / a chunk beyond K (gemm_big.hip, CONV)
+  const bf16* zero16;      // >= 1 KB of device-resident zeros (64 lanes x 16 B): what the LDS-DMA lanes read for a padding tap / a chunk beyond K (gemm_big.hip, CONV)
 };
+
+// ---- XCD shares of a one-tile-per-block launch of the 256x128 kernel (gemm_big.hip big_tile, and its host-side grid sizes) ----------------
+// Panel ownership (round 4): XCD x owns whole 256-row panels -> an A panel is fetched by one L2.  It only pays while it costs no extra block
+// round: with tiles_m < 8 some XCDs own nothing (M = 512, N = 4096: 2 of 8 XCDs work), with tiles_m = 8k + 1 one XCD owns twice the others'
+// share (round-4 advisor finding).  Rule, evaluated identically on host and device: panels iff every XCD gets one AND the largest share needs no
+// more rounds of the XCD's 32 CUs than an even split of the tile list would; otherwise even runs of the (GM-grouped) tile list per XCD.
+__host__ __device__ inline int big_xcd_even_share(int tiles_m, int tiles_n) { return (tiles_m * tiles_n + 7) / 8; }
+__host__ __device__ inline bool big_xcd_panels(int tiles_m, int tiles_n) {
+  const int share = ((tiles_m + 7) / 8) * tiles_n;
+  return tiles_m >= 8 && (share + 31) / 32 <= (big_xcd_even_share(tiles_m, tiles_n) + 31) / 32;
+}
+__host__ __device__ inline int big_xcd_grid(int tiles_m, int tiles_n) {
+  return 8 * (big_xcd_panels(tiles_m, tiles_n) ? ((tiles_m + 7) / 8) * tiles_n : big_xcd_even_share(tiles_m, tiles_n));
+}
 
 // C row of result row m (identity unless an output row map is set: parity-class data gradients of the stride-2 convolutions)
 __device__ __forceinline__ size_t crow(const GemmParams& p, int m) {

@@ -88,8 +88,15 @@ class EncoderProgram:
         d, P = dims, store
         # BatchNorm's num_batches_tracked of every stem layer live in ONE int64 buffer (the module buffers are 0-dim views of it, so
         # state_dict / load_state_dict see them unchanged): a training forward increments all of them with one ph_add_i64 launch
-        bns = [m for dom in getattr(module, 'conv1', {}) if dom != 'rgb' for m in module.conv1[dom] if isinstance(m, torch.nn.BatchNorm2d)]
-        self._bn_flat = None
+        # (only the stems of the experts present in a batch advance, like the reference's per-module counters: _bn_range[dom] = rows of dom)
+        bns, self._bn_range = [], {}
+        for dom in getattr(module, 'conv1', {}):
+            if dom == 'rgb':
+                continue
+            mine = [m for m in module.conv1[dom] if isinstance(m, torch.nn.BatchNorm2d)]
+            self._bn_range[dom] = (len(bns), len(mine))
+            bns += mine
+        self._bn_flat, self._bn_mods = None, bns
         if bns:
             self._bn_flat = torch.stack([m.num_batches_tracked.reshape(()) for m in bns]).to(torch.int64).contiguous()
             for i, m in enumerate(bns):
@@ -477,11 +484,28 @@ class EncoderProgram:
                 keep.append(f)
             del keep
             if training and self._bn_flat is not None:
-                ops.add_i64(self._bn_flat, 1)
+                self._advance_bn_counters(names)
         if save:
             sv.update(B=B, names=names, rgb_col=col,
                       inst=(self._instance_ids(x['obj_detection']) if 'obj_detection' in x else None), inst_table=inst_table)
         return h, xf, sv
+
+    def _advance_bn_counters(self, names):
+        """num_batches_tracked += 1 for the stems that ran (vit.py:86-120: only the experts present in the batch go through their conv1)"""
+        lo, flat = self._bn_flat.data_ptr(), self._bn_flat
+        for m in (self._bn_mods[0], self._bn_mods[-1]):      # Module._apply (.to / .double) replaces ALL buffers: the views would silently stop advancing
+            p = m.num_batches_tracked.data_ptr()
+            if not (lo <= p < lo + flat.numel() * 8):
+                raise RuntimeError('a BatchNorm counter no longer aliases the program\'s counter buffer (module moved or cast after the '
+                                   'program was built): rebuild the program (module._prog = None)')
+        doms = [dom for dom in self._bn_range if dom in names or (dom == 'seg' and any('seg' in n for n in names))]
+        if len(doms) == len(self._bn_range):
+            ops.add_i64(flat, 1)
+            return
+        for dom in doms:
+            a, n = self._bn_range[dom]
+            if n:
+                ops.add_i64(flat[a:a + n], 1)
 
     def forward_trunk(self, h, xf, B, save):
         """h: [B*S, W] rows of B images (rgb tokens filled; the latent rows are written here); xf: [B*Mx, W] or None."""

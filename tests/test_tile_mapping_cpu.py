@@ -19,9 +19,28 @@ SRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 GM = 4
 
 
+def panels(tiles_m, tiles_n):
+    """gemm_common.h big_xcd_panels: panel ownership iff every XCD owns a panel and the largest share needs no more rounds of an XCD's 32 CUs
+    than an even split of the tile list (round-4 advisor finding: tiles_m < 8 left XCDs idle, tiles_m = 8k + 1 doubled one XCD's work)"""
+    share = ((tiles_m + 7) // 8) * tiles_n
+    even = (tiles_m * tiles_n + 7) // 8
+    return tiles_m >= 8 and (share + 31) // 32 <= (even + 31) // 32
+
+
 def tile_of(block_id, tiles_m, tiles_n):
     """big_tile, XCD_REMAP branch: (tm, tn) or None for a block beyond its XCD's share"""
     xcd, idx = block_id & 7, block_id >> 3
+    if not panels(tiles_m, tiles_n):                       # even runs of the GM-grouped tile list
+        nt = tiles_m * tiles_n
+        q, r = nt >> 3, nt & 7
+        if idx >= q + (1 if xcd < r else 0):
+            return None
+        lin = (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + idx
+        group_sz = GM * tiles_n
+        first_m = (lin // group_sz) * GM
+        gm = min(GM, tiles_m - first_m)
+        rin = lin % group_sz
+        return first_m + rin % gm, rin // gm
     q, r = tiles_m >> 3, tiles_m & 7
     cnt = q + (1 if xcd < r else 0)
     p0 = xcd * q + min(xcd, r)
@@ -35,6 +54,8 @@ def tile_of(block_id, tiles_m, tiles_n):
 
 
 def grid_of(tiles_m, tiles_n):
+    if not panels(tiles_m, tiles_n):
+        return 8 * ((tiles_m * tiles_n + 7) // 8)
     return 8 * ((tiles_m + 7) // 8) * tiles_n
 
 
@@ -51,11 +72,18 @@ def test_every_tile_once_and_panels_stay_on_one_xcd(tiles_m, tiles_n):
         assert 0 <= tm < tiles_m and 0 <= tn < tiles_n, (b, t)
         assert t not in seen, f'tile {t} computed by blocks {seen[t]} and {b}'
         seen[t] = b
-        assert panel_xcd.setdefault(tm, b & 7) == (b & 7), f'row panel {tm} is split over XCDs'
+        if panels(tiles_m, tiles_n):
+            assert panel_xcd.setdefault(tm, b & 7) == (b & 7), f'row panel {tm} is split over XCDs'
         if tm not in xcd_panels[b & 7]:
             xcd_panels[b & 7].append(tm)
     assert len(seen) == tiles_m * tiles_n
     assert idle == grid_of(tiles_m, tiles_n) - tiles_m * tiles_n
+    # the busiest XCD never needs more rounds of its 32 CUs than an even split of the tile list (the host cost model prices ceil(tiles / 256) rounds)
+    per_xcd = [sum(1 for b in seen.values() if b & 7 == x) for x in range(8)]
+    assert (max(per_xcd) + 31) // 32 <= ((tiles_m * tiles_n + 7) // 8 + 31) // 32, per_xcd
+    if not panels(tiles_m, tiles_n):
+        assert max(per_xcd) - min(per_xcd) <= 1
+        return
     shares = []
     for x in range(8):
         ps = sorted(xcd_panels[x])
@@ -91,10 +119,14 @@ def test_model_matches_the_sources():
     host = open(os.path.join(SRC, 'gemm.hip')).read()
     assert 'constexpr int GM = 4;' in big
     assert 'const int xcd = block_id & 7, idx = block_id >> 3;' in big
+    common = open(os.path.join(SRC, 'gemm_common.h')).read()
     assert 'const int q = p.tiles_m >> 3, r = p.tiles_m & 7;' in big
     assert 'const int cnt = q + (xcd < r ? 1 : 0), p0 = xcd * q + min(xcd, r);' in big
     assert 'if (idx >= cnt * p.tiles_n) return;' in big
     assert 'tm = p0 + first + rin % gm; tn = rin / gm;' in big
-    assert re.search(r'dim3\(8 \* \(\(p\.tiles_m \+ 7\) / 8\) \* p\.tiles_n\)', big)          # single launch: 8 x largest share x tiles_n
+    assert 'if (big_xcd_panels(p.tiles_m, p.tiles_n)) {' in big
+    assert 'const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;' in big
+    assert 'return tiles_m >= 8 && (share + 31) / 32 <= (big_xcd_even_share(tiles_m, tiles_n) + 31) / 32;' in common
+    assert 'dim3(big_xcd_grid(p.tiles_m, p.tiles_n))' in big          # single launch: 8 x largest share
     assert 'big_tile<VARIANT, false, false, true, 1>(g.p[i], b - g.tile_start[i]);' in big    # grouped conv: per-problem numbering
-    assert 'blocks += 8 * ceil_div(g.p[i].tiles_m, 8) * g.p[i].tiles_n;' in host
+    assert 'blocks += big_xcd_grid(g.p[i].tiles_m, g.p[i].tiles_n);' in host
