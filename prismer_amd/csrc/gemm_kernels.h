@@ -293,6 +293,10 @@ int launch_ks2(const GemmParams& p, hipStream_t s) {
   return PH_OK;
 }
 
+// (round 5: two further forms of the decoder's M = 960 launches were built, tested and measured neutral-to-negative -- a whole-K-resident 64x64
+//  kernel with every operand and write-out read requested in the prologue, and a 64x192-tile kernel for the wide qkv / MLP launches -- the
+//  N = 768 launches already sit at the latency of ONE tile, and 32-row wave tiles are LDS-bandwidth bound: profiles/r5_decoder_gemm.txt)
+
 template <int BM, int BN, bool TA, bool TB, int PF, int CONV = 0>
 int launch_pf(const GemmParams& p, int splits, hipStream_t s) {
   constexpr int smem_min = 2 * ((TA ? TileBytes<BM>::ks : TileBytes<BM>::kc) + (TB ? TileBytes<BN>::ks : TileBytes<BN>::kc));
