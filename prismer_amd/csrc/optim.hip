@@ -48,25 +48,30 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     }
   };
   if (mode == 1) {
-    // two 16-B vectors per stream and thread in flight (8 loads before the first use): the 4-read / 5-write stream mix left
-    // the kernel at 4.5-4.9 TB/s with one
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += 2 * stride) {
-      const int64_t j = i + stride;
-      const bool two = j < n4;
-      const int64_t jj = two ? j : i;
-      f32x4 tp0 = LD4(p, i), tg0 = LD4(g, i), tm0 = LD4(m, i), tv0 = LD4(v, i);
-      f32x4 tp1 = LD4(p, jj), tg1 = LD4(g, jj), tm1 = LD4(m, jj), tv1 = LD4(v, jj);
-      bf16x4 ob0, ob1;
-      update(tp0, tg0, tm0, tv0, ob0);
-      ST4(p, i, tp0); ST4(m, i, tm0); ST4(v, i, tv0);
-      if (pb) reinterpret_cast<bf16x4*>(pb)[i] = ob0;
-      if (zero_vec(i)) ST4(g, i, (f32x4{0.f, 0.f, 0.f, 0.f}));
-      if (two) {
-        update(tp1, tg1, tm1, tv1, ob1);
-        ST4(p, j, tp1); ST4(m, j, tm1); ST4(v, j, tv1);
-        if (pb) reinterpret_cast<bf16x4*>(pb)[j] = ob1;
-        if (zero_vec(j)) ST4(g, j, (f32x4{0.f, 0.f, 0.f, 0.f}));
+    // Every block owns ONE contiguous chunk of each of the nine streams (round 5; rounds 1-4 walked the buffers with a grid stride: at any
+    // moment the 2048 blocks then touched 2048 separate 4-KB pieces of every stream) and keeps two 16-B vectors per stream and thread in
+    // flight: 4.50 -> 5.15 TB/s on 174 M parameters, 3.90 -> 4.27 TB/s on a slower box (profiles/r5_ab_adamw_contiguous.txt); block count
+    // (256 .. 8192) and 4 vectors in flight: within 2 %; non-temporal stores: no gain.
+    constexpr int U = 2;
+    const int64_t per = ((n4 + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;          // whole 1024-gradient chunks (keep bitmap granularity)
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n4 ? lo + per : n4;
+    for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)U * 256) {
+      f32x4 tp[U], tg[U], tm[U], tv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = i0 + u * 256 < hi ? i0 + u * 256 : i0;
+        tp[u] = LD4(p, i); tg[u] = LD4(g, i); tm[u] = LD4(m, i); tv[u] = LD4(v, i);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = i0 + u * 256;
+        if (i < hi) {
+          bf16x4 ob;
+          update(tp[u], tg[u], tm[u], tv[u], ob);
+          ST4(p, i, tp[u]); ST4(m, i, tm[u]); ST4(v, i, tv[u]);
+          if (pb) reinterpret_cast<bf16x4*>(pb)[i] = ob;
+          if (zero_vec(i)) ST4(g, i, (f32x4{0.f, 0.f, 0.f, 0.f}));
+        }
       }
     }
   } else {
@@ -354,8 +359,8 @@ extern "C" int ph_adamw_keep(float* p, float* g, float* m, float* v, void* p_bf1
   PH_CHECK_ARG(p && g && m && v && hyper && n > 0, "ph_adamw: bad args");
   ProfScope prof__(PH_FAM_OPTIM, 0.0, 30.0 * (double)n, stream);
   PH_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && (((uintptr_t)p_bf16) & 7) == 0, "ph_adamw: misaligned");
-  constexpr int mode = 1;             // two vectors per stream in flight (0: the round-1 one-vector loop, 2: non-temporal stores -- both measured slower)
-  constexpr int blocks_cap = 2048;    // 8 blocks per CU: 1.298 -> 1.233 ms on 174 M parameters
+  constexpr int mode = 1;             // contiguous chunk per block, two vectors per stream in flight (0: the round-1 one-vector grid-stride loop)
+  constexpr int blocks_cap = 2048;    // 8 blocks per CU
   int grid = grid_for(n / 4 + 1);
   if (blocks_cap > 0 && grid > blocks_cap) grid = blocks_cap;
   hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, stream, p, g, m, v, (bf16*)p_bf16, n, hyper, beta1, beta2, eps,
