@@ -90,6 +90,10 @@ def build_trainer(batch, use_graph, rank, T=30, workload='base_caption', freeze=
         cfg = {'experts': pcfg.CAPTION_EXPERTS, 'image_resolution': 480, 'prismer_model': 'prismer_large', 'freeze': 'freeze_vision'}
         model = PrismerVQA(cfg).cuda()
         T = 40
+    elif workload == 'base_caption_480':                   # the SHIPPED caption fine-tune resolution (configs/caption.yaml:6,10: 480^2, batch 4 per GPU)
+        dims = pcfg.prismer_base(image_resolution=480)
+        cfg = {'experts': pcfg.CAPTION_EXPERTS, 'image_resolution': 480, 'prismer_model': 'prismer_base', 'freeze': freeze}
+        model = PrismerCaption(cfg).cuda()
     elif workload == 'z_base_caption':                     # BASELINE config 2: PrismerZ-BASE (rgb only, no resampler)
         dims = pcfg.prismerz_base()
         cfg = {'experts': 'none', 'image_resolution': 224, 'prismer_model': 'prismer_base', 'freeze': freeze}
@@ -117,11 +121,30 @@ def kernel_family_pass(tr, steps):
     tr.use_graph = False
     ops.join_side(); ops.SIDE = None           # single stream: per-launch durations without cross-stream contention
     tr.step(); torch.cuda.synchronize()
+    # decoder share of the step (round-4 review): HIP events around the decoder program's forward / backward entry points
+    dec_ev = []
+    dp = tr.dec_prog
+    saved = {n: getattr(dp, n) for n in ('forward', 'backward_start', 'backward_layers', 'backward_finish')}
+
+    def timed(fn):
+        def wrapper(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            dec_ev.append((e0, e1))
+            return r
+        return wrapper
+    for n, fn in saved.items():
+        setattr(dp, n, timed(fn))
     lib.ph_prof_enable(1)
     for _ in range(steps):
         tr.step()
-    if os.environ.get('PH_PROF_DUMP'):
-        lib.ph_prof_dump(os.environ['PH_PROF_DUMP'].encode())
+    for n in saved:
+        delattr(dp, n)                                      # (instance attributes shadowing the methods)
+    import tempfile
+    dump = os.environ.get('PH_PROF_DUMP') or os.path.join(tempfile.gettempdir(), f'ph_prof_{os.getpid()}.csv')
+    lib.ph_prof_dump(dump.encode())
     out = (ctypes.c_double * (len(FAMILIES) * 4))()
     lib.ph_prof_collect(out)
     lib.ph_prof_enable(0)
@@ -129,6 +152,26 @@ def kernel_family_pass(tr, steps):
     for i, name in enumerate(FAMILIES):
         ms, fl, by, n = out[4 * i:4 * i + 4]
         fam[name] = dict(ms_per_step=ms / steps, tflop_per_step=fl / steps / 1e12, launches_per_step=n / steps, gbytes_per_step=by / steps / 1e9)
+    # GEMM launches by KERNEL class (the library tags every profiled GEMM call with the class its dispatch chose)
+    names = ['gemm_kernel<128,*> (128x128 / 128x64 register-staged)', 'gemm_kernel<64,64> (64x64 register-staged)',
+             'gemm_ks2_kernel (64x64, k loop split inside the block: the decoder\'s M = 960 launches)',
+             'big::gemm_big_kernel<12,*,*> (256x128 LDS-DMA ping-pong, single launch)',
+             'big::gemm_big_grouped_kernel / gemm_big_conv_kernel (256x128 LDS-DMA, grouped: weight gradients, stem convolutions)',
+             'gemm_grouped_kernel (register-staged, grouped)', 'splitk_reduce']
+    cls = {}
+    try:
+        for line in open(dump):
+            f = line.rstrip('\n').split(',')
+            if f[0] == '0' and len(f) >= 5 and f[-1].lstrip('-').isdigit() and int(f[-1]) >= 0:
+                c = cls.setdefault(int(f[-1]), [0.0, 0.0, 0])
+                c[0] += float(f[1]); c[1] += float(f[2]); c[2] += 1
+    except OSError:
+        pass
+    if not os.environ.get('PH_PROF_DUMP') and os.path.isfile(dump):
+        os.remove(dump)
+    fam['_gemm_classes'] = {names[k] if k < len(names) else str(k): dict(ms_per_step=v[0] / steps, tflop_per_step=v[1] / steps / 1e12, launches_per_step=v[2] / steps)
+                            for k, v in cls.items()}
+    fam['_decoder_ms_per_step'] = sum(a.elapsed_time(b) for a, b in dec_ev) / steps
     return fam
 
 
@@ -137,7 +180,7 @@ def pmc_traffic():
     WRITE_SIZE in separate runs of this bench, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md; tools/profile_round4.sh is the
     recipe); counters cannot be read from inside the process, so this is (None, None) when the file is absent.  Returns the
     per-launch bytes and the launch count the passes saw, so that a stale file shows next to the live launch count."""
-    for name in ('r4_pmc_gemm.json', 'r3_pmc_gemm.json', 'r2_pmc_gemm.json', 'r1_pmc_gemm.json'):
+    for name in ('r5_pmc_gemm.json', 'r4_pmc_gemm.json', 'r3_pmc_gemm.json', 'r2_pmc_gemm.json', 'r1_pmc_gemm.json'):
         p = os.path.join(ROOT, 'profiles', name)
         if os.path.isfile(p):
             d = json.load(open(p))
@@ -429,6 +472,7 @@ def main():
     if rank == 0 and world == 1:
         if not args.no_roofline:
             fam = kernel_family_pass(tr, min(args.steps, 5))
+            gemm_classes, decoder_ms = fam.pop('_gemm_classes'), fam.pop('_decoder_ms_per_step')
             g = fam['gemm']
             ach = g['tflop_per_step'] / (g['ms_per_step'] / 1e3) if g['ms_per_step'] > 0 else 0.0
             out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_*kernel<*> (all bf16 MFMA GEMM launches of one step: gemm_kernel, gemm_ks2_kernel, gemm_grouped_kernel, big::gemm_big_kernel, big::gemm_big_grouped_kernel)',
@@ -436,7 +480,17 @@ def main():
                                'traffic': pmc_traffic()[0], 'traffic_source': pmc_traffic()[1], 'algorithmic_bytes_per_launch': round(g['gbytes_per_step'] * 1e9 / max(g['launches_per_step'], 1)),
                                'avg_launch_us': round(g['ms_per_step'] * 1e3 / max(g['launches_per_step'], 1), 2),
                                'launches_per_step': g['launches_per_step'], 'gemm_tflop_per_step': round(g['tflop_per_step'], 3)}
+            if gemm_classes:                                # the single most expensive GEMM kernel of the step, beside the family figure
+                dn, dv = max(gemm_classes.items(), key=lambda kv: kv[1]['ms_per_step'])
+                dach = dv['tflop_per_step'] / (dv['ms_per_step'] / 1e3) if dv['ms_per_step'] > 0 else 0.0
+                out['roofline']['dominant_kernel'] = {'name': dn, 'launches_per_step': round(dv['launches_per_step'], 1), 'ms_per_step': round(dv['ms_per_step'], 3),
+                                                      'achieved': round(dach, 1), 'frac': round(dach / PEAK_TFLOPS, 4),
+                                                      'note': 'algorithmic FLOPs / HIP-event time of the instrumented eager pass (2-3 us of event overhead per launch included)'}
+                out['roofline']['gemm_kernel_classes'] = {k: {'launches_per_step': round(v['launches_per_step'], 1), 'ms_per_step': round(v['ms_per_step'], 3),
+                                                              'frac': round((v['tflop_per_step'] / (v['ms_per_step'] / 1e3) if v['ms_per_step'] > 0 else 0.0) / PEAK_TFLOPS, 4)}
+                                                          for k, v in sorted(gemm_classes.items(), key=lambda kv: -kv[1]['ms_per_step'])}
             out['kernel_families_ms_per_step'] = {k: round(v['ms_per_step'], 3) for k, v in fam.items()}
+            out['decoder_ms_per_step'] = round(decoder_ms, 3)          # decoder forward (+ LM head, CE) + decoder backward, eager instrumented pass
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         if headline and not args.no_secondary and not args.no_graph:
@@ -447,7 +501,7 @@ def main():
             import gc
             gc.collect(); torch.cuda.empty_cache()
             sec = {}
-            for wl, bs, gf in (('z_base_caption', 32, 134.30), ('large_vqa', 16, 2987.8)):
+            for wl, bs, gf in (('z_base_caption', 32, 134.30), ('large_vqa', 16, 2987.8), ('base_caption_480', 4, None)):
                 try:
                     tr2, d2, _ = build_trainer(bs, True, 0, workload=wl)
                     f2 = tr2.step().item()
@@ -462,10 +516,12 @@ def main():
                     check_loss(wl, f2, l2.item())
                     v2 = bs * 10 / dt2
                     sec[wl] = dict(value=round(v2, 2), unit='images/sec', batch=bs, steps=10, warmup=3, ms_per_step=round(dt2 / 10 * 1e3, 3),
-                                   step_mfma_frac=round(v2 * gf / 1e3 / PEAK_TFLOPS, 4), hip_graph=bool(tr2.graphs is not None),
+                                   step_mfma_frac=None if gf is None else round(v2 * gf / 1e3 / PEAK_TFLOPS, 4), hip_graph=bool(tr2.graphs is not None),
                                    first_loss=round(float(f2), 4), final_loss=round(float(l2.item()), 4),
-                                   config='PrismerZ-BASE caption fine-tune, 224^2, rgb only (BASELINE config 2)' if wl == 'z_base_caption' else
-                                          'Prismer-LARGE VQAv2 fine-tune, 480^2, 6 experts, T=35+5, weighted loss (BASELINE config 5, one GPU)')
+                                   config={'z_base_caption': 'PrismerZ-BASE caption fine-tune, 224^2, rgb only (BASELINE config 2)',
+                                           'large_vqa': 'Prismer-LARGE VQAv2 fine-tune, 480^2, 6 experts, T=35+5, weighted loss (BASELINE config 5, one GPU)',
+                                           'base_caption_480': 'Prismer-BASE caption fine-tune at the SHIPPED resolution and per-GPU batch (configs/caption.yaml:6,10: '
+                                                               '480^2 rgb = 900 + 64 tokens, bicubic position re-grid, batch 4), T=30'}[wl])
                     del tr2
                     gc.collect(); torch.cuda.empty_cache()
                 except Exception as e:                     # a secondary leg must never take the headline line down

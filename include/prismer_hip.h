@@ -392,7 +392,7 @@ int ph_weighted_sum_f32(const float* x, const float* weights, int n, float scale
  * bytes, launches}.  Must stay disabled during hipGraph capture. */
 int ph_prof_enable(int on);
 int ph_prof_collect(double* out);
-int ph_prof_dump(const char* path);   /* CSV: family,ms,flops,description per recorded call */
+int ph_prof_dump(const char* path);   /* CSV: family,ms,flops,description,GEMM kernel class (ph_gemm_dispatch_counts order; -1: none) per recorded call */
 
 /* unit-test probe: exercises ds_read_b64_tr_b16 / MFMA lane layouts on the device (tests/test_kernels_gpu.py) */
 int ph_probe_layouts(const void* in_bf16, float* out, hipStream_t stream);

@@ -35,6 +35,7 @@ int ph_fail(int code, const char* fmt, ...);
 enum { PH_FAM_GEMM = 0, PH_FAM_LAYERNORM, PH_FAM_ATTN_FWD, PH_FAM_ATTN_BWD, PH_FAM_FRONTEND, PH_FAM_EMBED_CE, PH_FAM_OPTIM, PH_FAM_MISC,
        PH_FAM_COUNT };
 extern int g_ph_prof_enabled;
+extern int g_ph_prof_last_cls;      // GEMM kernel class of the profiled call in flight (core.hip)
 void ph_prof_begin(int family, double flops, double bytes, hipStream_t s, const char* desc = nullptr);
 void ph_prof_end(hipStream_t s);
 struct ProfScope {

@@ -48,7 +48,7 @@ extern "C" const char* ph_last_error(void) { return g_last_error.c_str(); }
 #include <vector>
 int g_ph_prof_enabled = 0;
 namespace {
-struct ProfRec { int fam; double flops, bytes; hipEvent_t a, b; std::string desc; };
+struct ProfRec { int fam; double flops, bytes; hipEvent_t a, b; std::string desc; int cls; };     // cls: GEMM kernel class of the launch (count_launch), -1 otherwise
 std::vector<ProfRec> g_recs;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t get_event() {
@@ -56,15 +56,17 @@ hipEvent_t get_event() {
   hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
 }  // namespace
+int g_ph_prof_last_cls = -1;        // set by the GEMM launchers (gemm_common.h count_launch): which kernel class the call in flight ended up on
 void ph_prof_begin(int family, double flops, double bytes, hipStream_t s, const char* desc) {
-  ProfRec r{family, flops, bytes, get_event(), get_event(), desc ? desc : ""};
+  ProfRec r{family, flops, bytes, get_event(), get_event(), desc ? desc : "", -1};
   (void)hipEventRecord(r.a, s);
+  g_ph_prof_last_cls = -1;
   g_recs.push_back(r);
 }
-void ph_prof_end(hipStream_t s) { (void)hipEventRecord(g_recs.back().b, s); }
+void ph_prof_end(hipStream_t s) { (void)hipEventRecord(g_recs.back().b, s); g_recs.back().cls = g_ph_prof_last_cls; }
 
 extern "C" int ph_prof_enable(int on) { g_ph_prof_enabled = on; return PH_OK; }
-/* writes one CSV line per recorded call (family, ms, flops, desc) WITHOUT clearing: call before ph_prof_collect */
+/* writes one CSV line per recorded call (family, ms, flops, desc, GEMM kernel class or -1) WITHOUT clearing: call before ph_prof_collect */
 extern "C" int ph_prof_dump(const char* path) {
   (void)hipDeviceSynchronize();
   FILE* f = fopen(path, "w");
@@ -72,7 +74,7 @@ extern "C" int ph_prof_dump(const char* path) {
   for (auto& r : g_recs) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, r.a, r.b);
-    fprintf(f, "%d,%.4f,%.0f,%s\n", r.fam, ms, r.flops, r.desc.c_str());
+    fprintf(f, "%d,%.4f,%.0f,%s,%d\n", r.fam, ms, r.flops, r.desc.c_str(), r.cls);
   }
   fclose(f);
   return PH_OK;

@@ -702,7 +702,7 @@ struct GroupParams {
 enum { PH_GEMM_CLS_128 = 0, PH_GEMM_CLS_64, PH_GEMM_CLS_KS2, PH_GEMM_CLS_BIG, PH_GEMM_CLS_BIG_GROUPED, PH_GEMM_CLS_GROUPED,
        PH_GEMM_CLS_SPLITK_REDUCE, PH_GEMM_CLS_COUNT };
 extern std::atomic<long long> g_gemm_counts[PH_GEMM_CLS_COUNT];
-inline void count_launch(int cls) { g_gemm_counts[cls].fetch_add(1, std::memory_order_relaxed); }
+inline void count_launch(int cls) { g_gemm_counts[cls].fetch_add(1, std::memory_order_relaxed); if (g_ph_prof_enabled) ::g_ph_prof_last_cls = cls; }
 
 // launchers of the register-staged kernels (gemm_kernels.h, instantiated by gemm_s128.hip / gemm_s64.hip / gemm_g128.hip / gemm_g64.hip)
 namespace reg {

@@ -22,6 +22,8 @@ def _dims(name):
         return config.prismer_base()
     if name == 'zbase_b4':                # BASELINE config 2 geometry: PrismerZ-BASE, full depth
         return config.prismerz_base()
+    if name == 'huge_b1':                 # configs/prismer.json:50-73 + ViT-H/14 (vit.py:211-214): width 1280, 32 + 24 layers, resampler head dim 160
+        return config.prismer_huge()
     if name in ('large_vqa_b1', 'large_vqa_b4'):            # BASELINE config 5 geometry: Prismer-LARGE VQA, 480^2, full depth (24 + 24 layers)
         return config.prismer_large()
     raise KeyError(name)
@@ -46,10 +48,12 @@ CASES = OrderedDict([
     ('base_b32', (32, 30, True)),
     # round 4: config 5 at a batch where the dispatch picks the 256x128 / grouped kernels UNFORCED (B=1 had to force them); ragged rows
     ('large_vqa_b4', (4, 40, True)),
+    # round 5: Prismer-HUGE geometry (the pre-train recipe's largest model): one sample, full depth
+    ('huge_b1', (1, 30, False)),
 ])
 
-LOGIT_STRIDE = {'base_caption': 97, 'base_b8': 97, 'zbase_b4': 97, 'large_vqa_b1': 97, 'base_b32': 97, 'large_vqa_b4': 97}    # every 97th vocab column for the big cases
-ENC_STRIDE = {'base_b8': 16, 'zbase_b4': 8, 'large_vqa_b1': 16, 'base_b32': 16, 'large_vqa_b4': 16}                             # every n-th feature of the encoder output
+LOGIT_STRIDE = {'base_caption': 97, 'base_b8': 97, 'zbase_b4': 97, 'large_vqa_b1': 97, 'base_b32': 97, 'large_vqa_b4': 97, 'huge_b1': 97}    # every 97th vocab column for the big cases
+ENC_STRIDE = {'base_b8': 16, 'zbase_b4': 8, 'large_vqa_b1': 16, 'base_b32': 16, 'large_vqa_b4': 16, 'huge_b1': 16}                             # every n-th feature of the encoder output
 VQA_CASES = ('tiny_vqa', 'large_vqa_b1', 'large_vqa_b4')
 VQA_HEAD_TQ, VQA_HEAD_TA = 9, 5
 DROP_CASES = ('tiny_caption', 'base_b8')     # <case>_drop.npz: reference outputs in full training mode under the library's dropout masks (round 5)
