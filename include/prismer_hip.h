@@ -144,6 +144,9 @@ typedef struct {
   void* y_f32;                    /* optional fp32 copy of the output [M,D] (identity row map) */
 } ph_layernorm_fwd_args;
 int ph_layernorm_fwd(const ph_layernorm_fwd_args* args, hipStream_t stream);
+/* 0: always the one-row-per-wave forward kernel (A/B, tests); 1: default (bf16 rows of a multiple of 256 elements and M >= 1024 take the
+ * half-wave-per-row kernel with 16-B vectors); < 0: query.  Returns the previous setting. */
+int ph_layernorm_tuning(int fwd16);
 
 typedef struct {
   const void* dy; ph_rowmap dy_map;      /* bf16 */

@@ -171,6 +171,7 @@ _SIGS = {
     'ph_gemm_grouped_capped_bf16': (c_int, [c_void_p, c_int, c_int, c_void_p]),
     'ph_gemm_tuning': (c_int, [c_int, c_int]),
     'ph_attention_tuning': (c_int, [c_int]),
+    'ph_layernorm_tuning': (c_int, [c_int]),
     'ph_gemm_flush_deferred': (c_int, [c_void_p]),
     'ph_gemm_dispatch_counts': (c_int, [c_void_p, c_int, c_int]),
     'ph_query_workspace': (c_i64, [c_int, c_void_p, c_int]),

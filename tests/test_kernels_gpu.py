@@ -405,6 +405,42 @@ def test_layernorm(ops, M, D):
         ops.WQ.enabled = True
 
 
+@pytest.mark.parametrize('M,D', [(8320, 768), (1027, 1024), (2049, 1280), (1200, 256)])
+def test_layernorm_fwd_half_wave_rows(ops, M, D):
+    """ln_fwd16_kernel (round 5: half a wave per bf16 row, 16-B vectors; rows of a multiple of 256 elements, M >= 1024): against fp32 torch and
+    against the one-row-per-wave kernel on the same call (ph_layernorm_tuning(0)), with the mapped second output, the fp32 copy and the
+    saved statistics; ragged M (rows beyond M in the last block)."""
+    from prismer_amd import _lib
+    from prismer_amd._lib import RowMap
+    x = rnd(M, D, seed=20)
+    g = 1 + 0.1 * rnd(D, dtype=torch.float32, seed=21)
+    b = 0.1 * rnd(D, dtype=torch.float32, seed=22)
+
+    def run():
+        y2 = torch.zeros(M + 5 * ((M + 99) // 100), D, dtype=BF, device='cuda')
+        yf = torch.empty(M, D, device='cuda')
+        a = _lib.LayerNormFwdArgs(x.data_ptr(), g.data_ptr(), b.data_ptr(), 0, _lib.IDENT, y2.data_ptr(), RowMap(100, 105, 5), 0, 0, M, D, 1e-5, 0, yf.data_ptr())
+        y = torch.empty(M, D, dtype=BF, device='cuda')
+        stats = torch.empty(2, M, device='cuda')
+        a.y, a.mean, a.rstd = y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr()
+        import ctypes as C
+        _lib.check(_lib.lib.ph_layernorm_fwd(C.byref(a), torch.cuda.current_stream().cuda_stream), 'ph_layernorm_fwd')
+        return y, y2, yf, stats
+    new = run()
+    assert _lib.lib.ph_layernorm_tuning(0) == 1
+    try:
+        old = run()
+    finally:
+        _lib.lib.ph_layernorm_tuning(1)
+    ref = F.layer_norm(x.float(), (D,), g, b, 1e-5)
+    assert rel_fro(new[0], ref) < 6e-3 and rel_fro(new[2], ref) < 1e-5
+    assert rel_fro(new[3][0], x.float().mean(1)) < 1e-5
+    for a_, b_, tol in zip(new, old, (2e-3, 2e-3, 1e-5, 1e-5)):        # (bf16 outputs: a different summation order flips single roundings)
+        assert rel_fro(a_, b_) < tol, rel_fro(a_, b_)
+    rows = torch.arange(M, device='cuda')
+    assert torch.equal(new[1][(rows // 100) * 105 + 5 + rows % 100], new[0])      # the mapped copy is the output, row for row
+
+
 def test_layernorm_rowmap_and_dropout(ops):
     from prismer_amd._lib import RowMap
     B, L, Mx, D = 3, 8, 20, 256

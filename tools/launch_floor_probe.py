@@ -28,6 +28,14 @@ def main():
              ('torch add_ 960x768 (elementwise)', lambda: outf.add_(1.0))]
     for name, fn in cases:
         print(f'{name:50s} {chain_time(fn):6.2f} us per launch in a chain of 40')
+    # trunk LayerNorm (8320 bf16 rows of 768): one row per wave with 8-B vectors vs half a wave per row with 16-B vectors (round 5)
+    xt = torch.randn(8320, 768, device='cuda').to(BF)
+    ot = torch.empty_like(xt)
+    for flag, what in ((0, 'one row per wave, 8-B vectors'), (1, 'half a wave per row, 16-B vectors')):
+        _lib.lib.ph_layernorm_tuning(flag)
+        t = chain_time(lambda: ops.layernorm_fwd(xt, g, b, out=ot))
+        print(f'layernorm_fwd 8320 x 768 bf16, {what:36s} {t:6.2f} us per launch = {8320 * 768 * 4 / t / 1e6:.2f} TB/s')
+    _lib.lib.ph_layernorm_tuning(1)
 
 
 if __name__ == '__main__':
