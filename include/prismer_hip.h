@@ -385,6 +385,10 @@ int ph_advance_seed(uint64_t* seed, hipStream_t stream);
 /* step glue (round 4: the last stock torch kernels inside the captured step).  x[i] += value for n int64 counters -- BatchNorm's
  * num_batches_tracked of all stem layers at once (torch/nn/modules/batchnorm.py semantics, vit.py:88-120) */
 int ph_add_i64(int64_t* x, int n, int64_t value, hipStream_t stream);
+/* zero fill and flat copy as kernels (16-B aligned, bytes % 16 == 0): the step's accumulator resets and the optimizer-sharding staging copies,
+ * so that a captured segment contains no memset / memcpy node (revision 103) */
+int ph_fill_zero(void* p, int64_t bytes, hipStream_t stream);
+int ph_copy_bytes(void* dst, const void* src, int64_t bytes, hipStream_t stream);
 /* out[0] = scale * sum_i x[i] * (weights ? weights[i] : 1): the batch loss -- caption loss.mean() (prismer_caption.py:33) with scale = 1/B,
  * VQA (weights * loss).mean() (prismer_vqa.py:40-41) */
 int ph_weighted_sum_f32(const float* x, const float* weights, int n, float scale, float* out, hipStream_t stream);

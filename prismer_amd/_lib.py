@@ -183,6 +183,8 @@ _SIGS = {
     'ph_conv_grad_from_shadow': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ph_advance_seed': (c_int, [c_void_p, c_void_p]),
     'ph_add_i64': (c_int, [c_void_p, c_int, c_i64, c_void_p]),
+    'ph_fill_zero': (c_int, [c_void_p, c_i64, c_void_p]),
+    'ph_copy_bytes': (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     'ph_weighted_sum_f32': (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
     'ph_prof_enable': (c_int, [c_int]),
     'ph_prof_collect': (c_int, [c_void_p]),

@@ -582,6 +582,33 @@ __global__ __launch_bounds__(256) void weighted_sum_kernel(const float* __restri
   if (threadIdx.x == 0) out[0] = (red[0] + red[1] + red[2] + red[3]) * scale;
 }
 }  // namespace
+namespace {
+// zero fill / flat copy as KERNELS (16-B vectors; n16 = bytes / 16): what the captured step uses instead of torch.zeros / Tensor.copy_, so that a
+// replayed segment holds nothing but this library's kernel nodes (round 5: a memset NODE of a captured hipGraph does not replay correctly on
+// ROCm 7.0 -- tools/graph_memset_probe.py -- and a memcpy node is one bug report away from the same)
+__global__ __launch_bounds__(256) void fill_zero_kernel(u32x4* __restrict__ p, int64_t n16) {
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) p[i] = z;
+}
+__global__ __launch_bounds__(256) void copy_bytes_kernel(u32x4* __restrict__ d, const u32x4* __restrict__ s, int64_t n16) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+}
+}  // namespace
+extern "C" int ph_fill_zero(void* p, int64_t bytes, hipStream_t stream) {
+  PH_CHECK_ARG(p && bytes > 0 && (bytes % 16) == 0 && (((uintptr_t)p) & 15) == 0, "ph_fill_zero: need a 16-B aligned buffer of a multiple of 16 bytes");
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_fill_zero");
+  hipLaunchKernelGGL(fill_zero_kernel, dim3(grid_for(bytes / 16)), dim3(256), 0, stream, (u32x4*)p, bytes / 16);
+  PH_LAUNCH_CHECK("fill_zero_kernel");
+  return PH_OK;
+}
+extern "C" int ph_copy_bytes(void* dst, const void* src, int64_t bytes, hipStream_t stream) {
+  PH_CHECK_ARG(dst && src && bytes > 0 && (bytes % 16) == 0 && ((((uintptr_t)dst) | ((uintptr_t)src)) & 15) == 0,
+               "ph_copy_bytes: need 16-B aligned buffers of a multiple of 16 bytes");
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_copy_bytes");
+  hipLaunchKernelGGL(copy_bytes_kernel, dim3(grid_for(bytes / 16)), dim3(256), 0, stream, (u32x4*)dst, (const u32x4*)src, bytes / 16);
+  PH_LAUNCH_CHECK("copy_bytes_kernel");
+  return PH_OK;
+}
 extern "C" int ph_add_i64(int64_t* x, int n, int64_t value, hipStream_t stream) {
   PH_CHECK_ARG(x && n > 0, "ph_add_i64: bad args");
   ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_add_i64");

@@ -24,6 +24,15 @@ import torch
 import torch.distributed as dist
 
 
+def _copy_flat(dst, src):
+    """staging copies of the reduce-scatter / all-gather mode: the library's copy kernel on the GPU (round-4 review: no stock torch kernel on the
+    step path), Tensor.copy_ for the CPU tensors of the gloo tests"""
+    if dst.is_cuda:
+        from . import ops
+        return ops.copy_flat(dst, src)
+    return dst.copy_(src)
+
+
 def bucket_ranges(n, bucket_elems, start=0):
     return [(o, min(n, o + bucket_elems)) for o in range(start, n, bucket_elems)]
 
@@ -171,14 +180,14 @@ class GradExchange:
         if self.payload == 'bf16':
             self.pack(flat[lo:hi], stage[:n], 1.0 / W)                  # (the pad tail of the staging buffer stays zero)
         else:
-            stage[:n].copy_(flat[lo:hi])
+            _copy_flat(stage[:n], flat[lo:hi])
         self.reduce_scatter(red, stage)
         a, b = self.piece(lo, hi)
         if b > a:
             if self.payload == 'bf16':
                 self.unpack(red[:b - a], flat[a:b])
             else:
-                flat[a:b].copy_(red[:b - a])
+                _copy_flat(flat[a:b], red[:b - a])
         self.owned.setdefault(id(flat), {})[lo] = (a, b)
         self.ranges.setdefault(id(flat), {})[lo] = hi
         self.bytes_per_step += stage.element_size() * n * (W - 1) // W
@@ -196,9 +205,9 @@ class GradExchange:
             full, mine = self.stage[key]
             a, b = self.piece(lo, hi)
             if b > a:
-                mine[:b - a].copy_(values[a:b])
+                _copy_flat(mine[:b - a], values[a:b])
             self.all_gather(full, mine)
-            values[lo:hi].copy_(full[:n])
+            _copy_flat(values[lo:hi], full[:n])
             self.bytes_per_step += values.element_size() * n * (W - 1) // W
 
 

@@ -818,6 +818,37 @@ def weighted_sum(x, weights, scale, out=None):
     return out
 
 
+def zeros(shape, dtype, device):
+    """torch.zeros through the library: an empty tensor + ONE ph_fill_zero launch (no stock torch kernel, no memset node in a captured step)."""
+    if isinstance(shape, int):
+        shape = (shape,)
+    n = 1
+    for v in shape:
+        n *= int(v)
+    nbytes = n * torch.empty((), dtype=dtype).element_size()
+    pad = (nbytes + 15) // 16 * 16
+    buf = torch.empty(pad, dtype=torch.uint8, device=device)              # (the caching allocator aligns to 512 B)
+    check(lib.ph_fill_zero(buf.data_ptr(), pad, _stream()), 'ph_fill_zero')
+    return buf[:nbytes].view(dtype).reshape(shape)
+
+
+def copy_flat(dst, src):
+    """dst[:] = src for contiguous 1-D tensors of one dtype: ph_copy_bytes for the 16-B aligned body, Tensor.copy_ for a ragged tail / head"""
+    assert dst.dtype == src.dtype and dst.numel() == src.numel() and dst.is_contiguous() and src.is_contiguous()
+    nbytes = dst.numel() * dst.element_size()
+    if nbytes == 0:
+        return dst
+    if (dst.data_ptr() | src.data_ptr()) & 15 or nbytes < 16:
+        dst.copy_(src)
+        return dst
+    body = nbytes // 16 * 16
+    check(lib.ph_copy_bytes(dst.data_ptr(), src.data_ptr(), body, _stream()), 'ph_copy_bytes')
+    if body < nbytes:
+        k = body // dst.element_size()
+        dst.reshape(-1)[k:].copy_(src.reshape(-1)[k:])
+    return dst
+
+
 def advance_seed(seed):
     check(lib.ph_advance_seed(seed.data_ptr(), _stream()), 'ph_advance_seed')
 

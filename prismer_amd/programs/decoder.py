@@ -379,7 +379,7 @@ class DecoderProgram:
         H = d.hidden_size
         nl = len(self.layers)
         merged = self.kv_all is not None and nl > 0
-        denc = None if merged else torch.zeros(B * S, d.vision_hidden_size, dtype=F32, device=dh.device)
+        denc = None if merged else ops.zeros((B * S, d.vision_hidden_size), F32, dh.device)
         dkv_all = torch.empty(B * S, 2 * H * nl, dtype=BF16, device=dh.device) if merged else None
         F_ = self.final
         dh = self.mlp_bwd(F_['mlp'], blocks.pop(), dh)

@@ -209,7 +209,7 @@ class EncoderProgram:
                            a_in=[], ys=[], stats=[], geo=[], col0=None))
         n_ch = sum(d.width // k for k in (8, 4, 2, 1))
         SL = COLSTAT_SLABS
-        sums_arena = torch.zeros(len(st) * SL * 2 * n_ch, dtype=torch.float64, device=st[0]['a'].device) if st else None     # fp64: see tile_colstats
+        sums_arena = ops.zeros(len(st) * SL * 2 * n_ch, torch.float64, st[0]['a'].device) if st else None     # fp64: see tile_colstats
         stats_arena = torch.empty(len(st) * 4 * n_ch, dtype=F32, device=st[0]['a'].device) if st else None
         so = to = 0
         for i in range(4):
@@ -272,7 +272,7 @@ class EncoderProgram:
             das.append(da)
         ops.gemm_grouped(probs, trans_b=True)
         n_ch = sum(self.d.width // k for k in (8, 4, 2, 1))
-        sums_arena = torch.zeros(len(doms) * 2 * n_ch, dtype=F32, device=dev)
+        sums_arena = ops.zeros(len(doms) * 2 * n_ch, F32, dev)
         so = 0
         for i in (3, 2, 1, 0):
             bn_items, dys = [], []
@@ -550,7 +550,7 @@ class EncoderProgram:
             G = d.expert_grid ** 2
             Mx = len(names) * G
             same = d.expert_grid == d.rgb_grid
-            dpos_e = gpos if same else torch.zeros(G, W, dtype=F32, device=dh.device)
+            dpos_e = gpos if same else ops.zeros((G, W), F32, dh.device)
             keep = []
             for ei, name in enumerate(names):
                 dfeat = torch.empty(B * G, W, dtype=BF16, device=dh.device)

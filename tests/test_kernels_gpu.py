@@ -878,6 +878,34 @@ def test_adamw_matches_torch(ops):
     assert rel_fro(pb, p) < 4e-3
 
 
+def test_fill_zero_and_copy_kernels(ops):
+    """ops.zeros / ops.copy_flat: the step's accumulator resets and the optimizer-sharding staging copies run as library kernels (round 5: no
+    memset / memcpy node and no stock torch kernel inside a captured segment), also under hipGraph replay over buffers that held junk."""
+    z = ops.zeros((7, 13), torch.float32, 'cuda')
+    assert z.shape == (7, 13) and z.dtype == torch.float32 and float(z.abs().sum()) == 0.0
+    z64 = ops.zeros(5, torch.float64, 'cuda')
+    assert z64.dtype == torch.float64 and float(z64.abs().sum()) == 0.0
+    src = torch.randn(100003, device='cuda')
+    for n in (100003, 4096, 3):
+        dst = torch.full((n,), 7.0, device='cuda')
+        ops.copy_flat(dst, src[:n])
+        assert torch.equal(dst, src[:n])
+    off = torch.full((1001,), 7.0, device='cuda')
+    ops.copy_flat(off[1:], src[:1000])                           # misaligned destination: falls back to Tensor.copy_
+    assert torch.equal(off[1:], src[:1000]) and off[0] == 7.0
+    buf = torch.full((1024,), 9.0, device='cuda')
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        t = ops.zeros(32, torch.float32, 'cuda')                 # a 128-byte reset: the size a memset node gets wrong
+        t.add_(buf[:32])
+        ops.copy_flat(buf[512:544], t)
+    for i in range(4):
+        buf[:32] = float(i + 1)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(buf[512:544], torch.full((32,), float(i + 1), device='cuda')), i
+
+
 def test_small_utils(ops):
     x = torch.randn(1000, 72, device='cuda')
     xb = ops.cast_to_bf16(x)
