@@ -1,14 +1,9 @@
 #!/bin/bash
-# end-of-round verification on the GPU box: full -m gpu suite, smoke, the profile set (tools/profile_round.sh) and the secondary bench lines
-out=gpurun_out/r2_check; mkdir -p $out
+# End-of-round check on the GPU box: the whole -m gpu suite, smoke(), the default bench line.      bash tools/round_check.sh [name]
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+out=gpurun_out/${1:-r5_final}; mkdir -p $out
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -q --timeout=900 --durations=5 > $out/pytest.log 2>&1; echo "pytest rc=$?" >> $out/pytest.log
-grep -E "^(FAILED|ERROR)|passed|failed|^E  " $out/pytest.log | tail -10
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; tail -1 $out/smoke.log
-bash tools/profile_round.sh gpurun_out/r2_prof > $out/profile.log 2>&1; grep -E "per step|total " $out/profile.log | head -3
-timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --compact-labels > gpurun_out/r2_prof/bench_compact_labels.json 2>/dev/null
-timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --workload z_base_caption > gpurun_out/r2_prof/bench_prismerz_base.json 2>/dev/null
-timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-roofline --workload large_vqa --batch 16 > gpurun_out/r2_prof/bench_large_vqa_bs16.json 2>/dev/null
-timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --freeze none > gpurun_out/r2_prof/bench_freeze_none.json 2>/dev/null
-for f in bench_n1 bench_compact_labels bench_prismerz_base bench_large_vqa_bs16 bench_freeze_none; do python -c "
-import json; d=json.load(open('gpurun_out/r2_prof/$f.json')); print('$f', d['value'], d['ms_per_step'], d.get('roofline',{}).get('frac'))"; done
+timeout 1800 python -m pytest tests -m gpu -q --timeout=1200 > $out/pytest.log 2>&1; echo "pytest rc=$?"; tail -5 $out/pytest.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $out/smoke.log
+timeout 600 python bench.py > $out/bench_n1.json 2> $out/bench_n1.err; echo "bench rc=$?"; tail -2 $out/bench_n1.err; python -c "
+import json; d=json.load(open('$out/bench_n1.json')); print('bench', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline'].get('dominant_kernel', {}).get('frac'), d['roofline']['traffic'], d['roofline']['traffic_source']); print({k:(v.get('value'), v.get('ms_per_step'), v.get('final_loss'), v.get('error')) for k,v in (d.get('secondary') or {}).items()}); print(d.get('cpu_baseline'))"
