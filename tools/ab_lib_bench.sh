@@ -8,6 +8,6 @@ for rep in 1 2; do
     lib=prismer_amd/lib/libprismer_hip.so; [ $w != prod ] && lib=prismer_amd/lib/libprismer_hip_$w.so
     PRISMER_HIP_LIB=$lib timeout 300 python bench.py --steps 20 --warmup 5 --no-secondary --no-cpu-baseline > $out/bench_${w}_$rep.json 2> $out/bench_${w}_$rep.err
     python -c "
-import json; d=json.load(open('$out/bench_${w}_$rep.json')); f=d['kernel_families_ms_per_step']; print('$w rep $rep:', d['value'], 'images/s', d['ms_per_step'], 'ms | attention fwd', f['attention_fwd'], 'bwd', f['attention_bwd'], '| gemm', f['gemm'], '| layernorm', f['layernorm'])"
+import json; d=json.load(open('$out/bench_${w}_$rep.json')); f=d['kernel_families_ms_per_step']; print('$w rep $rep:', d['value'], 'images/s', d['ms_per_step'], 'ms | attention fwd', f['attention_fwd'], 'bwd', f['attention_bwd'], '| gemm', f['gemm'], '| layernorm', f['layernorm'], '| frontend', f['frontend'], '| optimizer', f['optimizer'])"
   done
 done
