@@ -497,6 +497,7 @@ ATTN_CASES = [  # B, H, Sq, Sk, dh, causal, masked, drop
     (2, 3, 1, 23, 64, True, True, 0.0),          # one query: a cached decode step (generation)
     (2, 2, 17, 320, 64, False, True, 0.2),       # the largest key image the small kernels take
     (1, 2, 64, 37, 64, False, False, 0.0),       # full 64-query tile, ragged keys
+    (2, 3, 280, 150, 64, False, False, 0.0),     # mask-free kernels, ragged tails on both sides
 ]
 
 
