@@ -447,6 +447,13 @@ def _check_grads_against_golden(g, named_grads, tag):
         e_samp = float(np.linalg.norm(samp - g['gsamp.' + n]) / (np.linalg.norm(g['gsamp.' + n]) + 1e-30))
         bar_s = max(2 * TOL_GRAD, 2.0 * float(g['ac_samp.' + n]))
         bar_n = max(TOL_GRAD, 2.0 * float(g['ac_norm.' + n]))
+        # A 16-entry sample of a SPARSE gradient (the instance-embedding table: most rows are never drawn, vit.py:141-148; position rows beyond
+        # the text length; dead squared-ReLU units) can hold fewer than six non-zero entries: its relative error is then an estimate from a
+        # handful of numbers of magnitude 1e-6 (round 5, large_vqa_b4 instance_embedding, 3 non-zero samples: 0.035 with one LayerNorm forward
+        # kernel, 0.142 with another of IDENTICAL accuracy against fp64 -- while the full-tensor error of that gradient is 0.016 / 0.021, the
+        # autocast yardstick's own 0.020).  Such tensors are held to the full-tensor projection check below and to the norm, not to the sample.
+        if 'gproj.' + n in g and int((g['gsamp.' + n] != 0).sum()) < 6:
+            e_samp = 0.0
         worst.append((e_samp / bar_s, e_norm / bar_n, e_samp, e_norm, n))
         if 'gfull.' + n in g:
             assert rel_fro(gr, torch.from_numpy(g['gfull.' + n])) < max(bar_s, TOL_GRAD), n
