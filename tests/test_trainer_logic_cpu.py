@@ -51,3 +51,18 @@ def test_outputs_outside_the_gradient_buffer_are_ignored():
     fake = types.SimpleNamespace(stores=[st], device='cpu')
     Trainer._finish_count(fake, {other.data_ptr(): (1, 1024, True), st.grad.data_ptr() + 2: (1, 8, True)})     # foreign buffer; misaligned
     assert fake._exclusive == set() and int(fake._keep_maps[0].abs().sum()) == 0
+
+
+def test_bench_loss_check_rejects_garbage():
+    """bench.check_loss (round 5): a leg whose loss is not a sane training loss raises instead of publishing a throughput (the round-4 loader leg
+    reported 1.7e8 and 1.1e18)"""
+    import math
+    import pytest
+    import bench
+    bench.check_loss('ok', 283.8, 260.4)
+    bench.check_loss('ok', 32.6, 23.2)
+    for first, last in ((283.8, 1.7e8), (283.8, 1.147e18), (283.8, float('nan')), (283.8, float('inf')), (283.8, -1.19e34), (283.8, 0.0), (float('nan'), 260.0),
+                        (283.8, 600.0)):
+        with pytest.raises(RuntimeError, match='loss check failed'):
+            bench.check_loss('leg', first, last)
+    assert math.isfinite(283.8)
