@@ -350,7 +350,7 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
           tot += g.p[i].tiles_m * g.p[i].tiles_n;
         }
         g.tile_start[n] = tot;
-        return big::launch_grouped_wgrad(g, tot, big_mode_now() == 6 ? 5 : 4, stream);
+        return big::launch_grouped_wgrad(g, tot, big_mode_now() >= 6 ? 5 : 4, stream);
       }
     }
   }
@@ -374,7 +374,7 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
         blocks += big_xcd_grid(g.p[i].tiles_m, g.p[i].tiles_n);          // (XCD shares, see big_tile: the blocks beyond a share exit)
       }
       g.tile_start[n] = blocks;
-      return big::launch_grouped_conv(g, blocks, big_mode_now() == 6 ? 5 : 4, stream);
+      return big::launch_grouped_conv(g, blocks, big_mode_now() >= 6 ? 5 : 4, stream);
     }
   }
   if (conv) {               // gathered operand: forward (NN, A = im2col view) or weight gradient (TT, B = im2col view); no prefetch ring
@@ -462,7 +462,7 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
       p.tiles_m = ceil_div(a->M, big::BM); p.tiles_n = ceil_div(a->N, big::BN);
       p.k_tiles_per_split = a->K / BK;
       p.ws = nullptr; p.ldws = 0;
-      return big::launch_single(p, big_mode == 1 ? 0 : (big_mode == 6 ? 5 : 4), false, a->trans_b != 0, stream);
+      return big::launch_single(p, big_mode == 1 ? 0 : (big_mode == 6 ? 5 : (big_mode >= 7 && big_mode <= 11 ? big_mode : 4)), false, a->trans_b != 0, stream);
     }
     // weight-gradient layout (A = [K][M], B = [K][N]) with a long reduction: same kernel, both operands through the transposing reads
     if (big_mode > 0 && !a->conv && !a->col_stats && a->trans_a && a->trans_b && (a->K % BK) == 0 && a->K >= 32 * BK && a->split_k <= 0 &&
@@ -470,7 +470,7 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
       p.tiles_m = ceil_div(a->M, big::BM); p.tiles_n = ceil_div(a->N, big::BN);
       p.k_tiles_per_split = a->K / BK;
       p.ws = nullptr; p.ldws = 0;
-      return big::launch_single(p, big_mode == 6 ? 5 : 4, true, true, stream);
+      return big::launch_single(p, big_mode >= 6 ? 5 : 4, true, true, stream);
     }
   }
 

@@ -20,11 +20,11 @@ def _dims(name):
         return config.prismer_tiny(experts=[])
     if name in ('base_caption', 'base_b8', 'base_b32'):
         return config.prismer_base()
-    if name == 'zbase_b4':                # BASELINE config 2 geometry: PrismerZ-BASE, full depth
+    if name in ('zbase_b4', 'zbase_b32'):  # BASELINE config 2 geometry: PrismerZ-BASE, full depth
         return config.prismerz_base()
     if name == 'huge_b1':                 # configs/prismer.json:50-73 + ViT-H/14 (vit.py:211-214): width 1280, 32 + 24 layers, resampler head dim 160
         return config.prismer_huge()
-    if name in ('large_vqa_b1', 'large_vqa_b4'):            # BASELINE config 5 geometry: Prismer-LARGE VQA, 480^2, full depth (24 + 24 layers)
+    if name in ('large_vqa_b1', 'large_vqa_b4', 'large_vqa_b16'):            # BASELINE config 5 geometry: Prismer-LARGE VQA, 480^2, full depth (24 + 24 layers)
         return config.prismer_large()
     raise KeyError(name)
 
@@ -50,13 +50,20 @@ CASES = OrderedDict([
     ('large_vqa_b4', (4, 40, True)),
     # round 5: Prismer-HUGE geometry (the pre-train recipe's largest model): one sample, full depth
     ('huge_b1', (1, 30, False)),
+    # round 6: every benchmarked leg at ITS benchmarked batch (the GEMM dispatch -- tile choice, split-K, tail split -- depends on M = B * S):
+    # config 2 at bs32, config 5 at bs16
+    ('zbase_b32', (32, 30, True)),
+    ('large_vqa_b16', (16, 40, True)),
 ])
 
-LOGIT_STRIDE = {'base_caption': 97, 'base_b8': 97, 'zbase_b4': 97, 'large_vqa_b1': 97, 'base_b32': 97, 'large_vqa_b4': 97, 'huge_b1': 97}    # every 97th vocab column for the big cases
-ENC_STRIDE = {'base_b8': 16, 'zbase_b4': 8, 'large_vqa_b1': 16, 'base_b32': 16, 'large_vqa_b4': 16, 'huge_b1': 16}                             # every n-th feature of the encoder output
-VQA_CASES = ('tiny_vqa', 'large_vqa_b1', 'large_vqa_b4')
+LOGIT_STRIDE = {'base_caption': 97, 'base_b8': 97, 'zbase_b4': 97, 'large_vqa_b1': 97, 'base_b32': 97, 'large_vqa_b4': 97, 'huge_b1': 97, 'zbase_b32': 97, 'large_vqa_b16': 97}    # every 97th vocab column for the big cases
+ENC_STRIDE = {'base_b8': 16, 'zbase_b4': 8, 'large_vqa_b1': 16, 'base_b32': 16, 'large_vqa_b4': 16, 'huge_b1': 16, 'zbase_b32': 16, 'large_vqa_b16': 32}                             # every n-th feature of the encoder output
+VQA_CASES = ('tiny_vqa', 'large_vqa_b1', 'large_vqa_b4', 'large_vqa_b16')
 VQA_HEAD_TQ, VQA_HEAD_TA = 9, 5
-DROP_CASES = ('tiny_caption', 'base_b8')     # <case>_drop.npz: reference outputs in full training mode under the library's dropout masks (round 5)
+DROP_CASES = ('tiny_caption', 'base_b8', 'base_b32')     # (base_b32: round 6, the headline's exact arithmetic) <case>_drop.npz: reference outputs in full training mode under the library's dropout masks (round 5)
+TRAJ_CASES = ('base_b8',)                   # <case>_traj.npz: TRAJ_STEPS AdamW steps of the reference loop (train_caption.py:111-112,126-135) under the library's masks (round 6)
+TRAJ_STEPS, TRAJ_TOTAL = 4, 10              # cosine schedule over TRAJ_TOTAL iterations, init_lr / min_lr / weight_decay of configs/caption.yaml:12-14
+TRAJ_LR, TRAJ_MIN_LR, TRAJ_WD = 5e-5, 0.0, 0.05
 DROP_SEED = 0x5EED0123456789AB              # device dropout seed of step 1; step 2 uses splitmix64 of it (csrc/optim.hip advance_seed_kernel)
 
 

@@ -178,11 +178,80 @@ def run_drop_case(name):
     print(f'{name}_drop: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)  total_train s1={out["s1.total_train"]} s2={out["s2.total_train"]}')
 
 
+def run_traj_case(name):
+    """<case>_traj.npz (round 6): C.TRAJ_STEPS iterations of the REFERENCE training loop (train_caption.py:111-112 torch.optim.AdamW over the
+    requires_grad parameters, :126-135 cosine_lr_schedule -> forward -> zero_grad -> backward -> step) on the reference classes in full training
+    mode (BatchNorm batch statistics, dropout 0.1 / 0.1 under the library's masks: step k draws with splitmix64^(k-1)(C.DROP_SEED), exactly what the
+    Trainer's device seed does), same batch every step.  Keys: `losses` [steps], bn.* after the last step, per trainable tensor dnorm.* = |p_K - p_0|,
+    dproj.* = the N_PROJ projections of p_K - p_0; ac_losses / ac_drel.*: the same loop under PyTorch's own bf16 autocast (the yardstick:
+    AdamW's first steps are ~ lr * sign(g), so round-off level gradient entries flip and the update error is far above the gradient error)."""
+    import math
+    from tests.util import LibraryDropout, splitmix64
+    case = C.Case(name)
+    d = case.dims
+    x, ids, mask, labels, weights = case.inputs()
+    out = {}
+
+    def loop(autocast):
+        esd, dsd = case.weights()
+        enc, dec = RH.build_reference(d, esd, dsd)
+        holder = RH.reference_freeze(enc, dec, 'freeze_vision')
+        enc.train()
+        cur = {}
+        RH.patch_dropout(dec, lambda site, t: cur['drop'](site, t))
+        params = [(n, p) for n, p in holder.named_parameters() if p.requires_grad]
+        p0 = {n: p.detach().clone() for n, p in params}
+        opt = torch.optim.AdamW(params=[p for _, p in params], lr=C.TRAJ_LR, weight_decay=C.TRAJ_WD)      # train_caption.py:111-112
+        seed, losses = C.DROP_SEED, []
+        for it in range(C.TRAJ_STEPS):
+            lr = (C.TRAJ_LR - C.TRAJ_MIN_LR) * 0.5 * (1. + math.cos(math.pi * it / C.TRAJ_TOTAL)) + C.TRAJ_MIN_LR     # utils.py:13-17
+            for gp in opt.param_groups:
+                gp['lr'] = lr
+            cur['drop'] = LibraryDropout(seed, d.hidden_dropout_prob, d.attention_probs_dropout_prob)
+            random.seed(C.INSTANCE_SEED)
+            if autocast:
+                with torch.autocast('cpu', dtype=torch.bfloat16):
+                    e = enc(x)
+                    o = dec(ids, attention_mask=mask, encoder_hidden_states=e.permute(1, 0, 2), labels=labels, return_dict=True)
+                    loss = (o.loss.float() if weights is None else weights * o.loss.float()).mean()
+            else:
+                e = enc(x)
+                o = dec(ids, attention_mask=mask, encoder_hidden_states=e.permute(1, 0, 2), labels=labels, return_dict=True)
+                loss = (o.loss if weights is None else weights * o.loss).mean()
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+            seed = splitmix64(seed)
+            print(f'{name}_traj autocast={autocast} step {it + 1}: lr {lr:.3e} loss {losses[-1]:.6f}', flush=True)
+        delta = {n: (p.detach() - p0[n]) for n, p in params}
+        return losses, delta, enc
+
+    losses, delta, enc = loop(False)
+    out['losses'] = np.array(losses, dtype=np.float64)
+    for k, v in enc.state_dict().items():
+        if 'running_' in k or 'num_batches' in k:
+            out['bn.' + k] = v.numpy().copy()
+    for n, dl in delta.items():
+        out['dnorm.' + n] = np.float64(dl.double().norm().item())
+        out['dproj.' + n] = C.grad_projections(n, dl)
+    out['requires_grad'] = np.array('\n'.join(delta))
+    ac_losses, ac_delta, _ = loop(True)
+    out['ac_losses'] = np.array(ac_losses, dtype=np.float64)
+    for n, dl in ac_delta.items():
+        out['ac_drel.' + n] = np.float64((dl.double() - delta[n].double()).norm().item() / (float(out['dnorm.' + n]) + 1e-30))
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), name + '_traj.npz')
+    np.savez_compressed(path, **out)
+    print(f'{name}_traj: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)  losses={losses}  autocast losses={ac_losses}')
+
+
 if __name__ == '__main__':
     assert RH.available(), 'reference not mounted'
-    torch.set_num_threads(os.cpu_count())
-    for name in (sys.argv[1:] or list(C.CASES) + [n + '+drop' for n in C.DROP_CASES]):
+    torch.set_num_threads(int(os.environ.get('GOLDEN_THREADS', os.cpu_count())))
+    for name in (sys.argv[1:] or list(C.CASES) + [n + '+drop' for n in C.DROP_CASES] + [n + '+traj' for n in C.TRAJ_CASES]):
         if name.endswith('+drop'):
             run_drop_case(name[:-5])
+        elif name.endswith('+traj'):
+            run_traj_case(name[:-5])
         else:
             run_case(name)
