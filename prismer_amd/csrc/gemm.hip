@@ -83,7 +83,7 @@ namespace phg { std::atomic<long long> g_gemm_counts[PH_GEMM_CLS_COUNT]; }
 static std::atomic<int> g_big_mode{-1}, g_big_min_tiles{-1};
 static int big_mode_now() {
   int m = g_big_mode.load(std::memory_order_relaxed);
-  if (m < 0) m = 6;
+  if (m < 0) m = 7;
   return m;
 }
 static int big_min_tiles_now() {
@@ -350,7 +350,7 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
           tot += g.p[i].tiles_m * g.p[i].tiles_n;
         }
         g.tile_start[n] = tot;
-        return big::launch_grouped_wgrad(g, tot, big_mode_now() >= 6 ? 5 : 4, stream);
+        return big::launch_grouped_wgrad(g, tot, big_mode_now() >= 7 ? 7 : 5, stream);
       }
     }
   }
@@ -374,7 +374,7 @@ extern "C" int ph_gemm_grouped_capped_bf16(const ph_gemm_args* args, int n, int 
         blocks += big_xcd_grid(g.p[i].tiles_m, g.p[i].tiles_n);          // (XCD shares, see big_tile: the blocks beyond a share exit)
       }
       g.tile_start[n] = blocks;
-      return big::launch_grouped_conv(g, blocks, big_mode_now() >= 6 ? 5 : 4, stream);
+      return big::launch_grouped_conv(g, blocks, big_mode_now() >= 7 ? 7 : 5, stream);
     }
   }
   if (conv) {               // gathered operand: forward (NN, A = im2col view) or weight gradient (TT, B = im2col view); no prefetch ring
@@ -437,7 +437,8 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
   // ---- big-tile LDS-DMA kernel: forward-shaped (both operands K-contiguous) GEMMs with enough 256x128 tiles for the chip ----
   {
     // g_big_mode (PH_GEMM_BIG / ph_gemm_tuning): 0 = off, 1 = plain main loop (round-2 first version), 5 = ping-pong main loop (the
-    // two waves of a SIMD alternate read and MFMA phases), 6 = ping-pong with the LEAN tail (no surplus DMA, no drain; default since round 4)
+    // two waves of a SIMD alternate read and MFMA phases; retired in round 6, now = 6), 6 = ping-pong with the LEAN tail (no surplus DMA, no drain;
+    // round 4), 7 = 6 with the DMA requests spread over the M phase (default since round 6)
     const int big_mode = big_mode_now(), big_min_tiles = big_min_tiles_now();
     const int64_t tb = (int64_t)ceil_div(a->M, big::BM) * ceil_div(a->N, big::BN);
     // block rounds of either kernel (constants from the per-shape fits, us): a 256x128 block alone on its CU, a pair of co-resident
@@ -470,7 +471,7 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
       p.tiles_m = ceil_div(a->M, big::BM); p.tiles_n = ceil_div(a->N, big::BN);
       p.k_tiles_per_split = a->K / BK;
       p.ws = nullptr; p.ldws = 0;
-      return big::launch_single(p, big_mode >= 6 ? 5 : 4, true, true, stream);
+      return big::launch_single(p, big_mode >= 7 ? 7 : 5, true, true, stream);
     }
   }
 

@@ -201,8 +201,11 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
     constexpr int idx = decltype(idx_c)::value;
     char* sa = smem + stage * STAGE;
     char* sb = sa + A_BYTES;
-    const int koff = (VARIANT & 128) ? 0 : kt * BK;
-    if constexpr (idx < A_INSTR)
+    const int koff = kt * BK;
+    if constexpr (CONV == 1) {          // sources prepared by conv_prep(kt) in the R phase
+      if constexpr (idx < A_INSTR) __builtin_amdgcn_global_load_lds((gptr_t*)a_nxt[idx], (lptr_t*)(sa + (idx * 8 + wave) * 1024), 16, 0, 0);
+      else __builtin_amdgcn_global_load_lds((gptr_t*)b_nxt[idx - A_INSTR], (lptr_t*)(sb + ((idx - A_INSTR) * 8 + wave) * 1024), 16, 0, 0);
+    } else if constexpr (idx < A_INSTR)
       __builtin_amdgcn_global_load_lds((gptr_t*)(a_src[idx] + (TA ? (size_t)koff * p.lda : (size_t)koff)), (lptr_t*)(sa + (idx * 8 + wave) * 1024), 16, 0, 0);
     else
       __builtin_amdgcn_global_load_lds((gptr_t*)(b_src[idx - A_INSTR] + (TB ? (size_t)koff * p.ldb : (size_t)koff)), (lptr_t*)(sb + ((idx - A_INSTR) * 8 + wave) * 1024), 16, 0, 0);
@@ -272,72 +275,6 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
     constexpr bool DIAG_NOWAIT = (VARIANT & 64) != 0;          // diagnostic builds (tools/big_probe.py modes 9-11): WRONG results by design
     static_assert(!RDMA || (LEAN && CONV == 0), "R-phase requests: LEAN tail, dense operands");
     const int grp = wave >> 2;
-    if constexpr (RDMA) {
-      // ---- R-phase requests (round 6, VARIANT & 32).  Both groups request their share of tile t+2 in their R(t) phase, BEHIND the 16 fragment
-      // reads and in front of the phase's wait -- while the partner wave of the SIMD runs its 16 MFMAs -- so the M phase is bare MFMAs:
-      //     phase 2t   : group 0 R(t) + DMA(t+2)      | group 1 M(t-1)
-      //     phase 2t+1 : group 0 M(t)                 | group 1 R(t) + DMA(t+2)
-      //   WAR  tile t+2 lands in stage (t+2) % 3 = the stage of tile t-1, last read in phase 2t-1 (group 1's R(t-1), ended by lgkmcnt(0) + barrier).
-      //   RAW  tile t+1 is first read in phase 2t+2; before the barrier that ends phase 2t+1 group 0 (end of M(t): tiles t+1, t+2 outstanding)
-      //        and group 1 (end of R(t): tile t+1 and the just-requested t+2) wait vmcnt(6) -- vmcnt(0) when tile t+2 does not exist.
-      issue(0, 0);
-      issue(min(1, nk - 1), 1);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      PH_TL(1);
-      __builtin_amdgcn_s_barrier();
-      PH_TL(2);
-      if (grp) __builtin_amdgcn_s_barrier();
-      int st = 0;
-      auto ktile_r = [&](const int t, auto iss_c, auto last_c) {
-        constexpr bool ISS = decltype(iss_c)::value, LAST = decltype(last_c)::value;
-        const char* la = smem + st * STAGE;
-        const char* lb = la + A_BYTES;
-        bf16x8 fx[BK / 16][2], fw[BK / 16][2];
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i) fx[kk][i] = TA ? frag_ks_dma<512>(la, wm * 64 + i * 32, kk, lane) : frag_kc(la, wm * 64 + i * 32, kk, lane);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) fw[kk][j] = TB ? frag_ks_dma<256>(lb, wn * 64 + j * 32, kk, lane) : frag_kc(lb, wn * 64 + j * 32, kk, lane);
-        }
-        if constexpr (ISS) {
-          __builtin_amdgcn_sched_barrier(0);
-          int sn = st + 2; sn = sn >= 3 ? sn - 3 : sn;
-          issue(t + 2, sn);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        if (grp) {
-          if constexpr (ISS) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        } else {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk)
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[kk][j], fx[kk][i], acc[i][j], 0, 0, 0);
-        if (!grp) {
-          if constexpr (ISS) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (LAST) { if (!grp) __builtin_amdgcn_s_barrier(); }
-        else __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        st = st + 1 == 3 ? 0 : st + 1;
-      };
-      using T_ = std::true_type; using F_ = std::false_type;
-      int t = 0;
-      for (; t + 2 < nk; ++t) ktile_r(t, T_{}, F_{});
-      ktile_r(t, F_{}, F_{}); ++t;           // (nk >= 2 is a dispatch condition of this kernel: K >= 2 * BK)
-      ktile_r(t, F_{}, T_{});
-      PH_TL(3);
-    } else {
     conv_prep(0);
     issue(0, 0);
     conv_prep(min(1, nk - 1));
@@ -384,8 +321,7 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
         if (ISS1 || !grp) conv_prep(min(t + 2 + grp, nk - 1));
       }
       if (grp) {
-        if constexpr (DIAG_NOWAIT && NEWER) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        else if constexpr (NEWER) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        if constexpr (NEWER) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -396,7 +332,7 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
       // M(t)
       int sn = st + 2 + grp; sn = sn >= 3 ? sn - 3 : sn;
       if (VARIANT & 1) __builtin_amdgcn_s_setprio(1);
-      if constexpr (SPREAD && CONV == 0) {
+      if constexpr (SPREAD) {
         // MFMA, MFMA, request, MFMA, MFMA, request, ... : requests behind MFMAs 1, 3, 5, 7, 9, 11; the last four MFMAs run bare in front of the wait
         const bool mine = ISS0 && (ISS1 || !grp);
         const int kt_n = min(t + 2 + grp, nk - 1);
@@ -421,8 +357,7 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
       }
       if (VARIANT & 1) __builtin_amdgcn_s_setprio(0);
       if (!grp) {
-        if constexpr (DIAG_NOWAIT && NEWER) {}
-        else if constexpr (NEWER) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if constexpr (NEWER) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -443,7 +378,6 @@ __device__ __forceinline__ void big_tile(const GemmParams& p, const int block_id
     }
     PH_TL(3);
     if (!LEAN && !grp) __builtin_amdgcn_s_barrier();           // group 0 idles through the last phase (group 1's M(nk-1))
-    }
   }
   if constexpr ((VARIANT & 8) == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // drain the surplus DMA before the ring is reused as the C tile
@@ -549,22 +483,19 @@ int launch_conv_t(const GroupParams& g, int blocks, hipStream_t s) {
   return PH_OK;
 }
 int launch_grouped_conv(const GroupParams& g, int blocks, int variant, hipStream_t s) {
-  return variant == 5 ? launch_conv_t<12>(g, blocks, s) : launch_conv_t<4>(g, blocks, s);
+  return variant == 7 ? launch_conv_t<28>(g, blocks, s) : launch_conv_t<12>(g, blocks, s);
 }
 }  // namespace big
 
 namespace big {
+// variant: 0 = plain loop, 5 = ping-pong + LEAN tail (round 4), 7 = + SPREAD requests (round 6, default)
 int launch_single(const GemmParams& p, int variant, bool ta, bool tb, hipStream_t s) {
-  if (ta) return variant == 5 ? launch<12, true, true>(p, s) : launch<4, true, true>(p, s);      // weight-gradient layout: ping-pong only
-  // variant 5 (ping-pong + s_setprio, measured negative in round 2) gave its slot to the LEAN tail (VARIANT 12) in round 4
-  if (tb) return variant == 0 ? launch<0, false, true>(p, s) : variant == 5 ? launch<12, false, true>(p, s) : variant == 7 ? launch<28, false, true>(p, s)
-                 : variant == 8 ? launch<44, false, true>(p, s) : launch<4, false, true>(p, s);
-  return variant == 0 ? launch<0, false, false>(p, s) : variant == 5 ? launch<12, false, false>(p, s) : variant == 7 ? launch<28, false, false>(p, s)
-         : variant == 8 ? launch<44, false, false>(p, s) : variant == 9 ? launch<28 + 64, false, false>(p, s) : variant == 10 ? launch<28 + 128, false, false>(p, s)
-         : variant == 11 ? launch<28 + 192, false, false>(p, s) : launch<4, false, false>(p, s);
+  if (ta) return variant == 7 ? launch<28, true, true>(p, s) : launch<12, true, true>(p, s);      // weight-gradient layout: ping-pong only
+  if (tb) return variant == 0 ? launch<0, false, true>(p, s) : variant == 7 ? launch<28, false, true>(p, s) : launch<12, false, true>(p, s);
+  return variant == 0 ? launch<0, false, false>(p, s) : variant == 7 ? launch<28, false, false>(p, s) : launch<12, false, false>(p, s);
 }
 int launch_grouped_wgrad(const GroupParams& g, int total, int variant, hipStream_t s) {
-  return variant == 5 ? launch_grouped<12, true, true>(g, total, s) : launch_grouped<4, true, true>(g, total, s);
+  return variant == 7 ? launch_grouped<28, true, true>(g, total, s) : launch_grouped<12, true, true>(g, total, s);
 }
 }  // namespace big
 #ifdef PH_TIMELINE

@@ -156,11 +156,11 @@ def test_gemm_grouped_capped_background_launch(ops):
 
 
 @pytest.mark.parametrize('trans_b', [False, True])
-@pytest.mark.parametrize('mode', [1, 5, 6])
+@pytest.mark.parametrize('mode', [1, 6, 7])
 @pytest.mark.parametrize('M,N,K,act', [(1000, 776, 640, 1), (2048, 256, 128, 0), (515, 1536, 3072, 3)])
 def test_gemm_big_tile_lds_dma_kernel(ops, M, N, K, act, mode, trans_b):
-    """the 256x128 LDS-DMA kernel (global_load_lds into a 3-stage ring, counted vmcnt, raw barriers; mode 1 = plain main loop, 5 =
-    ping-pong phases of the two waves of a SIMD, 6 = + s_setprio), forced for shapes it would not normally take: ragged M / N
+    """the 256x128 LDS-DMA kernel (global_load_lds into a 3-stage ring, counted vmcnt, raw barriers; mode 1 = plain main loop, 6 =
+    ping-pong phases of the two waves of a SIMD with the LEAN tail, 7 = + the DMA requests spread over the M phase, the default), forced for shapes it would not normally take: ragged M / N
     tails, short and long k loops, the full fused epilogue, B given as [N,K] and as [K,N] -- against fp32 torch and against the
     128x128 register-staged kernel on the same inputs; repeated, because a mis-ordered DMA ring shows up as a rare wrong tile."""
     from prismer_amd import _lib

@@ -168,6 +168,10 @@ def test_model_constants_match_the_kernel_source():
     assert body.count(f'"s_waitcnt vmcnt({2 * DMA_PER_TILE})"') == 1              # group 1 prologue (three tiles issued)
     assert 'if constexpr (ISS0 && ISS1) issue(min(t + 2 + grp, nk - 1), sn);' in body and 'int sn = st + 2 + grp' in body
     assert 'else if constexpr (ISS0) { if (!grp) issue(min(t + 2, nk - 1), sn); }' in body
+    # SPREAD (round 6): the same requests of the same tile into the same stage, one piece behind every second MFMA of the M phase
+    assert 'const bool mine = ISS0 && (ISS1 || !grp);' in body and 'const int kt_n = min(t + 2 + grp, nk - 1);' in body
+    assert 'if (mine) issue_piece(kt_n, sn, std::integral_constant<int, m / 2>{});' in body
+    assert 'if constexpr (ISS0 && (m & 1) && m / 2 < A_INSTR + B_INSTR)' in body
     # the peeled LEAN tail: steady state while tile t+3 exists, then nk-3 (group 0 only requests), nk-2 and nk-1 (nobody requests, vmcnt(0))
     assert 'for (; t + 3 < nk; ++t) ktile(t, T_{}, T_{}, T_{}, F_{});' in body
     assert 'if (nk >= 3) { ktile(t, T_{}, T_{}, F_{}, F_{}); ++t; }' in body
