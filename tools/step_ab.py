@@ -2,7 +2,7 @@
 arms timed interleaved (A, B, A, B, ...) so that box / clock drift cannot pass for a change.
 
     python tools/step_ab.py gemm6 gemm7              # arms: ph_gemm_tuning mode during warm-up + capture (dispatch is frozen into the graphs)
-    python tools/step_ab.py base adamw_overlap       # arms defined in ARMS below
+    python tools/step_ab.py base base                # arms defined in ARMS below (trainer=dict(...) passes Trainer keyword arguments)
 
 Prints ms per step per arm (best and median of the rounds) and the loss after the last step (all arms start from the same weights)."""
 import os
@@ -18,7 +18,6 @@ ARMS = {
     'base': dict(),
     'gemm6': dict(gemm_mode=6),
     'gemm7': dict(gemm_mode=7),
-    'adamw_overlap': dict(trainer=dict(overlap_adamw=True)),
 }
 
 
