@@ -199,10 +199,13 @@ typedef struct {
   float* delta;                   /* workspace fp32 [B*H*Sq] */
 } ph_attn_bwd_args;
 int ph_attention_bwd(const ph_attn_bwd_args* args, hipStream_t stream);
-/* Kernel family selection (revision 103).  Launches with head dim 64, Sq <= 64 and Sk <= 320 -- the decoder's self- and cross-attention
+/* Kernel family selection (revision 103).  Launches with head dim 64, Sq <= 32 and Sk <= 320 -- the decoder's self- and cross-attention
  * (roberta.py:95-126 at T = 30 text tokens, 260 image tokens) -- run on the small-query kernels: one block per (batch, head), the keys split
- * over the waves, forward merged like split-K decoding, dQ + dK + dV in ONE launch (args.delta is not touched).  small_query_kernels = 0
- * forces the streaming kernels for every launch (A/B, tests), 1 restores the default, < 0 only queries.  Returns the previous setting. */
+ * over the waves, forward merged like split-K decoding, dQ + dK + dV in ONE launch (args.delta is not touched).  Plain launches (no causal cut,
+ * key mask or dropout) with head dim 64 and at most 272 queries and keys -- the ViT blocks at 224^2 (vit.py:52-53) -- run on the head-resident
+ * kernels (round 6): one block per (batch, head) with K / V (Q / dO) of the whole head staged once, dQ in one pass with the P / dP rows in
+ * registers.  small_query_kernels = 0 forces the streaming kernels for every launch (A/B, tests), 1 restores the default, 2 = default without
+ * the head-resident kernels, < 0 only queries.  Returns the previous setting. */
 int ph_attention_tuning(int small_query_kernels);
 
 /* ------------------------------------------------------------------------------------------------

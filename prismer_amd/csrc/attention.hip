@@ -15,7 +15,11 @@
 // Block = 4 waves; forward / dQ: 64 queries per block (16 per wave), K/V streamed in 64-key tiles through a
 // double-buffered LDS image; dK/dV: 64 keys per block, Q/dO streamed.
 #include <float.h>
+#include <algorithm>
+#include <mutex>
+#include <unordered_map>
 #include <type_traits>
+#include <utility>
 #include <stdlib.h>
 
 #include "common.h"
@@ -23,6 +27,11 @@
 namespace {
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+template <int... Is, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
 
 #ifndef PH_ATTN_PAD
 #define PH_ATTN_PAD 8
@@ -845,6 +854,297 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DH <= 64 ? 
 }
 
 // =====================================================================================================
+// Head-resident attention BACKWARD (round 6): the ViT blocks at 224^2 (vit.py:52-53; S = 260 with experts, 196 without), head dim 64, PLAIN.
+// =====================================================================================================
+// The streaming kernels above cut a head into 64-query (64-key) blocks: five blocks per head each stream ALL keys (queries) of the head through a
+// double-buffered LDS image, one 64-row tile per memory latency, and the dQ kernel sweeps them twice.  A head at these lengths is SMALL: K and V
+// (or Q and dO) of all <= 272 tokens are 2 x 36.9 KB as bf16.  So ONE block owns a (batch, head) pair -- 384 blocks at bs32, all resident at
+// once at two blocks per CU -- stages both operands ONCE with every request in flight together (one memory latency per block, 25 instead of
+// 127 MB through the L2s per launch), and each wave walks 16-row sub-tiles of the head (sub-tile s -> wave s % NW) entirely out of LDS:
+//   dQ      : ONE pass instead of two sweeps: P and dP rows of the 16 queries in registers (2 x 68 VGPRs at 17 key tiles), delta from the same
+//             fp32 P / dP as before (the consistency argument in attn_bwd_dq_kernel is untouched), dS -> dQ^T += K^T dS^T from the registers:
+//             3 matrix products instead of 5, the exponentials once.  44.6 -> 26.9 us per launch at bs32 (rocprofv3, same box).
+//   dK / dV : 16 keys per wave and sub-tile, Q / dO / -lse log2(e) / delta of ALL queries resident; rows beyond Sq carry lse = +inf, i.e. P = 0
+//             without a bounds select; 8 waves per block (four per SIMD at 118 VGPRs).  36.0 -> 31.8 us.
+// LDS image: 128-B rows (no padding) whose 16-B chunk index is XOR-ed with (row & 7): conflict-free for the ds_read_b128 row fragments (the
+// 16 lanes of an LDS cycle cover 16 distinct (row parity, chunk) slots) and for the ds_read_b64_tr_b16 transposing reads (8 rows x 2 chunks per
+// 32-lane cycle) -- the padded 144-B rows of the streaming kernels are 2-way conflicted on the row fragments and would not leave room for two
+// blocks per CU (2 x 41.5 KB).  `split` > 1 cuts the sub-tiles of a head over several blocks when there are too few heads to fill the chip.
+// Measured and NOT kept (profiles/r6_ab_attention_resident.txt): the same structure for the FORWARD (all score tiles of 16 queries in
+// registers, exact two-pass softmax: 25.5 vs 24.4 us), explicit one-tile-ahead fragment double buffers in all three kernels (+-0), V row
+// fragments straight from global memory (17 dependent latencies: 43.5 us), heads cut over 2 / 3 / 5 blocks at bs32 (+2...+4 us).  One sub-tile
+// costs a wave ~6 us of issue time whatever the occupancy: these kernels are bound by the per-wave VALU + LDS + MFMA instruction stream.
+constexpr int RES_RS = 64;                                    // elements per LDS row (128 B)
+// Per-lane element offsets inside an image, computed ONCE per kernel: with row0 a multiple of 16 (32 for the transposing reads) the swizzle term
+// (row & 7) depends on the lane only, so a fragment address is `image + row0 * 64 + offset[ks or d]` -- an immediate on the ds_read when row0 is
+// a compile-time constant (the fully unrolled key loops), one SALU add otherwise.
+struct ResOff { int rows[2], tr[4]; };
+__device__ __forceinline__ ResOff res_offsets(int lane) {
+  ResOff o;
+  const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) o.rows[ks] = c * RES_RS + (((ks * 4 + g) ^ (c & 7)) << 3);
+  const int r = 4 * g + (c >> 2);
+#pragma unroll
+  for (int d = 0; d < 4; ++d) o.tr[d] = r * RES_RS + ((((2 * d + ((c & 3) >> 1)) ^ (r & 7)) << 3) | ((c & 1) << 2));
+  return o;
+}
+// row-major fragment: lane gets X[row0 + (l&15)][ks*32 + (l>>4)*8 .. +8]
+__device__ __forceinline__ bf16x8 rfrag_rows(const bf16* lds, int row0, int ks, const ResOff& o) {
+  return *reinterpret_cast<const bf16x8*>(lds + row0 * RES_RS + o.rows[ks]);
+}
+// transposed fragment, same element order as frag_tr: lane (c, g) gets X[kappa(g, j)][d*16 + c]
+__device__ __forceinline__ bf16x8 rfrag_tr(const bf16* lds, int kbase, int d, const ResOff& o) {
+  const bf16* p = lds + kbase * RES_RS + o.tr[d];
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 16 * RES_RS));          // (row + 16) & 7 == row & 7
+  bf16x8 v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return v;
+}
+// two images of `rows` rows (a multiple of 32) x 64 columns each, all requests issued before the first LDS store; rows beyond the tensor read zeros
+template <int NCH, int NTHR>
+__device__ __forceinline__ void res_stage2(bf16* la, bf16* lb, rsrc_t ra, rsrc_t rb, int64_t tsa, int64_t tsb, int rows) {
+  u32x4 xa[NCH], xb[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int id = threadIdx.x + NTHR * i, r = id >> 3, cc = id & 7;
+    xa[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, (uint32_t)((r * tsa + cc * 8) * 2), 0, 0));
+    xb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (uint32_t)((r * tsb + cc * 8) * 2), 0, 0));
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int id = threadIdx.x + NTHR * i, r = id >> 3, cc = id & 7;
+    if (r < rows) {
+      *reinterpret_cast<u32x4*>(la + r * RES_RS + ((cc ^ (r & 7)) << 3)) = xa[i];
+      *reinterpret_cast<u32x4*>(lb + r * RES_RS + ((cc ^ (r & 7)) << 3)) = xb[i];
+    }
+  }
+}
+// sub-tiles [s_lo, s_hi) of the block: block x of `split` takes an even share of the nsub 16-row sub-tiles of the head
+__device__ __forceinline__ void res_share(int nsub, int split, int x, int& s_lo, int& s_hi) {
+  const int q = nsub / split, r = nsub % split;
+  s_lo = x * q + min(x, r);
+  s_hi = s_lo + q + (x < r ? 1 : 0);
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq_res_kernel(ph_attn_bwd_args a, int split) {
+  constexpr int DH = 64, KS = 2, DT = 4, ROWS = (NT + 1) / 2 * 32, NCH = ROWS * 8 / 256;
+  const ph_attn_fwd_args& f = a.f;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16* kl = reinterpret_cast<bf16*>(smem_raw);
+  bf16* vl = kl + ROWS * RES_RS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const ResOff ro = res_offsets(lane);
+  const BlockXY bxy = block_xy(split, f.B * f.H);
+  const int b = bxy.y / f.H, h = bxy.y % f.H;
+  const bf16* Q = reinterpret_cast<const bf16*>(f.q) + b * f.q_bs + (int64_t)h * DH;
+  const bf16* K = reinterpret_cast<const bf16*>(f.k) + b * f.k_bs + (int64_t)h * DH;
+  const bf16* V = reinterpret_cast<const bf16*>(f.v) + b * f.v_bs + (int64_t)h * DH;
+  const bf16* dO = reinterpret_cast<const bf16*>(a.d_o) + b * a.do_bs + (int64_t)h * DH;
+  const float* lse_base = f.lse + (int64_t)(b * f.H + h) * f.Sq;
+  res_stage2<NCH, 256>(kl, vl, tile_rsrc(K, f.k_ts, f.Sk, DH), tile_rsrc(V, f.v_ts, f.Sk, DH), f.k_ts, f.v_ts, ROWS);
+  int s_lo, s_hi;
+  res_share((f.Sq + 15) / 16, split, bxy.x, s_lo, s_hi);
+  int sub = s_lo + wave;
+  bf16x8 qf[KS], dof[KS], qn[KS], don[KS];
+  float lse = 0.f, lsen = 0.f;
+  auto qload = [&](int sb, bf16x8 (&dq_)[KS], bf16x8 (&dd_)[KS], float& l_) {
+    const int qr = min(sb * 16 + c, f.Sq - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      dq_[ks] = *reinterpret_cast<const bf16x8*>(Q + (int64_t)qr * f.q_ts + ks * 32 + g * 8);
+      dd_[ks] = *reinterpret_cast<const bf16x8*>(dO + (int64_t)qr * a.do_ts + ks * 32 + g * 8);
+    }
+    l_ = lse_base[qr];
+  };
+  if (sub < s_hi) qload(sub, qf, dof, lse);
+  __syncthreads();
+  const float c2 = f.scale * LOG2E;
+  for (; sub < s_hi; sub += 4) {
+    int sk = f.Sk;
+    asm volatile("" : "+s"(sk));                      // opaque per iteration: the tail compares are NOT hoisted out of the loop (68 mask pairs -> SGPR spills)
+    f32x4 P[NT], DP[NT];
+    f32x2 part = {0.f, 0.f};
+    const float l2 = lse * LOG2E;
+    const f32x2 c2v = {c2, c2}, nl = {-l2, -l2};
+    bf16x8 kfr[2][KS], vfr[2][KS];                       // one tile ahead (explicit: the fences below keep the scheduler from hoisting ALL tiles)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { kfr[0][ks] = rfrag_rows(kl, 0, ks, ro); vfr[0][ks] = rfrag_rows(vl, 0, ks, ro); }
+    static_for(std::make_integer_sequence<int, NT>{}, [&](auto nt_c) {
+      constexpr int nt = decltype(nt_c)::value;
+      if constexpr (nt + 1 < NT) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { kfr[(nt + 1) & 1][ks] = rfrag_rows(kl, (nt + 1) * 16, ks, ro); vfr[(nt + 1) & 1][ks] = rfrag_rows(vl, (nt + 1) * 16, ks, ro); }
+      }
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[nt & 1][ks], qf[ks], acc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[nt & 1][ks], dof[ks], dp, 0, 0, 0);
+      }
+      const bool tail = nt * 16 + 16 > sk;
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        f32x2 x = {acc[r], acc[r + 1]};
+        x = __builtin_elementwise_fma(x, c2v, nl);
+        f32x2 p2 = {fast_exp2(x[0]), fast_exp2(x[1])};
+        if (tail) {
+          asm volatile("");                            // (a real branch: if-converted, the selects ran on all NT tiles -- 207 VALU instructions per sub-tile)
+          p2[0] = (nt * 16 + g * 4 + r < sk) ? p2[0] : 0.f;
+          p2[1] = (nt * 16 + g * 4 + r + 1 < sk) ? p2[1] : 0.f;
+        }
+        const f32x2 dd = {dp[r], dp[r + 1]};
+        part = __builtin_elementwise_fma(p2, dd, part);
+        P[nt][r] = p2[0]; P[nt][r + 1] = p2[1];
+      }
+      DP[nt] = dp;
+      asm volatile("" ::: "memory");                                   // (keeps the scheduler from hoisting all NT tiles' fragment reads: spills)
+    });
+    if (sub + 4 < s_hi) qload(sub + 4, qn, don, lsen);          // (behind the P / dP pass: 17 registers fewer live across it)
+    const float delta = xor_sum(part[0] + part[1]);
+    const int qi = sub * 16 + c;
+    if (g == 0 && qi < f.Sq) a.delta[(int64_t)(b * f.H + h) * f.Sq + qi] = delta;      // consumed by the dK/dV kernel (launched after this one)
+    f32x4 dq[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ktr[2][DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) ktr[0][d] = rfrag_tr(kl, 0, d, ro);
+    static_for(std::make_integer_sequence<int, (NT + 1) / 2>{}, [&](auto k2_c) {
+      constexpr int k2 = decltype(k2_c)::value;
+      if constexpr (k2 + 1 < (NT + 1) / 2) {
+#pragma unroll
+        for (int d = 0; d < DT; ++d) ktr[(k2 + 1) & 1][d] = rfrag_tr(kl, (k2 + 1) * 32, d, ro);
+      }
+      if (k2 * 32 < sk) {
+        f32x4 ds0, ds1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ds0[r] = P[2 * k2][r] * (DP[2 * k2][r] - delta);
+          if constexpr (2 * k2 + 1 < NT) ds1[r] = P[2 * k2 + 1][r] * (DP[2 * k2 + 1][r] - delta);
+          else ds1[r] = 0.f;
+        }
+        const bf16x8 dsf = pack2(ds0, ds1);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktr[k2 & 1][d], dsf, dq[d], 0, 0, 0);
+      }
+      asm volatile("" ::: "memory");
+    });
+    if (qi < f.Sq) {
+      bf16* dQ = reinterpret_cast<bf16*>(a.dq) + b * a.dq_bs + (int64_t)qi * a.dq_ts + (int64_t)h * DH;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        bf16x4 tt = {f2bf(dq[d][0] * f.scale), f2bf(dq[d][1] * f.scale), f2bf(dq[d][2] * f.scale), f2bf(dq[d][3] * f.scale)};
+        *reinterpret_cast<bf16x4*>(dQ + d * 16 + g * 4) = tt;
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { qf[ks] = qn[ks]; dof[ks] = don[ks]; }
+    lse = lsen;
+  }
+}
+
+// dK / dV: Q, dO and the per-query statistics of the whole head resident (rows = Sq rounded up to 32); a wave walks 16-key sub-tiles
+template <int R32, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2, NW / 2))) void attn_bwd_dkv_res_kernel(ph_attn_bwd_args a, int split) {
+  constexpr int DH = 64, KS = 2, DT = 4, ROWS = R32 * 32, NCH = (ROWS * 8 + NW * 64 - 1) / (NW * 64);
+  const ph_attn_fwd_args& f = a.f;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16* ql = reinterpret_cast<bf16*>(smem_raw);
+  bf16* dl = ql + ROWS * RES_RS;
+  float* stl = reinterpret_cast<float*>(dl + ROWS * RES_RS);        // [ROWS] -lse * log2(e) (rows beyond Sq: -inf -> P = 0), then [ROWS] delta
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const ResOff ro = res_offsets(lane);
+  const BlockXY bxy = block_xy(split, f.B * f.H);
+  const int b = bxy.y / f.H, h = bxy.y % f.H;
+  const bf16* Q = reinterpret_cast<const bf16*>(f.q) + b * f.q_bs + (int64_t)h * DH;
+  const bf16* K = reinterpret_cast<const bf16*>(f.k) + b * f.k_bs + (int64_t)h * DH;
+  const bf16* V = reinterpret_cast<const bf16*>(f.v) + b * f.v_bs + (int64_t)h * DH;
+  const bf16* dO = reinterpret_cast<const bf16*>(a.d_o) + b * a.do_bs + (int64_t)h * DH;
+  const float* lse_base = f.lse + (int64_t)(b * f.H + h) * f.Sq;
+  const float* delta_base = a.delta + (int64_t)(b * f.H + h) * f.Sq;
+  for (int r = threadIdx.x; r < ROWS; r += NW * 64) {
+    stl[r] = r < f.Sq ? lse_base[r] * -LOG2E : -INFINITY;
+    stl[ROWS + r] = r < f.Sq ? delta_base[r] : 0.f;
+  }
+  res_stage2<NCH, NW * 64>(ql, dl, tile_rsrc(Q, f.q_ts, f.Sq, DH), tile_rsrc(dO, a.do_ts, f.Sq, DH), f.q_ts, a.do_ts, ROWS);
+  int s_lo, s_hi;
+  res_share((f.Sk + 15) / 16, split, bxy.x, s_lo, s_hi);
+  int sub = s_lo + wave;
+  bf16x8 kf[KS], vf[KS], kn[KS], vn[KS];
+  auto kload = [&](int sb, bf16x8 (&k_)[KS], bf16x8 (&v_)[KS]) {
+    const int kr = min(sb * 16 + c, f.Sk - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      k_[ks] = *reinterpret_cast<const bf16x8*>(K + (int64_t)kr * f.k_ts + ks * 32 + g * 8);
+      v_[ks] = *reinterpret_cast<const bf16x8*>(V + (int64_t)kr * f.v_ts + ks * 32 + g * 8);
+    }
+  };
+  if (sub < s_hi) kload(sub, kf, vf);
+  __syncthreads();
+  const float c2 = f.scale * LOG2E;
+  const f32x2 c2v = {c2, c2};
+  const int nq32 = (f.Sq + 31) / 32;
+  for (; sub < s_hi; sub += NW) {
+    if (sub + NW < s_hi) kload(sub + NW, kn, vn);
+    f32x4 dk[DT], dv[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) { dk[d] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int k2 = 0; k2 < nq32; ++k2) {
+      f32x4 pd[2], ds[2];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int q0 = k2 * 32 + hf * 16;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rfrag_rows(ql, q0, ks, ro), kf[ks], acc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rfrag_rows(dl, q0, ks, ro), vf[ks], dp, 0, 0, 0);
+        }
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(stl + q0 + g * 4);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(stl + ROWS + q0 + g * 4);
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const f32x2 nl = {l4[r], l4[r + 1]}, dl2 = {d4[r], d4[r + 1]};
+          f32x2 x = {acc[r], acc[r + 1]};
+          x = __builtin_elementwise_fma(x, c2v, nl);
+          const f32x2 p2 = {fast_exp2(x[0]), fast_exp2(x[1])};
+          f32x2 dd = {dp[r], dp[r + 1]};
+          dd = p2 * (dd - dl2);
+          pd[hf][r] = p2[0]; pd[hf][r + 1] = p2[1];
+          ds[hf][r] = dd[0]; ds[hf][r + 1] = dd[1];
+        }
+      }
+      const bf16x8 pf = pack2(pd[0], pd[1]), dsf = pack2(ds[0], ds[1]);
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rfrag_tr(dl, k2 * 32, d, ro), pf, dv[d], 0, 0, 0);
+        dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rfrag_tr(ql, k2 * 32, d, ro), dsf, dk[d], 0, 0, 0);
+      }
+    }
+    const int ki = sub * 16 + c;
+    if (ki < f.Sk) {
+      bf16* dK = reinterpret_cast<bf16*>(a.dk) + b * a.dk_bs + (int64_t)ki * a.dk_ts + (int64_t)h * DH;
+      bf16* dV = reinterpret_cast<bf16*>(a.dv) + b * a.dv_bs + (int64_t)ki * a.dv_ts + (int64_t)h * DH;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        bf16x4 tk = {f2bf(dk[d][0] * f.scale), f2bf(dk[d][1] * f.scale), f2bf(dk[d][2] * f.scale), f2bf(dk[d][3] * f.scale)};
+        bf16x4 tv = {f2bf(dv[d][0]), f2bf(dv[d][1]), f2bf(dv[d][2]), f2bf(dv[d][3])};
+        *reinterpret_cast<bf16x4*>(dK + d * 16 + g * 4) = tk;
+        *reinterpret_cast<bf16x4*>(dV + d * 16 + g * 4) = tv;
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { kf[ks] = kn[ks]; vf[ks] = vn[ks]; }
+  }
+}
+
+// =====================================================================================================
 // Small-query attention (round 5): the DECODER's launches.  Sq = T <= 32 text tokens per (batch, head) against Sk = T keys (causal cut, key
 // mask, probability dropout: roberta.py:101-126 self-attention) or against the Sk = 260 image tokens (cross-attention), head dim 64.  With the
 // streaming kernels above such a launch is a latency chain: 64-query blocks of which two waves hold nothing, the 64-key tiles of a head
@@ -1337,7 +1637,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(ph_attn_bwd_args a)
   }
 }
 
-// eligibility of the small-query kernels: head dim 64, all queries of a (batch, head) pair in QT <= 4 sub-tiles, K / V image within the LDS budget
+// eligibility of the small-query kernels: head dim 64, all queries of a (batch, head) pair in QT = 2 sub-tiles (Sq <= 32), K / V image within the LDS budget
 int attn_small_qt(const ph_attn_fwd_args* f) {
   if (f->dh != 64 || f->Sk > 32 * SM_MAX_UNITS) return 0;
   return f->Sq <= 32 ? 2 : 0;
@@ -1348,16 +1648,37 @@ bool attn_plain_ok(const ph_attn_fwd_args* f) {
   return !f->causal && !f->key_mask && !(f->drop_p > 0.f) && f->scale > 0.f;     // (the row max is taken on raw scores: needs scale > 0)
 }
 
+// head-resident kernels (round 6): plain launches with head dim 64 and at most 272 queries and keys.  Returns the number of blocks per head
+// (0 = not eligible): one when the heads alone fill the chip at two blocks per CU, else the 16-row sub-tiles of a head are cut over up to
+// ceil(sub-tiles / 4) blocks (at that point a block is what a 64-row block of the streaming kernels was, minus the tile-by-tile staging).
+int g_attn_small = 3;      // bit 0: small-query kernels (decoder), bit 1: head-resident kernels (ViT at 224^2); ph_attention_tuning(0) forces the streaming kernels (A/B, tests)
+int res_split(const ph_attn_fwd_args* f) {
+  if (!(g_attn_small & 2) || !attn_plain_ok(f) || f->dh != 64 || f->Sq > 272 || f->Sk > 272 || f->Sq <= 32) return 0;
+  const int heads = f->B * f->H, nsub = (std::max(f->Sq, f->Sk) + 15) / 16;
+  if (heads >= 256) return 1;
+  return std::max(1, std::min((nsub + 3) / 4, (511 + heads) / heads));
+}
+
 // 32 queries (keys, in the dK/dV kernel) per wave for long enough sequences
 int attn_qt2_ok() { return 1; }          // 1 = by sequence length (0 = never and 2 = wherever eligible were the round-3 A/B arms)
 
 template <typename KernelT>
 int set_smem(KernelT k, int bytes) {
-  if (bytes > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  // the attribute is raised only when a launch needs more than any earlier launch of THAT kernel did (the call costs host time on every
+  // eager launch otherwise; round-5 advisor finding).  Keyed by the kernel's address: KernelT is the same type for every kernel of one signature.
+  if (bytes <= 48 * 1024) return bytes;
+  static std::mutex mu;
+  static std::unordered_map<const void*, int> largest;
+  const void* key = reinterpret_cast<const void*>(k);
+  std::lock_guard<std::mutex> lock(mu);
+  int& cur = largest[key];
+  if (bytes > cur) {
+    hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    cur = bytes;
+  }
   return bytes;
 }
 
-int g_attn_small = 1;      // ph_attention_tuning(0): force the streaming kernels (A/B and the tests that compare the two families)
 
 int check_fwd(const ph_attn_fwd_args* f, const char* who) {
   PH_CHECK_ARG(f && f->q && f->k && f->v && f->o, "%s: null pointer", who);
@@ -1381,7 +1702,7 @@ extern "C" int ph_attention_fwd(const ph_attn_fwd_args* a, hipStream_t stream) {
   ProfScope prof__(PH_FAM_ATTN_FWD, 4.0 * a->B * (double)a->H * a->Sq * (double)a->Sk * a->dh, 0.0, stream);
   // the decoder's cross-attention: one block per (batch, head), keys split over the waves.  (One or two key units -- self-attention at T <= 64 --
   // stay on the streaming kernel in the FORWARD: 4.7 vs 5.2 us, tools/attn_small_probe.py; the fused backward wins at every size.)
-  if (const int sq = (g_attn_small && a->Sk > 64) ? attn_small_qt(a) : 0) {
+  if (const int sq = ((g_attn_small & 1) && a->Sk > 64) ? attn_small_qt(a) : 0) {
     const int rows_pad = ceil_div(a->Sk, 32) * 32;
     (void)sq;
     const int smem = set_smem(attn_fwd_small_kernel<2>, sm_fwd_bytes(rows_pad, sm_merge_bytes<2>()));
@@ -1416,11 +1737,11 @@ extern "C" int ph_attention_bwd(const ph_attn_bwd_args* a, hipStream_t stream) {
   ProfScope prof__(PH_FAM_ATTN_BWD, 10.0 * a->f.B * (double)a->f.H * a->f.Sq * (double)a->f.Sk * a->f.dh, 0.0, stream);
   int rc = check_fwd(&a->f, "ph_attention_bwd");
   if (rc) return rc;
-  PH_CHECK_ARG(a->d_o && a->dq && a->dk && a->dv && a->delta && a->f.lse, "ph_attention_bwd: null pointer");
+  PH_CHECK_ARG(a->d_o && a->dq && a->dk && a->dv && a->f.lse, "ph_attention_bwd: null pointer");
   PH_CHECK_ARG(((a->do_ts | a->dq_ts | a->dk_ts | a->dv_ts | a->do_bs | a->dq_bs | a->dk_bs | a->dv_bs) % 8) == 0, "ph_attention_bwd: strides must be multiples of 8");
   PH_CHECK_ARG((int64_t)a->f.Sq * a->do_ts < (1ll << 30), "ph_attention_bwd: a (batch, head) slice of dO must span < 2 GiB");
   const ph_attn_fwd_args& f = a->f;
-  if (const int sq = g_attn_small ? attn_small_qt(&f) : 0) {                // dQ, dK and dV of the decoder's launches in ONE launch
+  if (const int sq = (g_attn_small & 1) ? attn_small_qt(&f) : 0) {                // dQ, dK and dV of the decoder's launches in ONE launch
     const int rows_pad = ceil_div(f.Sk, 32) * 32;
     (void)sq;
     const int smem = set_smem(attn_bwd_small_kernel<2>, sm_bwd_bytes<2>(rows_pad));
@@ -1428,7 +1749,21 @@ extern "C" int ph_attention_bwd(const ph_attn_bwd_args* a, hipStream_t stream) {
     PH_LAUNCH_CHECK("attn_bwd_small_kernel");
     return PH_OK;
   }
+  PH_CHECK_ARG(a->delta, "ph_attention_bwd: the streaming kernels need the delta workspace (only the small-query path leaves it untouched)");
   const bool plain = attn_plain_ok(&f);
+  if (const int split = res_split(&f)) {                                      // head-resident kernels: the ViT blocks at 224^2
+    const dim3 grid(f.B * f.H * split);
+#define PH_RES_DQ(NTV) { const int sm = set_smem(attn_bwd_dq_res_kernel<NTV>, 2 * ((NTV + 1) / 2 * 32) * RES_RS * 2);             \
+                         hipLaunchKernelGGL((attn_bwd_dq_res_kernel<NTV>), grid, dim3(256), sm, stream, *a, split); }
+#define PH_RES_DKV(NCV) { const int sm = set_smem(attn_bwd_dkv_res_kernel<NCV, 8>, 2 * NCV * 32 * RES_RS * 2 + 2 * NCV * 32 * 4);    \
+                          hipLaunchKernelGGL((attn_bwd_dkv_res_kernel<NCV, 8>), grid, dim3(512), sm, stream, *a, split); }
+    if (f.Sk <= 208) PH_RES_DQ(13) else PH_RES_DQ(17)
+    if (f.Sq <= 224) PH_RES_DKV(7) else PH_RES_DKV(9)
+#undef PH_RES_DQ
+#undef PH_RES_DKV
+    PH_LAUNCH_CHECK("attn_bwd_res kernels");
+    return PH_OK;
+  }
   // backward: 32 queries / keys per wave pay from ~512 tokens on (LARGE, S = 1220: 184 vs 189 us; ViT S = 260: 91 vs 84 us)
   const int qt_mode = attn_qt2_ok();
   const bool q2 = plain && qt_mode && f.dh <= 64 && f.Sq >= (qt_mode == 2 ? 128 : 512);
@@ -1465,8 +1800,9 @@ extern "C" int ph_attention_bwd(const ph_attn_bwd_args* a, hipStream_t stream) {
 }
 
 extern "C" int ph_attention_tuning(int small_query_kernels) {
-  const int old = g_attn_small;
-  if (small_query_kernels >= 0) g_attn_small = small_query_kernels ? 1 : 0;
+  // argument / return value: 0 = streaming kernels only, 1 = default (every family), 2 = small-query kernels without the one-pass dQ kernel
+  const int old = g_attn_small == 3 ? 1 : (g_attn_small == 1 ? 2 : 0);
+  if (small_query_kernels >= 0) g_attn_small = small_query_kernels == 0 ? 0 : (small_query_kernels == 2 ? 1 : 3);
   return old;
 }
 

@@ -490,14 +490,23 @@ ATTN_CASES = [  # B, H, Sq, Sk, dh, causal, masked, drop
     (2, 2, 70, 130, 32, True, False, 0.0),
     (1, 2, 100, 200, 128, False, True, 0.2),
     (2, 8, 64, 300, 160, False, False, 0.0),     # Prismer-HUGE resampler: ViT-H width 1280 / 8 heads (configs/prismer.json:50-73, resampler.py:18-24)
-    # round 5: the small-query kernels (head dim 64, Sq <= 64, Sk <= 320: one block per (batch, head), keys split over the waves)
+    # round 5: the small-query kernels (head dim 64, Sq <= 32, Sk <= 320: one block per (batch, head), keys split over the waves)
     (3, 4, 30, 30, 64, True, True, 0.1),         # decoder self-attention as trained: causal + padding + dropout
     (2, 12, 30, 260, 64, False, False, 0.1),     # decoder cross-attention at BASE geometry (9 key units over 4 waves)
-    (2, 4, 40, 40, 64, True, True, 0.1),         # VQA text length (prismer_vqa.py:22-30): 3 query sub-tiles held as 4
+    (2, 4, 40, 40, 64, True, True, 0.1),         # VQA text length (prismer_vqa.py:22-30): Sq > 32 -> the streaming kernels on both sides
+    (2, 4, 30, 40, 64, True, True, 0.1),         # two key units over four waves (waves without a unit in the fused backward)
+    (2, 4, 20, 80, 64, False, True, 0.1),        # three key units: the 3-unit forward merge (Sk 65..96)
     (2, 3, 1, 23, 64, True, True, 0.0),          # one query: a cached decode step (generation)
     (2, 2, 17, 320, 64, False, True, 0.2),       # the largest key image the small kernels take
-    (1, 2, 64, 37, 64, False, False, 0.0),       # full 64-query tile, ragged keys
+    (1, 2, 64, 37, 64, False, False, 0.0),       # full 64-query tile, ragged keys (streaming kernels: Sq > 32)
     (2, 3, 280, 150, 64, False, False, 0.0),     # mask-free kernels, ragged tails on both sides
+    # round 6: the head-resident kernels (plain, head dim 64, Sq, Sk <= 272: one block per (batch, head) or per share of its sub-tiles, NT = 13 or 17)
+    (2, 4, 196, 196, 64, False, False, 0.0),     # PrismerZ-BASE: rgb tokens only (NT = 13, 12.25 tiles)
+    (1, 3, 100, 272, 64, False, False, 0.0),     # the longest key sequence it takes (17 full tiles)
+    (1, 2, 130, 209, 64, False, False, 0.0),     # first length on the NT = 17 instantiation, 14 tiles used, odd tail
+    (2, 2, 50, 16, 64, False, False, 0.0),       # one key tile
+    (40, 8, 260, 260, 64, False, False, 0.0),    # 320 heads: one block per head (split = 1), waves walking 5 / 4 / 4 / 4 sub-tiles
+    (3, 2, 272, 33, 64, False, False, 0.0),      # 17 query sub-tiles against 3 key tiles
 ]
 
 
@@ -535,7 +544,20 @@ def test_attention(ops, B, H, Sq, Sk, dh, causal, masked, p):
     assert rel_fro(dq, gq) < 1.5e-2, ('dq', rel_fro(dq, gq))
     assert rel_fro(dkv[:, :D], gk) < 1.5e-2, ('dk', rel_fro(dkv[:, :D], gk))
     assert rel_fro(dkv[:, D:], gv) < 1.5e-2, ('dv', rel_fro(dkv[:, D:], gv))
-    if dh == 64 and Sq <= 64 and Sk <= 320:
+    if dh == 64 and 32 < Sq <= 272 and Sk <= 272 and not (causal or masked or p > 0):
+        # head-resident kernels (default, ran above) against the streaming kernels on the same launch: same P / dP / delta arithmetic
+        from prismer_amd import _lib
+        assert _lib.lib.ph_attention_tuning(2) == 1
+        try:
+            o2, lse2 = ops.attention_fwd(q, k, v, B, H, Sq, Sk, dh, q_strides=qs, k_strides=ks, v_strides=ks, key_mask=km, causal=causal, drop=drop)
+            dq2 = torch.empty_like(q); dkv2 = torch.empty_like(kv)
+            ops.attention_bwd(d_o, q, k, v, o2, lse2, B, H, Sq, Sk, dh, q_strides=qs, k_strides=ks, v_strides=ks, dq=dq2, dk=dkv2[:, :D],
+                              dv=dkv2[:, D:], dq_strides=qs, dk_strides=ks, dv_strides=ks, key_mask=km, causal=causal, drop=drop)
+        finally:
+            assert _lib.lib.ph_attention_tuning(1) == 2
+        assert rel_fro(o, o2) < 4e-3 and rel_fro(lse, lse2) < 1e-5, (rel_fro(o, o2), rel_fro(lse, lse2))
+        assert rel_fro(dq, dq2) < 4e-3 and rel_fro(dkv, dkv2) < 4e-3, (rel_fro(dq, dq2), rel_fro(dkv, dkv2))
+    if dh == 64 and Sq <= 32 and Sk <= 320:
         # both kernel families on the same launch: the small-query kernels ran above (default); the streaming kernels must agree with them
         # far inside the reference tolerance (same recomputed P / dP, same dropout words, different summation order)
         from prismer_amd import _lib

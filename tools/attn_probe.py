@@ -1,11 +1,11 @@
 """Attention kernels at the step's shapes: correctness against an fp32 torch reference + timing under hipGraph replay.
-    PH_ATTN_PLAIN=0|1 python tools/attn_probe.py      (the switch is read once per process: run twice for the A/B)"""
+    ATTN_TUNING=0|1|2 python tools/attn_probe.py      (ph_attention_tuning: 0 streaming kernels only, 1 default, 2 default without the one-pass dQ kernel)"""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from prismer_amd import ops
+from prismer_amd import ops, _lib
 
 BF = torch.bfloat16
 
@@ -67,7 +67,8 @@ def case(name, B, H, Sq, Sk, dh):
 
 if __name__ == '__main__':
     torch.manual_seed(0)
-    print('PH_ATTN_PLAIN =', os.environ.get('PH_ATTN_PLAIN', '(default 1)'))
+    _lib.lib.ph_attention_tuning(int(os.environ.get('ATTN_TUNING', '1')))
+    print('ph_attention_tuning =', os.environ.get('ATTN_TUNING', '1'))
     case('vit 32x12 S=260 dh=64', 32, 12, 260, 260, 64)
     case('resampler 32x8 64x1240 dh=96', 32, 8, 64, 1240, 96)
     case('zbase 32x12 S=196 dh=64', 32, 12, 196, 196, 64)

@@ -18,6 +18,8 @@ ARMS = {
     'base': dict(),
     'gemm6': dict(gemm_mode=6),
     'gemm7': dict(gemm_mode=7),
+    'attn_stream': dict(attn_mode=2),            # ph_attention_tuning(2): without the head-resident backward kernels
+    'attn_res': dict(attn_mode=1),
 }
 
 
@@ -25,6 +27,8 @@ def make(arm):
     spec = ARMS[arm]
     if 'gemm_mode' in spec:
         _lib.lib.ph_gemm_tuning(spec['gemm_mode'], -1)
+    if 'attn_mode' in spec:
+        _lib.lib.ph_attention_tuning(spec['attn_mode'])
     extra = spec.get('trainer', {})
     if extra:
         from prismer_amd import trainer as T
@@ -43,6 +47,7 @@ def make(arm):
         if extra:
             T.Trainer.__init__ = orig
         _lib.lib.ph_gemm_tuning(*_lib.GEMM_BIG_DEFAULT)
+        _lib.lib.ph_attention_tuning(1)
     return tr
 
 
