@@ -20,7 +20,7 @@ from tests.util import rel_fro
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
-TOL_ACT, TOL_LOSS, TOL_GRAD = 2e-2, 2e-3, 6e-2
+TOL_ACT, TOL_LOSS, TOL_GRAD = 2e-2, 2e-3, 5e-2      # (gradient bar 5e-2 since round 6: SURVEY 8c; 6e-2 before)
 
 
 def to_dev(x):
@@ -484,7 +484,7 @@ def _check_grads_against_golden(g, named_grads, tag):
 PROJ_SLACK = 1.8
 
 
-@pytest.mark.parametrize('name', ['base_b8', 'zbase_b4', 'large_vqa_b1', 'large_vqa_b1+big', 'base_b32', 'large_vqa_b4', 'huge_b1'])
+@pytest.mark.parametrize('name', ['base_b8', 'zbase_b4', 'large_vqa_b1', 'large_vqa_b1+big', 'base_b32', 'large_vqa_b4', 'huge_b1', 'zbase_b32', 'large_vqa_b16'])
 def test_trainer_hipgraph_step_matches_reference_golden(name):
     force_big = name.endswith('+big')           # LARGE shapes (H = 1024, 24 + 24 layers, S = 1220) through the 256x128 ping-pong kernel:
     name = name.split('+')[0]                   # at B = 1 the cost model never picks it, config 5's bs16 does
@@ -519,6 +519,10 @@ def _hipgraph_step_vs_golden(name, force_big=False):
     print(name, 'GEMM launches by kernel class during warm-up + capture:', by_class)
     if force_big:
         assert by_class['big'] > 0, by_class
+    if name in ('zbase_b32', 'large_vqa_b16'):
+        # round 6: the secondary legs of the bench line at THEIR benchmarked batch (config 2 at bs32: M = 32 x 196; config 5 at bs16: M = 16 x 1220) --
+        # the dispatch (tile choice, tail split, grouped forms) depends on M, so the kernels the bench runs are the kernels this fixture pins
+        assert by_class['big'] > 0 and by_class['big_grouped'] > 0 and by_class['ks2'] > 0, by_class
     if name == 'large_vqa_b4':
         # config 5 at a batch where the dispatch itself (no ph_gemm_tuning override) puts the LARGE shapes -- M = 4 x 1220 rows, K = 1024 /
         # 4096, ragged text -- on the 256x128 ping-pong kernel and its grouped weight-gradient form (round-3 review: B = 1 had to force them)
@@ -601,6 +605,66 @@ def test_trainer_hipgraph_dropout_steps_match_reference_golden(name):
     for st, before in zip(tr.stores, p0):                     # lr = 0: the weights did not move (step 2 is the same model, other masks)
         assert torch.equal(st.master, before)
     assert abs(float(g['s1.total_train']) - float(g['s2.total_train'])) > 1e-4 * float(g['s1.total_train'])
+
+
+@pytest.mark.parametrize('name', list(C.TRAJ_CASES))
+def test_trainer_hipgraph_trajectory_matches_reference_loop(name):
+    """Steps 2+ against the REFERENCE (round 6): tests/golden/<case>_traj.npz holds C.TRAJ_STEPS iterations of the reference training loop
+    (train_caption.py:111-112 torch.optim.AdamW, :126-135 cosine_lr_schedule -> forward -> zero_grad -> backward -> step) on the reference classes in
+    full training mode (BatchNorm batch statistics, dropout 0.1 under this library's masks, the seed advanced per step exactly as the device
+    seed is), minted by tests/golden/make_golden.py <case>+traj, plus the same loop under PyTorch's own bf16 autocast as the yardstick.  Here:
+    the native Trainer under hipGraph REPLAY walks the same four steps -- loss curve, parameter displacement p_4 - p_0 of every trainable tensor
+    (16 fixed projections: a full-tensor estimate) and the BatchNorm running statistics after four updates.  AdamW's first steps move every entry
+    by ~lr whatever the gradient's size, so entries whose gradient is round-off flip sign under ANY bf16 arithmetic: the yardstick's own
+    displacement error is 8 % in the median; the bar is 2x the yardstick per tensor (floor 15 %), the loss curve is held to 2e-3."""
+    g = np.load(os.path.join(GOLD, name + '_traj.npz'))
+    case = C.Case(name)
+    assert (C.TRAJ_LR, C.TRAJ_MIN_LR, C.TRAJ_WD, C.TRAJ_TOTAL) == (5e-5, 0.0, 0.05, 10)         # what _pinned_trainer builds (configs/caption.yaml:12-14)
+    tr, m = _pinned_trainer(case, use_graph=True, lr=C.TRAJ_LR, p_drop=0.1, keep_grads=False)
+    tr.seed.copy_(torch.tensor([C.DROP_SEED - (1 << 64) if C.DROP_SEED >= (1 << 63) else C.DROP_SEED], dtype=torch.int64))
+    p0 = [st.master.clone() for st in tr.stores]
+    losses = []
+    for k in range(C.TRAJ_STEPS):
+        losses.append(tr.step().item())
+    torch.cuda.synchronize()
+    assert tr.use_graph and tr.graphs is not None and tr.it == C.TRAJ_STEPS
+    ref, ac = g['losses'], g['ac_losses']
+    print(name, 'loss curve', losses, 'reference', ref.tolist(), 'autocast yardstick', ac.tolist())
+    for k in range(C.TRAJ_STEPS):
+        bar = max(TOL_LOSS, 3.0 * abs(ac[k] - ref[k]) / ref[k])
+        assert math_close(losses[k], float(ref[k]), bar), (k, losses[k], float(ref[k]))
+    assert ref[-1] < 0.9 * ref[0]                                       # the fixture itself trains
+    trainable = str(g['requires_grad']).split('\n')
+    rows = []
+    for pref, st, before in (('expert_encoder.', tr.stores[0], p0[0]), ('text_decoder.', tr.stores[1], p0[1])):
+        for nm in st.names:
+            if not st.is_trainable(nm):
+                continue
+            n = pref + nm
+            assert n in trainable
+            dn = float(g['dnorm.' + n])
+            if dn < 1e-6:
+                continue
+            o = st.offset[nm]
+            delta = st.master[o:o + st.numel[nm]] - before[o:o + st.numel[nm]]
+            e = C.projected_error(C.grad_projections(n, delta), g['dproj.' + n]) / dn
+            bar = PROJ_SLACK * max(0.15, 2.0 * float(g['ac_drel.' + n]))
+            rows.append((e / bar, e, float(g['ac_drel.' + n]), abs(delta.double().norm().item() - dn) / dn, n))
+    rows.sort(reverse=True)
+    med = float(np.median([r[1] for r in rows]))
+    print(name, 'displacement after', C.TRAJ_STEPS, 'steps: worst (err/bar, full-tensor error estimate, autocast error, norm error, name)', rows[:3], 'median', med,
+          'autocast median', float(np.median([r[2] for r in rows])))
+    assert rows[0][0] < 1.0, rows[:4]
+    # norm of the displacement: same yardstick (a tensor whose fp32 gradient is EXACTLY zero in most entries -- untouched embedding rows: only the
+    # weight decay moves them -- picks up +-lr from round-off gradients under any bf16 arithmetic, PyTorch's autocast included)
+    worst_n = max(rows, key=lambda r: r[3] / max(0.1, 2.0 * r[2]))
+    print(name, 'worst displacement norm (norm error, autocast full-tensor error, name):', worst_n[3], worst_n[2], worst_n[4])
+    assert med < 0.15 and worst_n[3] < max(0.1, 2.0 * worst_n[2]), worst_n
+    for k, v in m.expert_encoder.state_dict().items():
+        if 'running_' in k:
+            assert rel_fro(v, torch.from_numpy(g['bn.' + k])) < 1e-2, k
+        if 'num_batches' in k:
+            assert int(v) == int(g['bn.' + k]) == C.TRAJ_STEPS
 
 
 def test_bench_gradient_handling_equals_the_pinned_one():
