@@ -20,6 +20,8 @@ ARMS = {
     'gemm7': dict(gemm_mode=7),
     'attn_stream': dict(attn_mode=2),            # ph_attention_tuning(2): without the head-resident backward kernels
     'attn_res': dict(attn_mode=1),
+    'ln_old': dict(ln_mode=0),                   # ph_layernorm_tuning(0): one-row-per-wave LayerNorm kernels
+    'ln_new': dict(ln_mode=1),
 }
 
 
@@ -27,6 +29,8 @@ def make(arm):
     spec = ARMS[arm]
     if 'gemm_mode' in spec:
         _lib.lib.ph_gemm_tuning(spec['gemm_mode'], -1)
+    if 'ln_mode' in spec:
+        _lib.lib.ph_layernorm_tuning(spec['ln_mode'])
     if 'attn_mode' in spec:
         _lib.lib.ph_attention_tuning(spec['attn_mode'])
     extra = spec.get('trainer', {})
@@ -48,6 +52,7 @@ def make(arm):
             T.Trainer.__init__ = orig
         _lib.lib.ph_gemm_tuning(*_lib.GEMM_BIG_DEFAULT)
         _lib.lib.ph_attention_tuning(1)
+        _lib.lib.ph_layernorm_tuning(1)
     return tr
 
 
