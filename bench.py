@@ -353,8 +353,9 @@ def main():
     ap.add_argument('--compact-labels', action='store_true',
                     help='label experts as uint8 maps + feature tables, in-painted on the device (SURVEY 8f #2; secondary: the headline '
                          'keeps the reference loader contract of dense 64-channel fp32 maps)')
-    ap.add_argument('--grad-payload', default='fp32', choices=['fp32', 'bf16'],
-                    help='N > 1: gradient exchange payload. fp32 = DDP semantics (default); bf16 = pre-scaled by 1/world, half the bytes')
+    ap.add_argument('--grad-payload', default='auto', choices=['auto', 'fp32', 'bf16'],
+                    help='N > 1: gradient exchange payload. fp32 = DDP semantics; bf16 = pre-scaled by 1/world, half the bytes; auto (default) = fp32 unless a '
+                         'probe all-reduce at start-up measures < 150 GB/s of bus bandwidth on >= 4 ranks (the decision is printed in grad_exchange)')
     ap.add_argument('--shard', default='none', choices=['none', 'zero1', 'rs_ag'],
                     help='N > 1: none = replicated AdamW behind an all-reduce; zero1 = sharded AdamW + broadcasts; rs_ag = reduce-scatter + '
                          'sharded AdamW + all-gather (FSDP SHARD_GRAD_OP pattern)')

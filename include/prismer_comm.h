@@ -38,6 +38,13 @@ int ph_comm_unique_id(void* out_id_128);
 int ph_comm_init(int rank, int world, const void* unique_id_128, ph_comm** out);
 /* in-place SUM all-reduce of `count` elements of `dtype` (one gradient bucket), enqueued on `stream` */
 int ph_allreduce_bucket(ph_comm* comm, void* buf, int64_t count, int dtype, hipStream_t stream);
+/* The reduce-scatter + all-gather form of the exchange (round 6; the communication pattern of accelerate's FSDP SHARD_GRAD_OP flag,
+ * train_caption.py:56-66, Trainer(shard_optimizer='rs_ag')): rank r receives the SUM of chunk r of `world` equal chunks of `send`
+ * (`world * recv_count` elements); the all-gather is its inverse (`recv` holds `world * send_count` elements); ph_broadcast ships `count`
+ * elements of `buf` from rank `root` in place (the owners' updated slices of the ZeRO-1 style sharded optimizer, train_pretrain.py:56-91). */
+int ph_reduce_scatter(ph_comm* comm, const void* send, void* recv, int64_t recv_count, int dtype, hipStream_t stream);
+int ph_all_gather(ph_comm* comm, const void* send, void* recv, int64_t send_count, int dtype, hipStream_t stream);
+int ph_broadcast(ph_comm* comm, void* buf, int64_t count, int dtype, int root, hipStream_t stream);
 int ph_comm_world(const ph_comm* comm);
 int ph_comm_destroy(ph_comm* comm);
 const char* ph_comm_last_error(void);

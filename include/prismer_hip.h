@@ -217,6 +217,15 @@ int ph_patchify(const float* img, void* col, int B, int C, int R, int p, int Kp,
 /* nn.UpsamplingBilinear2d (align_corners=True, vit.py:89,106) fused with NCHW fp32 -> NHWC bf16. */
 int ph_resize_bilinear_nchw_to_nhwc(const float* x, void* y, int B, int C, int Hin, int Win, int Hout, int Wout,
                                     hipStream_t stream);
+/* Dense-expert remap on the device (round 6).  Replaces the depth / normal / edge branch of post_label_process (dataset/utils.py:120-121:
+ * `2 * (x - x.min()) / (x.max() - x.min() + eps) - 1`, eps = 1e-6, min / max over the whole [C, H, W] map of ONE sample) followed by
+ * nn.UpsamplingBilinear2d (vit.py:88-90): the loader hands over the RAW expert maps [B, C, Hin, Win] fp32,
+ *   ph_dense_minmax_partial        part[b][p] = (min, max) of the p-th of `nparts` contiguous shares of sample b (fp32 [B][nparts][2]),
+ *   ph_resize_remap_nchw_to_nhwc   folds the pairs per sample and applies the remap to every bilinear tap in the reference's expression order
+ *                                  (same taps / weights as ph_resize_bilinear_nchw_to_nhwc), NHWC bf16 out. */
+int ph_dense_minmax_partial(const float* x, float* part, int B, int64_t n_per_sample, int nparts, hipStream_t stream);
+int ph_resize_remap_nchw_to_nhwc(const float* x, const float* minmax_part, int nparts, void* y, int B, int C, int Hin, int Win, int Hout, int Wout,
+                                 hipStream_t stream);
 /* Label-expert in-painting fused with the stem's bilinear resize.  Replaces post_label_process (dataset/utils.py:117-160: the
  * per-label Python loop that paints CLIP text features over seg / obj_detection / ocr_detection label maps on the CPU, 64 fp32
  * channels per pixel) followed by nn.UpsamplingBilinear2d (vit.py:88-90, align_corners=True).
@@ -314,6 +323,9 @@ int ph_ce_fwd(const void* logits, int ld, const int64_t* labels, int B, int T, i
               hipStream_t stream);
 int ph_ce_bwd(void* logits, int ld, const int64_t* labels, int B, int T, int V, int Vpad, float eps,
               const float* row_lse, const float* dloss, hipStream_t stream);
+/* out[r][j] = softmax(logits[r, :V])[ids[j]] (fp32 [rows][n]) over bf16 logit rows `ld` elements apart: the first-token probabilities of the
+ * answer candidates of inference='rank' (prismer_caption.py:70, prismer_vqa.py:51: softmax(dim=1).index_select(1, first tokens)). */
+int ph_softmax_gather_bf16(const void* logits, int64_t ld, int rows, int V, const int64_t* ids, int n, float* out, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimizer and small utilities.

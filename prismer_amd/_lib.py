@@ -135,6 +135,8 @@ _SIGS = {
     'ph_patchify': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ph_resize_bilinear_nchw_to_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ph_gather_rows_bf16': (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p]),
+    'ph_dense_minmax_partial': (c_int, [c_void_p, c_void_p, c_int, c_i64, c_int, c_void_p]),
+    'ph_resize_remap_nchw_to_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ph_inpaint_resize_nhwc': (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'ph_im2col_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'ph_col2im_nhwc': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -152,6 +154,7 @@ _SIGS = {
     'ph_scatter_taps': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'ph_embed_fwd': (c_int, [C.POINTER(EmbedFwdArgs), c_void_p]),
     'ph_embed_bwd': (c_int, [C.POINTER(EmbedBwdArgs), c_void_p]),
+    'ph_softmax_gather_bf16': (c_int, [c_void_p, c_i64, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'ph_ce_fwd': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'ph_ce_bwd': (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     'ph_adamw': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_float, c_float, c_float,

@@ -27,13 +27,17 @@ def lib():
         L.ph_comm_unique_id.argtypes = [C.c_void_p]
         L.ph_comm_init.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.ph_allreduce_bucket.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        L.ph_reduce_scatter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        L.ph_all_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        L.ph_broadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
         L.ph_comm_world.argtypes = [C.c_void_p]
         L.ph_comm_destroy.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
 
-EXPORTS = ['ph_comm_unique_id', 'ph_comm_init', 'ph_allreduce_bucket', 'ph_comm_world', 'ph_comm_destroy', 'ph_comm_last_error']
+EXPORTS = ['ph_comm_unique_id', 'ph_comm_init', 'ph_allreduce_bucket', 'ph_reduce_scatter', 'ph_all_gather', 'ph_broadcast', 'ph_comm_world', 'ph_comm_destroy',
+           'ph_comm_last_error']
 F32, BF16 = 0, 1
 
 
@@ -76,6 +80,29 @@ class NativeComm:
         assert t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16)
         _check(lib().ph_allreduce_bucket(self.handle, t.data_ptr(), t.numel(), BF16 if t.dtype == torch.bfloat16 else F32,
                                          torch.cuda.current_stream().cuda_stream), 'ph_allreduce_bucket')
+        return t
+
+    @staticmethod
+    def _dt(t):
+        assert t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16)
+        return BF16 if t.dtype == torch.bfloat16 else F32
+
+    def reduce_scatter(self, out, inp):
+        """out[c] = SUM over ranks of chunk `rank` of inp[world * c] (torch.distributed.reduce_scatter_tensor), on torch's current stream"""
+        assert inp.numel() == self.world * out.numel() and inp.dtype == out.dtype
+        _check(lib().ph_reduce_scatter(self.handle, inp.data_ptr(), out.data_ptr(), out.numel(), self._dt(out), torch.cuda.current_stream().cuda_stream),
+               'ph_reduce_scatter')
+        return out
+
+    def all_gather(self, out, inp):
+        """out[world * c] = the ranks' inp[c] in rank order (torch.distributed.all_gather_into_tensor)"""
+        assert out.numel() == self.world * inp.numel() and inp.dtype == out.dtype
+        _check(lib().ph_all_gather(self.handle, inp.data_ptr(), out.data_ptr(), inp.numel(), self._dt(inp), torch.cuda.current_stream().cuda_stream),
+               'ph_all_gather')
+        return out
+
+    def broadcast_(self, t, root):
+        _check(lib().ph_broadcast(self.handle, t.data_ptr(), t.numel(), self._dt(t), int(root), torch.cuda.current_stream().cuda_stream), 'ph_broadcast')
         return t
 
     def destroy(self):

@@ -31,6 +31,9 @@ struct Api {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*);
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+  ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
   ncclResult_t (*CommDestroy)(ncclComm_t);
   const char* (*GetErrorString)(ncclResult_t);
   bool ok = false;
@@ -58,9 +61,12 @@ Api& api() {
   a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
   a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
   a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
+  a.ReduceScatter = (decltype(a.ReduceScatter))dlsym(h, "ncclReduceScatter");
+  a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
+  a.Broadcast = (decltype(a.Broadcast))dlsym(h, "ncclBroadcast");
   a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
   a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
-  a.ok = a.GetUniqueId && a.CommInitRank && a.AllReduce && a.CommDestroy && a.GetErrorString;
+  a.ok = a.GetUniqueId && a.CommInitRank && a.AllReduce && a.ReduceScatter && a.AllGather && a.Broadcast && a.CommDestroy && a.GetErrorString;
   return a;
 }
 }  // namespace
@@ -111,6 +117,39 @@ extern "C" int ph_allreduce_bucket(ph_comm* comm, void* buf, int64_t count, int 
   NEED_RCCL();
   RCCL_CALL(A.AllReduce(buf, buf, (size_t)count, dtype == PH_COMM_BF16 ? ncclBfloat16 : ncclFloat32, ncclSum, comm->comm, stream),
             "ncclAllReduce");
+  return PH_COMM_OK;
+}
+
+static int dtype_of(int dtype, ncclDataType_t* out) {
+  if (dtype == PH_COMM_F32) { *out = ncclFloat32; return 0; }
+  if (dtype == PH_COMM_BF16) { *out = ncclBfloat16; return 0; }
+  return -1;
+}
+
+extern "C" int ph_reduce_scatter(ph_comm* comm, const void* send, void* recv, int64_t recv_count, int dtype, hipStream_t stream) {
+  ncclDataType_t dt;
+  if (!comm || !send || !recv || recv_count < 0 || dtype_of(dtype, &dt)) return fail(PH_COMM_ERR_BAD_ARG, "ph_reduce_scatter: bad arguments");
+  if (recv_count == 0) return PH_COMM_OK;
+  NEED_RCCL();
+  RCCL_CALL(A.ReduceScatter(send, recv, (size_t)recv_count, dt, ncclSum, comm->comm, stream), "ncclReduceScatter");
+  return PH_COMM_OK;
+}
+
+extern "C" int ph_all_gather(ph_comm* comm, const void* send, void* recv, int64_t send_count, int dtype, hipStream_t stream) {
+  ncclDataType_t dt;
+  if (!comm || !send || !recv || send_count < 0 || dtype_of(dtype, &dt)) return fail(PH_COMM_ERR_BAD_ARG, "ph_all_gather: bad arguments");
+  if (send_count == 0) return PH_COMM_OK;
+  NEED_RCCL();
+  RCCL_CALL(A.AllGather(send, recv, (size_t)send_count, dt, comm->comm, stream), "ncclAllGather");
+  return PH_COMM_OK;
+}
+
+extern "C" int ph_broadcast(ph_comm* comm, void* buf, int64_t count, int dtype, int root, hipStream_t stream) {
+  ncclDataType_t dt;
+  if (!comm || !buf || count < 0 || dtype_of(dtype, &dt) || root < 0 || root >= comm->world) return fail(PH_COMM_ERR_BAD_ARG, "ph_broadcast: bad arguments");
+  if (count == 0) return PH_COMM_OK;
+  NEED_RCCL();
+  RCCL_CALL(A.Broadcast(buf, buf, (size_t)count, dt, root, comm->comm, stream), "ncclBroadcast");
   return PH_COMM_OK;
 }
 

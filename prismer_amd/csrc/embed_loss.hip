@@ -190,6 +190,37 @@ __device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max) {
   return r;
 }
 
+// out[row][j] = softmax(logits[row, :V])[ids[j]]: the first-token probabilities of the answer candidates of `inference='rank'`
+// (prismer_caption.py:70, prismer_vqa.py:51: `F.softmax(logits, dim=1).index_select(dim=1, index=answer_first_token)`).  One block per row:
+// the same single-sweep max / sum-of-exponentials as ce_fwd_kernel, then the gathered columns.
+__global__ __launch_bounds__(256) void softmax_gather_kernel(const bf16* __restrict__ logits, int64_t ld, int V, const int64_t* __restrict__ ids, int n,
+                                                             float* __restrict__ out) {
+  __shared__ float sh[4];
+  const bf16* x = logits + (int64_t)blockIdx.x * ld;
+  float mx = -FLT_MAX, se = 0.f;
+  const int nch = (V + 7) / 8;
+  for (int c = threadIdx.x; c < nch; c += 256) {
+    bf16x8 tv = *reinterpret_cast<const bf16x8*>(x + c * 8);
+    float v[8];
+    float cm = -FLT_MAX;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { v[e] = (c * 8 + e < V) ? bf2f(tv[e]) : -INFINITY; cm = fmaxf(cm, v[e]); }
+    const float nm = fmaxf(mx, cm);
+    float acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc += __expf(v[e] - nm);
+    se = se * __expf(mx - nm) + acc;
+    mx = nm;
+  }
+  const float gm = block_reduce(mx, sh, true);
+  const float gs = block_reduce(se * __expf(mx - gm), sh, false);
+  const float inv = 1.0f / gs;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const int64_t id = ids[j];
+    out[(int64_t)blockIdx.x * n + j] = (id >= 0 && id < V) ? __expf(bf2f(x[id]) - gm) * inv : 0.f;
+  }
+}
+
 // Per-row loss into row_loss[row] (0 for ignored / last positions), summed per sample by ce_sample_sum_kernel: no atomics and -- the round-5
 // finding -- NO hipMemsetAsync in front of the kernel: a small memset NODE of a captured hipGraph does not replay correctly on this ROCm
 // (tools/graph_memset_probe.py, profiles/r5_graph_memset_order.txt: from the second replay on it leaves junk instead of zeros), which is what
@@ -298,6 +329,14 @@ extern "C" int ph_ce_fwd(const void* logits, int ld, const int64_t* labels, int 
   hipLaunchKernelGGL(ce_fwd_kernel, dim3(B * T), dim3(256), 0, stream, (const bf16*)logits, ld, labels, B, T, V, eps, row_loss, row_lse);
   hipLaunchKernelGGL(ce_sample_sum_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, stream, (const float*)row_loss, B, T, loss);
   PH_LAUNCH_CHECK("ce_fwd_kernel");
+  return PH_OK;
+}
+
+extern "C" int ph_softmax_gather_bf16(const void* logits, int64_t ld, int rows, int V, const int64_t* ids, int n, float* out, hipStream_t stream) {
+  PH_CHECK_ARG(logits && ids && out && rows > 0 && V > 0 && n > 0 && ld >= V && (ld % 8) == 0 && (((uintptr_t)logits) & 15) == 0, "ph_softmax_gather_bf16: bad args");
+  ProfScope prof__(PH_FAM_EMBED_CE, 0.0, 2.0 * rows * (double)V, stream);
+  hipLaunchKernelGGL(softmax_gather_kernel, dim3(rows), dim3(256), 0, stream, (const bf16*)logits, ld, V, ids, n, out);
+  PH_LAUNCH_CHECK("softmax_gather_kernel");
   return PH_OK;
 }
 

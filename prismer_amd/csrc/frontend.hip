@@ -36,14 +36,43 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
 // NCHW fp32 -> NHWC bf16 layout change.  One block per (b, out row, group of 8 channels): consecutive lanes walk
 // consecutive x of one channel plane (coalesced source rows), the 8-channel pixel vectors are assembled in LDS
 // and stored as 16-B pieces.
+// per-sample min / max of a dense expert map, first stage: block (p, b) reduces a contiguous 1/nparts share of sample b's n values to one
+// (min, max) pair; the consumer (resize_kernel) folds the nparts pairs itself -- no atomics, no second launch
+__global__ __launch_bounds__(256) void dense_minmax_partial_kernel(const float* __restrict__ x, float* __restrict__ part, int64_t n, int nparts) {
+  __shared__ float red[2][4];
+  const int p = blockIdx.x, b = blockIdx.y;
+  const int64_t per = (n + nparts - 1) / nparts, lo_i = p * per, hi_i = min(n, lo_i + per);
+  const float* xs = x + (int64_t)b * n;
+  float lo = INFINITY, hi = -INFINITY;
+  for (int64_t i = lo_i + threadIdx.x; i < hi_i; i += 256) { const float v = xs[i]; lo = fminf(lo, v); hi = fmaxf(hi, v); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = lo; red[1][threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[((int64_t)b * nparts + p) * 2] = fminf(fminf(red[0][0], red[0][1]), fminf(red[0][2], red[0][3]));
+    part[((int64_t)b * nparts + p) * 2 + 1] = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+  }
+}
+
+// mm_part != nullptr (round 6): the per-sample min-max remap of the dense experts (dataset/utils.py:120-121, `2 * (x - min) / (max - min + eps) - 1`
+// with eps = 1e-6 over the whole [C, H, W] map of a sample) is applied to every tap BEFORE the interpolation, in the reference's expression
+// order; the sample's min / max are folded from the `nparts` partial pairs ph_dense_minmax_partial left (32 cached loads per thread).
+template <bool REMAP>          // (a template flag, not a run-time one: the plain instantiation must stay bit-identical to inpaint_resize_kernel's tap arithmetic)
 __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ x, bf16* __restrict__ y, int B, int C, int Hin,
-                                                     int Win, int Hout, int Wout) {
+                                                     int Win, int Hout, int Wout, const float* __restrict__ mm_part, int nparts) {
   __shared__ bf16 tile[1024 * 8];
   int cgroups = (C + 7) / 8;
   int cg = blockIdx.x % cgroups;
   int oy = (blockIdx.x / cgroups) % Hout;
   int b = blockIdx.x / (cgroups * Hout);
   int c0 = cg * 8, nc = min(8, C - c0);
+  float mn = 0.f, den = 1.f;
+  if constexpr (REMAP) {
+    float lo = INFINITY, hi = -INFINITY;
+    for (int p = 0; p < nparts; ++p) { lo = fminf(lo, mm_part[((int64_t)b * nparts + p) * 2]); hi = fmaxf(hi, mm_part[((int64_t)b * nparts + p) * 2 + 1]); }
+    mn = lo; den = (hi - lo) + 1e-6f;
+  }
   float sy = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f;
   float sx = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
   float fy = oy * sy;
@@ -59,6 +88,10 @@ __global__ __launch_bounds__(256) void resize_kernel(const float* __restrict__ x
       const float* pl = x + ((int64_t)b * C + c0 + cc) * Hin * Win;
       float v00 = pl[(int64_t)y0 * Win + x0], v01 = pl[(int64_t)y0 * Win + x1];
       float v10 = pl[(int64_t)y1 * Win + x0], v11 = pl[(int64_t)y1 * Win + x1];
+      if constexpr (REMAP) {
+        v00 = (2.f * (v00 - mn)) / den - 1.f; v01 = (2.f * (v01 - mn)) / den - 1.f;
+        v10 = (2.f * (v10 - mn)) / den - 1.f; v11 = (2.f * (v11 - mn)) / den - 1.f;
+      }
       float v = (1.f - wy) * ((1.f - wx) * v00 + wx * v01) + wy * ((1.f - wx) * v10 + wx * v11);
       tile[(ox - xb) * 8 + cc] = f2bf(v);
     }
@@ -605,7 +638,26 @@ extern "C" int ph_resize_bilinear_nchw_to_nhwc(const float* x, void* y, int B, i
   ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream, "ph_resize_bilinear_nchw_to_nhwc");
   int64_t blocks = (int64_t)B * Hout * ((C + 7) / 8);
   PH_CHECK_ARG(blocks < (1ll << 31), "ph_resize_bilinear: grid too large");
-  hipLaunchKernelGGL(resize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, (bf16*)y, B, C, Hin, Win, Hout, Wout);
+  hipLaunchKernelGGL(resize_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, x, (bf16*)y, B, C, Hin, Win, Hout, Wout, (const float*)nullptr, 0);
+  PH_LAUNCH_CHECK("resize_kernel");
+  return PH_OK;
+}
+
+extern "C" int ph_dense_minmax_partial(const float* x, float* part, int B, int64_t n_per_sample, int nparts, hipStream_t stream) {
+  PH_CHECK_ARG(x && part && B > 0 && n_per_sample > 0 && nparts > 0 && nparts <= 64, "ph_dense_minmax_partial: bad args");
+  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream, "ph_dense_minmax_partial");
+  hipLaunchKernelGGL(dense_minmax_partial_kernel, dim3(nparts, B), dim3(256), 0, stream, x, part, n_per_sample, nparts);
+  PH_LAUNCH_CHECK("dense_minmax_partial_kernel");
+  return PH_OK;
+}
+
+extern "C" int ph_resize_remap_nchw_to_nhwc(const float* x, const float* minmax_part, int nparts, void* y, int B, int C, int Hin, int Win, int Hout,
+                                            int Wout, hipStream_t stream) {
+  PH_CHECK_ARG(x && y && minmax_part && nparts > 0 && nparts <= 64 && B > 0 && C > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "ph_resize_remap: bad args");
+  ProfScope prof__(PH_FAM_FRONTEND, 0.0, 0.0, stream, "ph_resize_remap_nchw_to_nhwc");
+  int64_t blocks = (int64_t)B * Hout * ((C + 7) / 8);
+  PH_CHECK_ARG(blocks < (1ll << 31), "ph_resize_remap: grid too large");
+  hipLaunchKernelGGL(resize_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, x, (bf16*)y, B, C, Hin, Win, Hout, Wout, minmax_part, nparts);
   PH_LAUNCH_CHECK("resize_kernel");
   return PH_OK;
 }

@@ -4,6 +4,18 @@ import torch
 from .prismer import Prismer
 
 
+def _first_token_probs(logits_last, first_ids):
+    """softmax(logits, dim=1).index_select(1, first token of every candidate answer) (prismer_caption.py:70, prismer_vqa.py:51) through the
+    library's kernel (ph_softmax_gather_bf16: no stock torch softmax on the rank path, round 6); logits_last: [B, V] view of the decoder's logits"""
+    from .. import ops
+    x = logits_last
+    if x.dtype != torch.bfloat16 or x.stride(-1) != 1 or (x.stride(0) % 8) != 0 or (x.data_ptr() % 16) != 0:
+        x = x.to(torch.bfloat16).contiguous()
+        if x.shape[1] % 8:                                      # (row stride must be a multiple of 8 elements)
+            x = torch.nn.functional.pad(x, (0, 8 - x.shape[1] % 8))[:, :logits_last.shape[1]]
+    return ops.softmax_gather(x, first_ids.to(torch.int64))
+
+
 def tile(x, dim, n_tile):
     """prismer_caption.py:115-121: repeat each slice n_tile times consecutively."""
     return x.repeat_interleave(n_tile, dim=dim)
@@ -66,8 +78,7 @@ class PrismerCaption(Prismer):
                 s_ids, s_att = self._ids(prefix, device)
             s_ids, s_att = s_ids[:, :-1], s_att[:, :-1]
             start = self.text_decoder(s_ids, attention_mask=s_att, encoder_hidden_states=experts_train, return_dict=True)
-            logits = start.logits[:, -1, :].float()
-            prob_first = torch.softmax(logits, dim=1).index_select(dim=1, index=a_ids[:, 0])
+            prob_first = _first_token_probs(start.logits[:, -1, :], a_ids[:, 0])
             _, topk_ids = prob_first.topk(k_test, dim=1)
             ans_ids = torch.cat([a_ids.index_select(0, t) for t in topk_ids], dim=0)
             ans_att = torch.cat([a_att.index_select(0, t) for t in topk_ids], dim=0)

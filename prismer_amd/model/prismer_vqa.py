@@ -2,7 +2,7 @@
 import torch
 
 from .prismer import Prismer
-from .prismer_caption import tile
+from .prismer_caption import tile, _first_token_probs
 
 
 class PrismerVQA(Prismer):
@@ -47,8 +47,7 @@ class PrismerVQA(Prismer):
             a_ids, a_att = self._ids(answer, device) if not (isinstance(answer, (list, tuple)) and isinstance(answer[0], str)) else \
                 self._ids([' ' + a.capitalize() + '</s>' for a in answer], device, padding='longest', add_special_tokens=False)
             start = self.text_decoder(q_ids, attention_mask=q_att, encoder_hidden_states=enc, return_dict=True)
-            logits = start.logits[:, -1, :].float()
-            prob_first = torch.softmax(logits, dim=1).index_select(dim=1, index=a_ids[:, 0])
+            prob_first = _first_token_probs(start.logits[:, -1, :], a_ids[:, 0])
             _, topk_ids = prob_first.topk(k_test, dim=1)
             ans_ids = torch.cat([a_ids.index_select(0, t) for t in topk_ids], dim=0)
             ans_att = torch.cat([a_att.index_select(0, t) for t in topk_ids], dim=0)

@@ -26,9 +26,10 @@ _MODELS = {'ViT-B/32': (768, 12, 12, 32), 'ViT-B/16': (768, 12, 12, 16), 'ViT-L/
 
 def _expert_map(v):
     """the tensor that carries an expert's spatial size: dense map, obj_detection {'label','instance'} (dataset/utils.py:149) or
-    the compact {'label_map': uint8, 'table': fp32} form that is in-painted on the device"""
+    the compact {'label_map': uint8, 'table': fp32} form that is in-painted on the device, or {'raw': fp32} = a dense expert map before the
+    min-max remap of post_label_process (remapped on the device, round 6)"""
     if isinstance(v, dict):
-        return v['label_map'] if 'label_map' in v else v['label']
+        return v['label_map'] if 'label_map' in v else (v['raw'] if 'raw' in v else v['label'])
     return v
 
 

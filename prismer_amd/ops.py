@@ -438,6 +438,22 @@ def resize_to_nhwc(x, Hout, Wout):
     return y
 
 
+REMAP_PARTS = 16
+
+
+def remap_resize_to_nhwc(raw, Hout, Wout):
+    """raw: fp32 [B, C, H, W] dense expert map BEFORE post_label_process (depth / normal / edge).  Returns the stem input [B, Hout, Wout, C] bf16 =
+    bilinear(2 * (x - min) / (max - min + 1e-6) - 1) with the min / max of each sample's whole map (dataset/utils.py:120-121 + vit.py:88-90)."""
+    B, Cc, Hin, Win = raw.shape
+    raw = raw.contiguous().float()
+    part = torch.empty((B, REMAP_PARTS, 2), dtype=F32, device=raw.device)
+    check(lib.ph_dense_minmax_partial(raw.data_ptr(), part.data_ptr(), B, Cc * Hin * Win, REMAP_PARTS, _stream()), 'ph_dense_minmax_partial')
+    y = torch.empty((B, Hout, Wout, Cc), dtype=BF16, device=raw.device)
+    check(lib.ph_resize_remap_nchw_to_nhwc(raw.data_ptr(), part.data_ptr(), REMAP_PARTS, y.data_ptr(), B, Cc, Hin, Win, Hout, Wout, _stream()),
+          'ph_resize_remap_nchw_to_nhwc')
+    return y
+
+
 def inpaint_resize(label_map, table, Hout, Wout):
     """label_map: uint8 [B, H, W] (or [B, 1, H, W]); table: fp32 [256, C] (shared) or [B, 256, C] (per image).
     Returns the stem input [B, Hout, Wout, C] bf16 = bilinear(post_label_process(label_map)) (dataset/utils.py:117-160 + vit.py:88-90)."""
@@ -666,6 +682,17 @@ def ce_fwd(logits, labels, B, T, V, eps):
                         row_lse[1].data_ptr(), _stream()), 'ph_ce_fwd')
     row_lse = row_lse[0]
     return loss, row_lse
+
+
+def softmax_gather(logits, ids):
+    """softmax(logits, dim=1).index_select(1, ids) for bf16 logit rows [R, V] (a strided view of the decoder's padded logits buffer is fine:
+    the row stride must be a multiple of 8 elements, the rows 16-B aligned); fp32 [R, len(ids)] out -- prismer_caption.py:70 / prismer_vqa.py:51"""
+    assert logits.dim() == 2 and logits.dtype == BF16 and logits.stride(1) == 1 and ids.dtype == torch.int64
+    R, V = logits.shape
+    ids = ids.contiguous()
+    out = torch.empty((R, ids.numel()), dtype=F32, device=logits.device)
+    check(lib.ph_softmax_gather_bf16(logits.data_ptr(), logits.stride(0), R, V, ids.data_ptr(), ids.numel(), out.data_ptr(), _stream()), 'ph_softmax_gather_bf16')
+    return out
 
 
 def ce_bwd(logits, labels, B, T, V, eps, row_lse, dloss):

@@ -202,6 +202,8 @@ class EncoderProgram:
             Hs = int(d.expert_resolution * (4 if label else 16) / d.patch_size)
             if isinstance(val, dict) and 'label_map' in val:
                 a = ops.inpaint_resize(val['label_map'], val['table'], Hs, Hs)
+            elif isinstance(val, dict) and 'raw' in val:          # dense expert as the expert network left it: min-max remap on the device (round 6)
+                a = ops.remap_resize_to_nhwc(val['raw'], Hs, Hs)
             else:
                 inp = (val['label'] if name == 'obj_detection' else val).contiguous().float()
                 a = ops.resize_to_nhwc(inp, Hs, Hs)

@@ -23,6 +23,7 @@ reference).  DDP's per-step buffer broadcast from rank 0 is replaced by rank-loc
 import contextlib
 import math
 import random
+import time
 
 import torch
 
@@ -102,6 +103,7 @@ class Trainer:
         nl = len(self.dec_prog.layers)
         k = max(1, min(dec_backward_stages, nl)) if (self.world > 1 and self.micro == 1) else 1
         self.dec_cuts = [nl - (nl * i) // k for i in range(k + 1)]      # e.g. 12 layers, 3 stages: [12, 8, 4, 0]
+        self._bucket_mb = bucket_mb
         self.bucket_elems = bucket_mb * 1024 * 1024 // (2 if grad_payload == 'bf16' else 4)
         self.exchange = self._make_exchange(grad_payload, transport)
         self.stage_ranges = self._stage_ranges()
@@ -138,6 +140,7 @@ class Trainer:
         self.allow_eager_fallback = bool(allow_eager_fallback)
         self._exclusive, self._keep_maps, self._count_config = None, None, None
         self._graph_no_fill = False
+        self._host_comm_s, self._host_comm_steps = 0.0, 0
         self._step_open = False                # a step was started and did not reach its last segment (exception between replays)
         if self.world > 1:
             self.broadcast_parameters()
@@ -155,30 +158,79 @@ class Trainer:
     def _make_exchange(self, payload, transport):
         if self.world == 1:
             return None
+        self._native_comm = None
         if transport == 'native':                              # the library's own RCCL communicator (include/prismer_comm.h)
             from . import comm
             self._native_comm = comm.NativeComm.from_process_group(self.pg, self.device)
-            reduce_fn = self._native_comm.all_reduce_
+            nc = self._native_comm
+            reduce_fn, rs_fn, ag_fn = nc.all_reduce_, nc.reduce_scatter, nc.all_gather
+            # (round 6: reduce-scatter / all-gather / broadcast are entry points of the communicator too, so the sharded modes run on ONE
+            # transport -- a second RCCL communicator driven from another stream is the classic multi-communicator ordering hazard)
+            self._bcast = lambda t, src: nc.broadcast_(t, src)
         else:
             def reduce_fn(t):
                 torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=self.pg)
-        if (self.rs_ag or self.shard) and transport == 'native':
-            # (the sharded updates issue torch.distributed collectives; a second RCCL communicator driven from another stream is the
-            # classic multi-communicator ordering hazard -- one transport per Trainer)
-            raise ValueError("shard_optimizer uses torch.distributed collectives: combine it with transport='torch.distributed', not 'native'")
 
-        def rs_fn(out, inp):
-            torch.distributed.reduce_scatter_tensor(out, inp, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            def rs_fn(out, inp):
+                torch.distributed.reduce_scatter_tensor(out, inp, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
-        def ag_fn(out, inp):
-            torch.distributed.all_gather_into_tensor(out, inp, group=self.pg)
+            def ag_fn(out, inp):
+                torch.distributed.all_gather_into_tensor(out, inp, group=self.pg)
+
+            def _bcast(t, src):
+                torch.distributed.broadcast(t, torch.distributed.get_global_rank(self.pg, src) if self.pg is not None else src, group=self.pg)
+            self._bcast = _bcast
+        if payload == 'auto':
+            payload = self._choose_payload(reduce_fn)
+            self.bucket_elems = self._bucket_mb * 1024 * 1024 // (2 if payload == 'bf16' else 4)
         return GradExchange(self.world, reduce_fn, pack=lambda src, dst, scale=1.0: ops.cast_to_bf16(src, out=dst, scale=scale),
                             unpack=lambda src, dst: ops.cast_to_f32(src, out=dst), payload=payload, chunk_elems=self.bucket_elems,
                             comm_stream=self.comm_stream, transport='rccl via ' + ('prismer_comm (native)' if transport == 'native' else 'torch.distributed'),
                             mode='rs_ag' if self.rs_ag else 'allreduce', rank=self.rank, reduce_scatter=rs_fn, all_gather=ag_fn)
 
+    AUTO_BUSBW_GB_S = 150.0          # below this measured all-reduce bus bandwidth the fp32 payload no longer hides behind the backward
+
+    def _choose_payload(self, reduce_fn):
+        """grad_payload='auto' (bench.py default for N > 1, round 6): DDP's fp32 payload when the node's all-reduce sustains it, else the
+        pre-scaled bf16 buckets (half the bytes per link).  Decided ONCE at construction from a probe all-reduce -- 3 x 64 MB fp32 on the
+        communication stream, bus bandwidth = 2 (W-1)/W x bytes / time, the slowest rank's time (MAX all-reduce) so that every rank decides alike --
+        and shown beside dist.predict_exchange on the measured phase times of one GPU; small worlds (< 4 ranks) keep fp32.  The decision and the probe
+        are part of exchange_desc() / the bench line."""
+        from .dist import predict_exchange
+        self.payload_decision = dict(requested='auto', world=self.world)
+        if self.world < 4 or self.device.type != 'cuda':
+            self.payload_decision.update(chosen='fp32', reason='world < 4: DDP payload')
+            return 'fp32'
+        n = 16 << 20
+        buf = torch.zeros(n, dtype=F32, device=self.device)
+        with torch.cuda.stream(self.comm_stream):
+            reduce_fn(buf)                                         # channel set-up
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(3):
+                reduce_fn(buf)
+            b.record()
+        b.synchronize()
+        t = torch.tensor([a.elapsed_time(b) / 3.0], dtype=torch.float64, device=self.device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=self.pg)
+        ms = float(t.item())
+        busbw = 2.0 * (self.world - 1) / self.world * n * 4 / (ms * 1e-3) / 1e9
+        # phase times of one MI355X at Prismer-BASE bs32 (profiles/r5_phase_times.txt): decoder backward stages, trunk, front; payload per stage (fp32 MB)
+        seg, mb = [1.6, 1.1, 1.3, 7.0, 3.2], [182, 151, 364, 170, 102]
+        link = busbw * self.world / (2.0 * (self.world - 1))
+        pred = {p: predict_exchange(seg, [m * 1e6 * (0.5 if p == 'bf16' else 1.0) for m in mb], link, self.world) for p in ('fp32', 'bf16')}
+        chosen = 'fp32' if busbw >= self.AUTO_BUSBW_GB_S else 'bf16'
+        self.payload_decision.update(chosen=chosen, probe_ms_64mb=round(ms, 3), probe_busbw_gb_s=round(busbw, 1), threshold_gb_s=self.AUTO_BUSBW_GB_S,
+                                     predicted_exposed_ms={p: round(v['comm_ms_exposed'], 2) for p, v in pred.items()})
+        return chosen
+
     def exchange_desc(self):
-        return None if self.exchange is None else self.exchange.describe()
+        if self.exchange is None:
+            return None
+        d = self.exchange.describe()
+        if getattr(self, 'payload_decision', None):
+            d['payload_decision'] = self.payload_decision
+        return d
 
     def _stage_ranges(self):
         """{stage: [(store index, lo, hi)]}: the ranges of the flat gradient buffers whose gradients are COMPLETE once backward
@@ -246,7 +298,13 @@ class Trainer:
         exposed = [a.elapsed_time(b) for a, b in self.exposed_events]
         self.exposed_events = []
         n = max(len(exposed), 1)
-        return dict(comm_ms_total=round(sum(busy) / max(len(busy), 1), 3), comm_ms_exposed=round(sum(exposed) / n, 3), steps_timed=len(exposed))
+        # exposed = what the compute stream waited at the join (device events) + what the HOST spent inside the exchange calls (round 6: the
+        # gloo dry run blocks the host for ~300 ms per step and reported 0.07 ms exposed, because the device never saw the wait)
+        host = self._host_comm_s * 1e3 / max(self._host_comm_steps, 1)
+        self._host_comm_s, self._host_comm_steps = 0.0, 0
+        join = sum(exposed) / n
+        return dict(comm_ms_total=round(sum(busy) / max(len(busy), 1), 3), comm_ms_exposed=round(join + host, 3), comm_ms_exposed_device_join=round(join, 3),
+                    comm_ms_host_in_exchange_calls=round(host, 3), steps_timed=len(exposed))
 
     # ------------------------------------------------------------------------------------------ step pieces
     def _slices(self, B):
@@ -345,8 +403,7 @@ class Trainer:
                       self.betas[1], self.eps, self.wd, self._post_scale(), zero_grad=False)
         for k, (a, b) in enumerate(bounds):
             if b > a:
-                src = torch.distributed.get_global_rank(self.pg, k) if self.pg is not None else k
-                torch.distributed.broadcast(st.master[a:b], src, group=self.pg)
+                self._bcast(st.master[a:b], k)
         ops.cast_to_bf16(st.master[:st.n_train], st.shadow[:st.n_train])
         st.refresh_derived()
 
@@ -544,7 +601,7 @@ class Trainer:
         """(re)binds the static input buffers. First call allocates them; later calls copy into them."""
         for k, v in experts.items():                 # expert-map resolution fixes the program's token geometry
             if k != 'rgb':
-                er = (v.get('label_map', v.get('label')) if isinstance(v, dict) else v).shape[-1]
+                er = (v.get('label_map', v.get('label', v.get('raw'))) if isinstance(v, dict) else v).shape[-1]
                 if er != self.enc.expert_resolution:
                     assert self.graphs is None, 'expert resolution changed after graph capture'
                     self.enc.expert_resolution, self.enc._prog = er, None
@@ -754,11 +811,19 @@ class Trainer:
                 for st in self.stores:
                     st.grad.zero_()
             self._step_open = True
+            timed = self.exchange is not None and self.exchange.timing
             for i, (g, coll) in enumerate(self.graphs):
                 self.trace.append(('seg', i))
                 g.replay()
                 if coll is not None:
-                    coll()
+                    if timed:                                   # host time inside the exchange calls: a transport that BLOCKS the host thread (gloo; a
+                        t0 = time.perf_counter()                # mis-configured RCCL) stalls the launches behind it -- invisible to device events
+                        coll()
+                        self._host_comm_s += time.perf_counter() - t0
+                    else:
+                        coll()
+            if timed:
+                self._host_comm_steps += 1
             self._step_open = False
         else:
             with self._wq_scope():

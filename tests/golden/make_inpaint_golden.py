@@ -64,13 +64,19 @@ def main():
         obj_info = {str(i): int(torch.randint(0, U.DETECTION_FEATURES.shape[0], (1,), generator=g)) for i in range(6)}
         ocr_info = {i: {'features': torch.randn(64, generator=g) * 0.75} for i in range(4)}
         depth_in = torch.rand(1, 224, 224, generator=g) * 0.7 + 0.1
-        inputs = {'depth': depth_in.clone(), 'seg_coco': seg.clone(), 'seg_ade': ade.clone(),
+        # round 6: the other two dense experts -- a THREE-channel map (the min / max of dataset/utils.py:121 run over the whole [C, H, W] tensor, not
+        # per channel) and an edge map; stored in full: the device-side remap (ph_dense_minmax_partial + the resize kernel) is tested on them
+        normal_in = (torch.rand(3, 224, 224, generator=g) * torch.tensor([0.9, 0.5, 0.2]).view(3, 1, 1) + torch.tensor([0.05, 0.3, 0.6]).view(3, 1, 1)).half().float()
+        edge_in = ((torch.rand(1, 224, 224, generator=g) > 0.93).float() * torch.rand(1, 224, 224, generator=g)).half().float()
+        inputs = {'depth': depth_in.clone(), 'normal': normal_in.clone(), 'edge': edge_in.clone(), 'seg_coco': seg.clone(), 'seg_ade': ade.clone(),
                   'obj_detection': obj.clone(), 'ocr_detection': ocr.clone()}
         res = U.post_label_process(inputs, {'obj_detection': obj_info, 'ocr_detection': ocr_info})
         p = f'img{img}.'
         out[p + 'depth_in'] = depth_in.numpy()[:, ::STRIDE, ::STRIDE]
         out[p + 'depth_minmax'] = np.array([depth_in.min().item(), depth_in.max().item()])
         out[p + 'depth'] = res['depth'].numpy()[:, ::STRIDE, ::STRIDE]
+        out[p + 'normal_in'], out[p + 'normal'] = normal_in.numpy().astype(np.float16), res['normal'].numpy()[:, ::STRIDE, ::STRIDE]
+        out[p + 'edge_in'], out[p + 'edge'] = edge_in.numpy().astype(np.float16), res['edge'].numpy()[:, ::STRIDE, ::STRIDE]
         for k, lab in (('seg_coco', seg), ('seg_ade', ade), ('obj_detection', obj), ('ocr_detection', ocr)):
             out[p + k + '.map'] = lab.numpy().astype(np.uint8)
             r = res[k]['label'] if k == 'obj_detection' else res[k]

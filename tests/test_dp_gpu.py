@@ -17,7 +17,7 @@ def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, use_graph, out, payload='bf16', n_steps=2, shard=False, backend='gloo', own_device=False):
+def _worker(rank, world, port, use_graph, out, payload='bf16', n_steps=2, shard=False, backend='gloo', own_device=False, transport='torch.distributed'):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
@@ -46,7 +46,7 @@ def _worker(rank, world, port, use_graph, out, payload='bf16', n_steps=2, shard=
     m = Holder(); m.expert_encoder, m.text_decoder = enc, dec
     tab = case.instance_table(x)
     tr = Trainer(m, lr=1e-3, total_steps=10, use_graph=use_graph, keep_grads=True, grad_payload=payload, dec_backward_stages=2,
-                 shard_optimizer=shard)
+                 shard_optimizer=shard, transport=transport)
     assert tr.world == world and tr.dec_cuts == [2, 1, 0]
     tr.set_batch(T.to_dev(x), ids, mask, labels)
     orig = tr._host_prologue
@@ -127,6 +127,21 @@ for dt in (torch.bfloat16, torch.float32):
         c.all_reduce_(t)
     s.synchronize()
     assert torch.equal(t, ref), dt
+# round 6: the sharded modes' collectives on the same communicator (world 1: reduce-scatter and all-gather are copies, broadcast a no-op)
+for dt in (torch.bfloat16, torch.float32):
+    src = torch.randn(4096, device='cuda').to(dt); dst = torch.zeros_like(src); full = torch.zeros_like(src)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        c.reduce_scatter(dst, src)
+        c.all_gather(full, dst)
+        c.broadcast_(full, 0)
+    s.synchronize()
+    assert torch.equal(dst, src) and torch.equal(full, src), dt
+try:
+    c.broadcast_(full, 1)
+    raise SystemExit('root beyond the world must be rejected')
+except RuntimeError:
+    pass
 assert comm.lib().ph_comm_world(c.handle) == 1
 c.destroy()
 print('NATIVE_COMM_OK')

@@ -13,13 +13,16 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason='needs two GPUs (RCCL refuses two ranks per device)')
-@pytest.mark.parametrize('shard', [False, 'rs_ag'])
-def test_two_ranks_two_gpus_rccl_matches_gloo(shard):
+@pytest.mark.parametrize('shard,transport', [(False, 'torch.distributed'), ('rs_ag', 'torch.distributed'), (False, 'native'), ('rs_ag', 'native'), (True, 'native')])
+def test_two_ranks_two_gpus_rccl_matches_gloo(shard, transport):
+    """transport='native' (round 6): the library's own communicator carries all-reduce, reduce-scatter + all-gather ('rs_ag') and the broadcasts of the
+    ZeRO-1 style sharded optimizer (shard_optimizer=True) -- include/prismer_comm.h ph_reduce_scatter / ph_all_gather / ph_broadcast"""
     world = 2
     res = {}
     for backend in ('nccl', 'gloo'):
         mgr = mp.Manager(); out = mgr.dict()
-        mp.spawn(_worker, args=(world, _free_port(), True, out, 'fp32', 2, shard, backend, True), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), True, out, 'fp32', 2, shard, backend, True, transport if backend == 'nccl' else 'torch.distributed'),
+                 nprocs=world, join=True)
         res[backend] = (out[0], out[1])
     for backend in res:
         a, b = res[backend]

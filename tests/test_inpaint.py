@@ -39,6 +39,10 @@ def test_oracle_matches_reference_post_label_process():
         d = torch.from_numpy(g[f'img{img}.depth_in'])
         got = 2 * (d - float(lo)) / (float(hi) - float(lo) + 1e-6) - 1                         # remap_dense on the sub-sampled map
         assert torch.allclose(got, torch.from_numpy(g[f'img{img}.depth']), atol=1e-6)
+        # round 6: a three-channel map (min / max over the WHOLE [C, H, W] tensor) and an edge map, raw inputs stored in full
+        for k in ('normal', 'edge'):
+            raw = torch.from_numpy(g[f'img{img}.{k}_in'].astype(np.float32))
+            assert torch.equal(O.remap_dense(raw)[:, ::s, ::s], torch.from_numpy(g[f'img{img}.{k}'])), (img, k)      # same torch expression: bit-exact
     x = torch.rand(1, 8, 8)
     assert float(O.remap_dense(x).min()) == -1.0 and abs(float(O.remap_dense(x).max()) - 1.0) < 1e-5
 
@@ -99,3 +103,53 @@ def test_encoder_with_compact_label_experts_equals_dense():
         a = enc(to_dev(dense))
         b = enc(to_dev(compact))
     assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('Hout', [14, 30])            # the dense stems resize 224 -> 16 * E / p (vit.py:106): 224 at BASE; other sizes exercise the taps
+def test_dense_remap_on_device_matches_reference_function(Hout):
+    """ph_dense_minmax_partial + ph_resize_remap_nchw_to_nhwc (round 6) against the REFERENCE's post_label_process outputs (tests/golden/inpaint.npz:
+    depth-like one-channel, three-channel normal, sparse edge maps): the per-sample min / max, the remapped taps (checked through an identity
+    resize: Hout = Hin reproduces the remapped map itself to bf16 rounding) and the fused remap + resize against resize(remap) of the dense path."""
+    from prismer_amd import ops
+    g = np.load(GOLD)
+    s = int(g['stride'])
+    for k in ('normal', 'edge'):
+        raw = torch.stack([torch.from_numpy(g[f'img{img}.{k}_in'].astype(np.float32)) for img in range(2)]).cuda()       # [2, C, 224, 224]
+        raw[1] = raw[1] * 0.5 + 0.25                                       # the two samples of the batch get DIFFERENT ranges: the remap is per sample
+        want_full = torch.stack([O.remap_dense(raw[b].cpu()) for b in range(2)])
+        ident = ops.remap_resize_to_nhwc(raw, 224, 224).permute(0, 3, 1, 2).float().cpu()
+        assert (ident - want_full).abs().max() <= 2.0 ** -8 * 1.0 + 1e-6, k                                # bf16 rounding of values in [-1, 1]
+        ref0 = torch.from_numpy(g[f'img0.{k}'])                                                              # the reference function's own output (sample 0)
+        assert (ident[0][:, ::s, ::s] - ref0).abs().max() <= 2.0 ** -8 + 1e-6, k
+        got = ops.remap_resize_to_nhwc(raw, Hout, Hout)
+        want = ops.resize_to_nhwc(want_full.cuda(), Hout, Hout)            # the dense path: the host remaps (reference expression), the device resizes
+        assert got.shape == want.shape == (2, Hout, Hout, raw.shape[1])
+        assert (got.float() - want.float()).abs().max() <= 2.0 ** -7, k     # same taps; the remap's division may differ in the last fp32 bit
+        assert (got != want).float().mean() < 2e-2, k
+
+
+@pytest.mark.gpu
+def test_encoder_with_raw_dense_experts_equals_remapped():
+    """the encoder fed {'raw': map} dense experts (remapped on the device) against the same encoder fed the host-remapped maps"""
+    from tests.golden import cases as C
+    from tests.test_parity_gpu import build, to_dev
+    case = C.Case('tiny_caption')
+    enc, _, _, _ = build(case)
+    enc.eval()
+    x = case.inputs()[0]
+    gen = torch.Generator().manual_seed(9)
+    raw_form, dense = dict(x), dict(x)
+    for name in ('depth', 'normal', 'edge'):
+        if name not in x:
+            continue
+        raw = torch.rand(x[name].shape, generator=gen) * 3.0 + 0.5
+        raw[0] *= 0.3
+        raw_form[name] = {'raw': raw}
+        dense[name] = torch.stack([O.remap_dense(raw[b]) for b in range(raw.shape[0])])
+    assert any(isinstance(v, dict) and 'raw' in v for v in raw_form.values())
+    enc.instance_table = torch.tensor([(7 * i) % 128 for i in range(256)], dtype=torch.int32).cuda()       # (pins the per-forward random instance draw, vit.py:145-147)
+    with torch.no_grad():
+        a = enc(to_dev(dense))
+        b = enc(to_dev(raw_form))
+    assert torch.equal(a, b)                                 # (the remapped taps and the resize are bit-identical on both paths)

@@ -950,3 +950,16 @@ def test_small_utils(ops):
     s = torch.tensor([5], dtype=torch.int64, device='cuda')
     ops.advance_seed(s)
     assert s.item() != 5
+
+
+def test_softmax_gather(ops):
+    """ph_softmax_gather_bf16 (round 6: the first-token candidate probabilities of inference='rank', prismer_caption.py:70) against torch on a
+    strided view of a padded logits buffer (the decoder's [B, T, Vpad] layout), vocabulary not a multiple of 8, out-of-range ids -> 0"""
+    B, T, V, Vp = 5, 7, 50265, 50304
+    buf = (torch.randn(B, T, Vp, device='cuda') * 3).to(BF)
+    last = buf[:, -1, :V]
+    ids = torch.tensor([0, 5, 50264, 1234, 5, 49999], device='cuda')
+    got = ops.softmax_gather(last, ids)
+    ref = torch.softmax(last.float(), dim=1).index_select(1, ids)
+    assert got.shape == (B, 6) and rel_fro(got, ref) < 1e-5
+    assert ops.softmax_gather(last, torch.tensor([V + 3], device='cuda')).abs().max().item() == 0.0
