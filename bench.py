@@ -138,10 +138,15 @@ def kernel_family_pass(tr, steps):
     for n, fn in saved.items():
         setattr(dp, n, timed(fn))
     lib.ph_prof_enable(1)
-    for _ in range(steps):
-        tr.step()
-    for n in saved:
-        delattr(dp, n)                                      # (instance attributes shadowing the methods)
+    try:
+        for _ in range(steps):
+            tr.step()
+    except BaseException:
+        lib.ph_prof_enable(0)                               # (a failed instrumented step must not leave the profiler on for the later legs)
+        raise
+    finally:
+        for n in saved:
+            delattr(dp, n)                                  # (instance attributes shadowing the methods)
     import tempfile
     dump = os.environ.get('PH_PROF_DUMP') or os.path.join(tempfile.gettempdir(), f'ph_prof_{os.getpid()}.csv')
     lib.ph_prof_dump(dump.encode())
@@ -155,7 +160,7 @@ def kernel_family_pass(tr, steps):
     # GEMM launches by KERNEL class (the library tags every profiled GEMM call with the class its dispatch chose)
     names = ['gemm_kernel<128,*> (128x128 / 128x64 register-staged)', 'gemm_kernel<64,64> (64x64 register-staged)',
              'gemm_ks2_kernel (64x64, k loop split inside the block: the decoder\'s M = 960 launches)',
-             'big::gemm_big_kernel<12,*,*> (256x128 LDS-DMA ping-pong, single launch)',
+             'big::gemm_big_kernel<28,*,*> (256x128 LDS-DMA ping-pong, single launch)',
              'big::gemm_big_grouped_kernel / gemm_big_conv_kernel (256x128 LDS-DMA, grouped: weight gradients, stem convolutions)',
              'gemm_grouped_kernel (register-staged, grouped)', 'splitk_reduce']
     cls = {}
@@ -175,17 +180,20 @@ def kernel_family_pass(tr, steps):
     return fam
 
 
-def pmc_traffic():
+def pmc_traffic(live_launches=None):
     """HBM bytes per GEMM launch from the committed PMC passes (profiles/rN_pmc_gemm.json, newest round first: rocprofv3 --pmc FETCH_SIZE and
     WRITE_SIZE in separate runs of this bench, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md; tools/profile_round4.sh is the
     recipe); counters cannot be read from inside the process, so this is (None, None) when the file is absent.  Returns the
     per-launch bytes and the launch count the passes saw, so that a stale file shows next to the live launch count."""
-    for name in ('r5_pmc_gemm.json', 'r4_pmc_gemm.json', 'r3_pmc_gemm.json', 'r2_pmc_gemm.json', 'r1_pmc_gemm.json'):
-        p = os.path.join(ROOT, 'profiles', name)
-        if os.path.isfile(p):
-            d = json.load(open(p))
-            return round(d['hbm_bytes_per_launch']), dict(file='profiles/' + name, launches_per_step=d['launches_per_step'],
-                                                          whole_step_hbm_gb=round(d['whole_step_hbm_gb'], 1))
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_gemm.json')), key=lambda f: int(re.search(r'r(\d+)', os.path.basename(f)).group(1)), reverse=True)
+    for p in files[:1]:                                    # the NEWEST committed pass only: no silent fall-back through older rounds (round-5 review)
+        d = json.load(open(p))
+        if live_launches is not None and abs(d['launches_per_step'] - live_launches) > 0.5:
+            return None, dict(file='profiles/' + os.path.basename(p), launches_per_step=d['launches_per_step'], refused=f'stale: the live step has {live_launches:g} GEMM launches')
+        return round(d['hbm_bytes_per_launch']), dict(file='profiles/' + os.path.basename(p), launches_per_step=d['launches_per_step'],
+                                                      whole_step_hbm_gb=round(d['whole_step_hbm_gb'], 1))
     return None, None
 
 
@@ -478,7 +486,7 @@ def main():
             ach = g['tflop_per_step'] / (g['ms_per_step'] / 1e3) if g['ms_per_step'] > 0 else 0.0
             out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_*kernel<*> (all bf16 MFMA GEMM launches of one step: gemm_kernel, gemm_ks2_kernel, gemm_grouped_kernel, big::gemm_big_kernel, big::gemm_big_grouped_kernel)',
                                'achieved': round(ach, 1), 'peak': PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_TFLOPS, 4),
-                               'traffic': pmc_traffic()[0], 'traffic_source': pmc_traffic()[1], 'algorithmic_bytes_per_launch': round(g['gbytes_per_step'] * 1e9 / max(g['launches_per_step'], 1)),
+                               'traffic': pmc_traffic(g['launches_per_step'])[0], 'traffic_source': pmc_traffic(g['launches_per_step'])[1], 'algorithmic_bytes_per_launch': round(g['gbytes_per_step'] * 1e9 / max(g['launches_per_step'], 1)),
                                'avg_launch_us': round(g['ms_per_step'] * 1e3 / max(g['launches_per_step'], 1), 2),
                                'launches_per_step': g['launches_per_step'], 'gemm_tflop_per_step': round(g['tflop_per_step'], 3)}
             if gemm_classes:                                # the single most expensive GEMM kernel of the step, beside the family figure

@@ -852,7 +852,9 @@ def zeros(shape, dtype, device):
     n = 1
     for v in shape:
         n *= int(v)
-    nbytes = n * torch.empty((), dtype=dtype).element_size()
+    nbytes = n * (torch.finfo(dtype).bits if dtype.is_floating_point else (8 if dtype == torch.bool else torch.iinfo(dtype).bits)) // 8
+    assert torch.device(device).type != 'cuda' or torch.cuda.current_device() == (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()), \
+        'ops.zeros fills on the current stream: it must belong to `device`'
     pad = (nbytes + 15) // 16 * 16
     buf = torch.empty(pad, dtype=torch.uint8, device=device)              # (the caching allocator aligns to 512 B)
     check(lib.ph_fill_zero(buf.data_ptr(), pad, _stream()), 'ph_fill_zero')

@@ -500,14 +500,20 @@ class EncoderProgram:
             if not (lo <= p < lo + flat.numel() * 8):
                 raise RuntimeError('a BatchNorm counter no longer aliases the program\'s counter buffer (module moved or cast after the '
                                    'program was built): rebuild the program (module._prog = None)')
-        doms = [dom for dom in self._bn_range if dom in names or (dom == 'seg' and any('seg' in n for n in names))]
-        if len(doms) == len(self._bn_range):
+        # one advance per CALL of a stem: the reference runs conv1['seg'] once per seg_* expert of the batch (vit.py:136-139), so two seg experts advance
+        # the shared stem's counters by two (round-5 advisor finding: they advanced by one)
+        calls = {}
+        for n in names:
+            dom = 'seg' if 'seg' in n else n
+            if dom in self._bn_range:
+                calls[dom] = calls.get(dom, 0) + 1
+        if len(calls) == len(self._bn_range) and all(c == 1 for c in calls.values()):
             ops.add_i64(flat, 1)
             return
-        for dom in doms:
+        for dom, c in calls.items():
             a, n = self._bn_range[dom]
             if n:
-                ops.add_i64(flat[a:a + n], 1)
+                ops.add_i64(flat[a:a + n], c)
 
     def forward_trunk(self, h, xf, B, save):
         """h: [B*S, W] rows of B images (rgb tokens filled; the latent rows are written here); xf: [B*Mx, W] or None."""
