@@ -31,8 +31,9 @@ typedef struct ihipStream_t* hipStream_t;
 #endif
 
 /* ABI revision: bumped whenever an argument struct or a signature changes (101: ph_conv_gather window fields, ph_gemm_args row map +
- * defer_reduce; 102: round 4; 103: round 5 -- ph_ce_fwd takes a row_loss scratch, no memset nodes anywhere).  A host built against another revision must refuse to run: ph_version() != PH_VERSION. */
-#define PH_VERSION 103
+ * defer_reduce; 102: round 4; 103: round 5 -- ph_ce_fwd takes a row_loss scratch, no memset nodes anywhere; 104: round 6 -- ph_dense_minmax_partial,
+ * ph_resize_remap_nchw_to_nhwc, ph_softmax_gather_bf16, new values of ph_gemm_tuning / ph_attention_tuning).  A host built against another revision must refuse to run: ph_version() != PH_VERSION. */
+#define PH_VERSION 104
 
 enum { PH_OK = 0, PH_ERR_BAD_ARG = -1, PH_ERR_UNSUPPORTED = -2, PH_ERR_LAUNCH = -3 };
 enum { PH_ACT_NONE = 0, PH_ACT_QUICKGELU = 1, PH_ACT_RELU2 = 2, PH_ACT_GELU = 3, PH_ACT_RELU = 4,
@@ -114,10 +115,10 @@ int ph_gemm_flush_deferred(hipStream_t stream);
  * cover 18..144 tiles each, far fewer than the chip holds, so the host side defers them and issues each layer's set at once. */
 #define PH_GEMM_GROUP_MAX 16
 int ph_gemm_grouped_bf16(const ph_gemm_args* args, int n, hipStream_t stream);
-/* tuning hook for benchmarks and tests: variant of the big-tile (256x128, LDS-DMA) kernel -- 0 = off, 1 = plain main loop, 5 = ping-pong
- * main loop, 6 = ping-pong with the LEAN tail (no surplus DMA, no drain; default) -- and the tile count from which it is used (1 = every eligible launch, bypassing the
- * dispatch cost model); a negative value leaves the setting unchanged.  The library reads no environment variable: the defaults
- * (6, 128) are compiled in and this call is the only switch. */
+/* tuning hook for benchmarks and tests: variant of the big-tile (256x128, LDS-DMA) kernel -- 0 = off, 1 = plain main loop, 5 / 6 = ping-pong
+ * main loop with the LEAN tail (no surplus DMA, no drain; round 4), 7 = 6 with the LDS-DMA requests spread over the M phase (round 6, default) -- and the
+ * tile count from which it is used (1 = every eligible launch, bypassing the dispatch cost model); a negative value leaves the setting unchanged.
+ * The library reads no environment variable: the defaults (7, 128) are compiled in and this call is the only switch. */
 int ph_gemm_tuning(int big_mode, int big_min_tiles);
 /* same, as a BACKGROUND launch: at most `max_blocks` blocks (0 = one per tile), each walking several tiles.  Deferred weight
  * gradients issued beside the latency-bound backward chain of the decoder (roberta.py:212-231 in reverse) then fill the

@@ -216,7 +216,7 @@ def _load():
 
 lib, LIB_PATH = _load()
 GEMM_BIG_DEFAULT = (7, 128)    # ph_gemm_tuning(mode, min_tiles) values of the product dispatch (tests / probes restore them after an override)
-ABI_VERSION = 103          # PH_VERSION of include/prismer_hip.h these ctypes structures mirror
+ABI_VERSION = 104          # PH_VERSION of include/prismer_hip.h these ctypes structures mirror
 if lib.ph_version() != ABI_VERSION:
     raise ImportError(f'{LIB_PATH} reports ABI revision {lib.ph_version()}, this binding was written for {ABI_VERSION} '
                       '(stale build? run `python -m prismer_amd.build --force`)')

@@ -1701,7 +1701,7 @@ extern "C" int ph_attention_fwd(const ph_attn_fwd_args* a, hipStream_t stream) {
   if (rc) return rc;
   ProfScope prof__(PH_FAM_ATTN_FWD, 4.0 * a->B * (double)a->H * a->Sq * (double)a->Sk * a->dh, 0.0, stream);
   // the decoder's cross-attention: one block per (batch, head), keys split over the waves.  (One or two key units -- self-attention at T <= 64 --
-  // stay on the streaming kernel in the FORWARD: 4.7 vs 5.2 us, tools/attn_small_probe.py; the fused backward wins at every size.)
+  // stay on the streaming kernel in the FORWARD: 4.7 vs 5.2 us, profiles/r5_ab_attention_small_query.txt; the fused backward wins at every size.)
   if (const int sq = ((g_attn_small & 1) && a->Sk > 64) ? attn_small_qt(a) : 0) {
     const int rows_pad = ceil_div(a->Sk, 32) * 32;
     (void)sq;

@@ -3,6 +3,7 @@
 // Replaces the non-GEMM parts of model/modules/vit.py:86-160.  All of these are HBM-bound byte movers:
 // every thread moves 16-B vectors along the channel (innermost NHWC) dimension.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 

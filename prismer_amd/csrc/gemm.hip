@@ -497,7 +497,7 @@ extern "C" int ph_gemm_bf16(const ph_gemm_args* a, hipStream_t stream) {
                                                                                        //  2 output tiles, 6272 k-tiles -- 48 splits left them at 94 us)
     for (int bm = 64; bm <= 128; bm += 64) {
       if (bm == 128 && (a->M <= 64 || a->N <= 64)) continue;
-      // tools/gemm_probe.py on MI355X: 8320x768 NT, K 768 -> 3072: 1.07 us per k-tile for one wave of co-resident
+      // round-1 slope probe on MI355X: 8320x768 NT, K 768 -> 3072: 1.07 us per k-tile for one wave of co-resident
       // 128x128 blocks (2 per CU), 0.83 us per k-tile and wave of 64x64 blocks (4 per CU); ~4 us fixed per block wave.
       const double tiles = (double)(bm == 128 ? t128 : t64), cap = bm == 128 ? 512.0 : 1024.0, t_iter = bm == 128 ? 1.07 : 0.83;
       for (int sp : cand) {

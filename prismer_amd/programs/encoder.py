@@ -188,7 +188,8 @@ class EncoderProgram:
     #   conv3x3 as an IMPLICIT GEMM (the A operand is gathered from the NHWC activation inside the GEMM loader: no im2col matrix is
     #   written, kept for the backward or re-read), BatchNorm statistics accumulated in the GEMM epilogue (col_stats), then one
     #   grouped pass a = relu(bn(y)) that also derives scale / shift and updates the running statistics.
-    # Only the first layer of the dense stems (Cin = 1 or 3: K = 9 or 27) keeps an explicit (tiny) im2col matrix.
+    # Only the first layer of the dense stems (Cin = 1 or 3: K = 9 or 27) keeps an explicit (tiny) im2col matrix (direct kernels for it were
+    # built in round 6 and measured slower: profiles/r6_ab_stem_conv1.txt).
     # Backward: grouped BN-ReLU backward; weight gradients as implicit GEMMs with the gather on the reduction side; data gradients
     # as dcol = dY.W followed by the col2im gather (dcol is transient, never saved).
     def stems_fwd(self, x, names, training, sv):

@@ -963,3 +963,4 @@ def test_softmax_gather(ops):
     ref = torch.softmax(last.float(), dim=1).index_select(1, ids)
     assert got.shape == (B, 6) and rel_fro(got, ref) < 1e-5
     assert ops.softmax_gather(last, torch.tensor([V + 3], device='cuda')).abs().max().item() == 0.0
+

@@ -33,6 +33,7 @@ def make(arm):
         _lib.lib.ph_layernorm_tuning(spec['ln_mode'])
     if 'attn_mode' in spec:
         _lib.lib.ph_attention_tuning(spec['attn_mode'])
+    restore = []
     extra = spec.get('trainer', {})
     if extra:
         from prismer_amd import trainer as T
@@ -48,6 +49,8 @@ def make(arm):
             loss = tr.step()
         torch.cuda.synchronize()
     finally:
+        for r in restore:
+            r()
         if extra:
             T.Trainer.__init__ = orig
         _lib.lib.ph_gemm_tuning(*_lib.GEMM_BIG_DEFAULT)
