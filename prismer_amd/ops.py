@@ -845,6 +845,9 @@ def weighted_sum(x, weights, scale, out=None):
     return out
 
 
+_ELEM_SIZE = {}
+
+
 def zeros(shape, dtype, device):
     """torch.zeros through the library: an empty tensor + ONE ph_fill_zero launch (no stock torch kernel, no memset node in a captured step)."""
     if isinstance(shape, int):
@@ -852,9 +855,13 @@ def zeros(shape, dtype, device):
     n = 1
     for v in shape:
         n *= int(v)
-    nbytes = n * (torch.finfo(dtype).bits if dtype.is_floating_point else (8 if dtype == torch.bool else torch.iinfo(dtype).bits)) // 8
-    assert torch.device(device).type != 'cuda' or torch.cuda.current_device() == (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()), \
-        'ops.zeros fills on the current stream: it must belong to `device`'
+    esz = _ELEM_SIZE.get(dtype)
+    if esz is None:
+        esz = _ELEM_SIZE[dtype] = (torch.finfo(dtype).bits if dtype.is_floating_point else (8 if dtype == torch.bool else torch.iinfo(dtype).bits)) // 8
+    nbytes = n * esz
+    dev = device if isinstance(device, torch.device) else torch.device(device)
+    # the fill runs on the calling thread's current stream: that stream must belong to `device` (round-5 advisor finding)
+    assert dev.type != 'cuda' or dev.index is None or dev.index == torch.cuda.current_device(), 'ops.zeros: `device` is not the current device'
     pad = (nbytes + 15) // 16 * 16
     buf = torch.empty(pad, dtype=torch.uint8, device=device)              # (the caching allocator aligns to 512 B)
     check(lib.ph_fill_zero(buf.data_ptr(), pad, _stream()), 'ph_fill_zero')

@@ -16,6 +16,7 @@ from prismer_amd import _lib
 
 ARMS = {
     'base': dict(),
+    'r5_kernels': dict(gemm_mode=6, attn_mode=2),   # the round-5 kernel selection: LEAN loop without SPREAD, streaming attention backward
     'gemm6': dict(gemm_mode=6),
     'gemm7': dict(gemm_mode=7),
     'attn_stream': dict(attn_mode=2),            # ph_attention_tuning(2): without the head-resident backward kernels
