@@ -62,7 +62,7 @@ def _worker(rank, world, port, use_graph, out, payload='bf16', n_steps=2, shard=
                      params=[st.master[:st.n_train].float().cpu() for st in tr.stores], trace=list(tr.trace),
                      shadow=[st.shadow[:st.n_train].float().cpu() for st in tr.stores], m=[t.float().cpu() for t in tr.m],
                      bounds=[tr._shard_bounds(i) for i in range(2)], pieces=sorted(tr.piece_state), post_scale=tr._post_scale(),
-                     log=list(tr.exchange.log), desc=tr.exchange.describe() if tr.exchange.log_last else None,
+                     log=list(tr.exchange.log), desc=tr.exchange_desc() if tr.exchange.log_last else None,
                      n_train=[st.n_train for st in tr.stores])
     dist.barrier()
     dist.destroy_process_group()
@@ -104,6 +104,20 @@ def test_two_ranks_bf16_payload_close_to_fp32():
     assert res['fp32']['post_scale'] == 0.5 and res['bf16']['post_scale'] == 1.0      # fp32: SUM, averaged in AdamW; bf16: pre-scaled, already the mean
     for g32, g16 in zip(res['fp32']['grads'], res['bf16']['grads']):
         assert ((g16 * world - g32).norm() / g32.norm()).item() < 1e-2
+
+
+def test_two_ranks_auto_payload_keeps_ddp_payload_and_reports_the_decision():
+    """grad_payload='auto' (round 6; what bench.py --gpus N passes): below four ranks the DDP payload is kept without a probe, and the decision travels
+    with the exchange description (the bench line's grad_exchange.payload_decision); from four ranks on a probe all-reduce decides (needs hardware)"""
+    world = 2
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), True, out, 'auto', 2), nprocs=world, join=True)
+    for r in (0, 1):
+        d = out[r]['desc']
+        assert d['payload'] == 'fp32' and d['post_scale'] == 0.5
+        assert d['payload_decision']['requested'] == 'auto' and d['payload_decision']['chosen'] == 'fp32' and d['payload_decision']['world'] == 2
+    for pa, pb in zip(out[0]['params'], out[1]['params']):
+        assert torch.equal(pa, pb)
 
 
 def test_native_comm_single_rank_allreduce():
