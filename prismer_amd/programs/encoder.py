@@ -96,11 +96,25 @@ class EncoderProgram:
             mine = [m for m in module.conv1[dom] if isinstance(m, torch.nn.BatchNorm2d)]
             self._bn_range[dom] = (len(bns), len(mine))
             bns += mine
-        self._bn_flat, self._bn_mods = None, bns
+        self._bn_flat, self._bn_mods, self._bn_stats_flat = None, bns, None
         if bns:
             self._bn_flat = torch.stack([m.num_batches_tracked.reshape(()) for m in bns]).to(torch.int64).contiguous()
             for i, m in enumerate(bns):
                 m._buffers['num_batches_tracked'] = self._bn_flat[i]
+            # round 6: running_mean / running_var of every stem layer are views of ONE fp32 buffer as well (16-B aligned pieces), so that DDP's
+            # per-step buffer broadcast (train_caption.py:117: DistributedDataParallel(broadcast_buffers=True)) is two collectives
+            # -- this buffer and the counters -- instead of 72 (Trainer(broadcast_buffers=True))
+            pieces, off = [], 0
+            for m in bns:
+                for nm in ('running_mean', 'running_var'):
+                    t = m._buffers[nm]
+                    pieces.append((m, nm, off, t.numel()))
+                    off += (t.numel() + 3) // 4 * 4
+            flat = torch.zeros(off, dtype=F32, device=self._bn_flat.device)
+            for m, nm, o, n in pieces:
+                flat[o:o + n].copy_(m._buffers[nm].reshape(-1).float())
+                m._buffers[nm] = flat[o:o + n]
+            self._bn_stats_flat = flat
         W = d.width
         self.Kp_rgb = _rup(3 * d.patch_size ** 2, 8)
         self.experts = [e for e in d.experts if e != 'rgb']
@@ -496,9 +510,10 @@ class EncoderProgram:
     def _advance_bn_counters(self, names):
         """num_batches_tracked += 1 for the stems that ran (vit.py:86-120: only the experts present in the batch go through their conv1)"""
         lo, flat = self._bn_flat.data_ptr(), self._bn_flat
+        slo, sflat = self._bn_stats_flat.data_ptr(), self._bn_stats_flat
         for m in (self._bn_mods[0], self._bn_mods[-1]):      # Module._apply (.to / .double) replaces ALL buffers: the views would silently stop advancing
-            p = m.num_batches_tracked.data_ptr()
-            if not (lo <= p < lo + flat.numel() * 8):
+            p, q = m.num_batches_tracked.data_ptr(), m.running_var.data_ptr()
+            if not (lo <= p < lo + flat.numel() * 8) or not (slo <= q < slo + sflat.numel() * 4):
                 raise RuntimeError('a BatchNorm counter no longer aliases the program\'s counter buffer (module moved or cast after the '
                                    'program was built): rebuild the program (module._prog = None)')
         # one advance per CALL of a stem: the reference runs conv1['seg'] once per seg_* expert of the batch (vit.py:136-139), so two seg experts advance

@@ -17,8 +17,8 @@ stems' backward runs, only the stems' own gradients wait on the critical path.
 Data parallel semantics = DDP's: every rank holds all parameters, gradients are summed over ranks in fp32 and divided by
 world size (folded into the AdamW kernel as grad_scale; `grad_payload='bf16'` is an opt-in that halves the bytes: each rank
 pre-scales by 1/world and rounds to bf16 before the sum), BatchNorm uses per-rank batch statistics (no SyncBN in the
-reference).  DDP's per-step buffer broadcast from rank 0 is replaced by rank-local BN running statistics
-(documented deviation).
+reference).  DDP's per-step buffer broadcast from rank 0 is replaced by rank-local BN running statistics by default
+(documented deviation); Trainer(broadcast_buffers=True) restores DDP's semantics with two collectives per step.
 """
 import contextlib
 import math
@@ -41,7 +41,7 @@ class Trainer:
     def __init__(self, model, lr=5e-5, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8, min_lr=0.0, total_steps=1000,
                  task='caption', use_graph=True, process_group=None, bucket_mb=64, side_stream=False, micro_batches=1, keep_grads=False,
                  max_text_len=None, grad_payload='fp32', transport='torch.distributed', dec_backward_stages=3, lr_schedule=None,
-                 shard_optimizer=False, overwrite_single_writer=True, allow_eager_fallback=False):
+                 shard_optimizer=False, overwrite_single_writer=True, allow_eager_fallback=False, broadcast_buffers=False):
         self.model = model
         self.enc, self.dec = model.expert_encoder, model.text_decoder
         self.init_lr, self.min_lr, self.total_steps = lr, min_lr, total_steps
@@ -141,6 +141,10 @@ class Trainer:
         self._exclusive, self._keep_maps, self._count_config = None, None, None
         self._graph_no_fill = False
         self._host_comm_s, self._host_comm_steps = 0.0, 0
+        # DDP(broadcast_buffers=True) semantics (what accelerate wraps the model in, train_caption.py:117): before every forward rank 0's BatchNorm
+        # running statistics and counters overwrite everybody's.  Off by default: rank-local statistics, the documented deviation of SURVEY 8e
+        # (a per-step collective in front of the forward for buffers no training computation reads)
+        self.broadcast_buffers = bool(broadcast_buffers) and self.world > 1
         self._step_open = False                # a step was started and did not reach its last segment (exception between replays)
         if self.world > 1:
             self.broadcast_parameters()
@@ -154,6 +158,15 @@ class Trainer:
         for mod in (self.enc, self.dec):
             for b in mod.buffers():
                 torch.distributed.broadcast(b, 0, group=self.pg)
+
+    def sync_buffers(self):
+        """rank 0's BatchNorm running statistics and num_batches_tracked -> every rank (DDP's _sync_module_buffers before each forward), two
+        collectives on the compute stream: the programs keep these buffers as views of two flat tensors"""
+        ep = self.enc_prog
+        if self.world == 1 or ep._bn_stats_flat is None:
+            return
+        self._bcast(ep._bn_stats_flat, 0)
+        self._bcast(ep._bn_flat.view(torch.float32) if self._native_comm is not None else ep._bn_flat, 0)
 
     def _make_exchange(self, payload, transport):
         if self.world == 1:
@@ -801,6 +814,8 @@ class Trainer:
                 self.graphs, self.use_graph = None, False
                 ops.join_side()
         self._host_prologue()
+        if self.broadcast_buffers:
+            self.sync_buffers()
         if self.exchange is not None:
             self.exchange.begin_step()
         self.trace = []                                         # host enqueue order of compute segments and bucket hand-offs

@@ -17,7 +17,7 @@ def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, use_graph, out, payload='bf16', n_steps=2, shard=False, backend='gloo', own_device=False, transport='torch.distributed'):
+def _worker(rank, world, port, use_graph, out, payload='bf16', n_steps=2, shard=False, backend='gloo', own_device=False, transport='torch.distributed', bcast_buffers=False):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
@@ -46,7 +46,7 @@ def _worker(rank, world, port, use_graph, out, payload='bf16', n_steps=2, shard=
     m = Holder(); m.expert_encoder, m.text_decoder = enc, dec
     tab = case.instance_table(x)
     tr = Trainer(m, lr=1e-3, total_steps=10, use_graph=use_graph, keep_grads=True, grad_payload=payload, dec_backward_stages=2,
-                 shard_optimizer=shard, transport=transport)
+                 shard_optimizer=shard, transport=transport, broadcast_buffers=bcast_buffers)
     assert tr.world == world and tr.dec_cuts == [2, 1, 0]
     tr.set_batch(T.to_dev(x), ids, mask, labels)
     orig = tr._host_prologue
@@ -58,7 +58,12 @@ def _worker(rank, world, port, use_graph, out, payload='bf16', n_steps=2, shard=
     for _ in range(n_steps):
         loss = tr.step()
     torch.cuda.synchronize()
-    out[rank] = dict(loss=float(loss), grads=[st.grad[:st.n_train].float().cpu() for st in tr.stores],
+    bn_before = (tr.enc_prog._bn_stats_flat.clone().cpu(), tr.enc_prog._bn_flat.clone().cpu())
+    tr.sync_buffers()                                          # (what the NEXT step would start with under broadcast_buffers=True)
+    torch.cuda.synchronize()
+    bn_after = (tr.enc_prog._bn_stats_flat.clone().cpu(), tr.enc_prog._bn_flat.clone().cpu())
+    bn_mod = {k: v.detach().float().cpu() for k, v in enc.state_dict().items() if 'running_' in k or 'num_batches' in k}
+    out[rank] = dict(loss=float(loss), bn_before=bn_before, bn_after=bn_after, bn_mod=bn_mod, grads=[st.grad[:st.n_train].float().cpu() for st in tr.stores],
                      params=[st.master[:st.n_train].float().cpu() for st in tr.stores], trace=list(tr.trace),
                      shadow=[st.shadow[:st.n_train].float().cpu() for st in tr.stores], m=[t.float().cpu() for t in tr.m],
                      bounds=[tr._shard_bounds(i) for i in range(2)], pieces=sorted(tr.piece_state), post_scale=tr._post_scale(),
@@ -118,6 +123,32 @@ def test_two_ranks_auto_payload_keeps_ddp_payload_and_reports_the_decision():
         assert d['payload_decision']['requested'] == 'auto' and d['payload_decision']['chosen'] == 'fp32' and d['payload_decision']['world'] == 2
     for pa, pb in zip(out[0]['params'], out[1]['params']):
         assert torch.equal(pa, pb)
+
+
+def test_broadcast_buffers_gives_every_rank_rank0_batchnorm_state():
+    """Trainer(broadcast_buffers=True) = DistributedDataParallel's default (train_caption.py:117 through accelerate): before every forward
+    rank 0's BatchNorm running statistics and num_batches_tracked overwrite everybody's.  Two ranks with DIFFERENT batches: without the option the
+    statistics diverge (the documented default); the buffer sync makes rank 1 equal to rank 0's state bit for bit, through the module's own
+    state_dict tensors (they are views of the two flat buffers that travel)."""
+    world = 2
+    res = {}
+    for bb in (False, True):
+        mgr = mp.Manager(); out = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), True, out, 'fp32', 2, False, 'gloo', False, 'torch.distributed', bb), nprocs=world, join=True)
+        res[bb] = (out[0], out[1])
+    for bb in (False, True):
+        a, b = res[bb]
+        assert not torch.equal(a['bn_before'][0], b['bn_before'][0])                 # different batches: the local updates of the last step differ
+        assert torch.equal(a['bn_after'][0], b['bn_after'][0]) and torch.equal(a['bn_after'][1], b['bn_after'][1])
+        assert torch.equal(a['bn_after'][0], a['bn_before'][0])                      # rank 0 is the source
+        assert int(a['bn_after'][1].min()) == 2                                      # two steps
+        for k, v in b['bn_mod'].items():
+            assert torch.equal(v, a['bn_mod'][k]), k
+    # with the per-step broadcast rank 1 entered step 2 with rank 0's statistics: its last local update starts from another base than without
+    assert not torch.equal(res[True][1]['bn_before'][0], res[False][1]['bn_before'][0])
+    d0 = (res[True][0]['bn_before'][0] - res[False][0]['bn_before'][0]).norm() / res[False][0]['bn_before'][0].norm()
+    d1 = (res[True][1]['bn_before'][0] - res[False][1]['bn_before'][0]).norm() / res[False][1]['bn_before'][0].norm()
+    assert d0 < 1e-3 and d1 > 10 * d0, (float(d0), float(d1))   # rank 0 never receives anything (run-to-run atomics noise only); rank 1's base moved
 
 
 def test_native_comm_single_rank_allreduce():
