@@ -164,7 +164,11 @@ __device__ __forceinline__ float score_of(float s, float scale, float kstate, bo
 // instructions per element); only a tile that crosses the end of the sequence pays a bounds select.
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
+#ifdef PH_ATTN_NOEXP           // timing diagnostic (tools/build_variant.py attention.hip:-DPH_ATTN_NOEXP): WRONG results, the exponential replaced by one fma
+__device__ __forceinline__ float fast_exp2(float x) { return fmaf(x, 1e-3f, 1.0f); }
+#else
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+#endif
 
 // =====================================================================================================
 // forward
@@ -939,6 +943,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 15, g = lane >> 4;
   const ResOff ro = res_offsets(lane);
+  PH_TL_DECL;
+  PH_TL(0);
   const BlockXY bxy = block_xy(split, f.B * f.H);
   const int b = bxy.y / f.H, h = bxy.y % f.H;
   const bf16* Q = reinterpret_cast<const bf16*>(f.q) + b * f.q_bs + (int64_t)h * DH;
@@ -962,7 +968,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     l_ = lse_base[qr];
   };
   if (sub < s_hi) qload(sub, qf, dof, lse);
+  PH_TL(1);
   __syncthreads();
+  PH_TL(2);
+  int tl_first__ = 1;
   const float c2 = f.scale * LOG2E;
   for (; sub < s_hi; sub += 4) {
     int sk = f.Sk;
@@ -971,56 +980,77 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     f32x2 part = {0.f, 0.f};
     const float l2 = lse * LOG2E;
     const f32x2 c2v = {c2, c2}, nl = {-l2, -l2};
-    bf16x8 kfr[2][KS], vfr[2][KS];                       // one tile ahead (explicit: the fences below keep the scheduler from hoisting ALL tiles)
+    // Software pipeline over the key tiles, three stages deep, written out by hand (round 6, timeline: a tile cost 265 cycles = LDS latency + two dependent
+    // MFMA pairs + the exponentials IN SEQUENCE, and two waves per SIMD cannot hide that): step s requests the fragments of tile s, multiplies tile s - 1
+    // (fragments requested a step ago) and runs the exponentials of tile s - 2 (accumulators finished a step ago) -- three independent instruction groups.
+    bf16x8 kfr[2][KS], vfr[2][KS];
+    f32x4 sacc[2], dacc[2];
+    static_for(std::make_integer_sequence<int, NT + 2>{}, [&](auto s_c) {
+      constexpr int st = decltype(s_c)::value;
+      if constexpr (st >= 1 && st <= NT) {
+        constexpr int nt = st - 1;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) { kfr[0][ks] = rfrag_rows(kl, 0, ks, ro); vfr[0][ks] = rfrag_rows(vl, 0, ks, ro); }
-    static_for(std::make_integer_sequence<int, NT>{}, [&](auto nt_c) {
-      constexpr int nt = decltype(nt_c)::value;
-      if constexpr (nt + 1 < NT) {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) { kfr[(nt + 1) & 1][ks] = rfrag_rows(kl, (nt + 1) * 16, ks, ro); vfr[(nt + 1) & 1][ks] = rfrag_rows(vl, (nt + 1) * 16, ks, ro); }
-      }
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[nt & 1][ks], qf[ks], acc, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[nt & 1][ks], dof[ks], dp, 0, 0, 0);
-      }
-      const bool tail = nt * 16 + 16 > sk;
-#pragma unroll
-      for (int r = 0; r < 4; r += 2) {
-        f32x2 x = {acc[r], acc[r + 1]};
-        x = __builtin_elementwise_fma(x, c2v, nl);
-        f32x2 p2 = {fast_exp2(x[0]), fast_exp2(x[1])};
-        if (tail) {
-          asm volatile("");                            // (a real branch: if-converted, the selects ran on all NT tiles -- 207 VALU instructions per sub-tile)
-          p2[0] = (nt * 16 + g * 4 + r < sk) ? p2[0] : 0.f;
-          p2[1] = (nt * 16 + g * 4 + r + 1 < sk) ? p2[1] : 0.f;
+        for (int ks = 0; ks < KS; ++ks) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[nt & 1][ks], qf[ks], acc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[nt & 1][ks], dof[ks], dp, 0, 0, 0);
         }
-        const f32x2 dd = {dp[r], dp[r + 1]};
-        part = __builtin_elementwise_fma(p2, dd, part);
-        P[nt][r] = p2[0]; P[nt][r + 1] = p2[1];
+        sacc[nt & 1] = acc; dacc[nt & 1] = dp;
       }
-      DP[nt] = dp;
-      asm volatile("" ::: "memory");                                   // (keeps the scheduler from hoisting all NT tiles' fragment reads: spills)
+      if constexpr (st < NT) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { kfr[st & 1][ks] = rfrag_rows(kl, st * 16, ks, ro); vfr[st & 1][ks] = rfrag_rows(vl, st * 16, ks, ro); }
+      }
+      if constexpr (st >= 2) {
+        constexpr int nt = st - 2;
+        const f32x4 acc = sacc[nt & 1], dp = dacc[nt & 1];
+        const bool tail = nt * 16 + 16 > sk;
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          f32x2 x = {acc[r], acc[r + 1]};
+          x = __builtin_elementwise_fma(x, c2v, nl);
+          f32x2 p2 = {fast_exp2(x[0]), fast_exp2(x[1])};
+          if (tail) {
+            asm volatile("");                            // (a real branch: if-converted, the selects ran on all NT tiles -- 207 VALU instructions per sub-tile)
+            p2[0] = (nt * 16 + g * 4 + r < sk) ? p2[0] : 0.f;
+            p2[1] = (nt * 16 + g * 4 + r + 1 < sk) ? p2[1] : 0.f;
+          }
+          const f32x2 dd = {dp[r], dp[r + 1]};
+          part = __builtin_elementwise_fma(p2, dd, part);
+          P[nt][r] = p2[0]; P[nt][r + 1] = p2[1];
+        }
+        DP[nt] = dp;
+      }
+      __builtin_amdgcn_sched_barrier(0);
     });
+    if (tl_first__) PH_TL(3);
     if (sub + 4 < s_hi) qload(sub + 4, qn, don, lsen);          // (behind the P / dP pass: 17 registers fewer live across it)
     const float delta = xor_sum(part[0] + part[1]);
+    if (tl_first__) PH_TL(4);
     const int qi = sub * 16 + c;
-    if (g == 0 && qi < f.Sq) a.delta[(int64_t)(b * f.H + h) * f.Sq + qi] = delta;      // consumed by the dK/dV kernel (launched after this one)
+    if (g == 0 && qi < f.Sq)
+      a.delta[(int64_t)(b * f.H + h) * f.Sq + qi] = delta;      // consumed by the dK/dV kernel (launched after this one)
     f32x4 dq[DT];
 #pragma unroll
     for (int d = 0; d < DT; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 ktr[2][DT];
+    // same three-stage pipeline over the 32-key steps: transposed K fragments of step s, dS of step s - 1 packed, dQ MFMAs of step s - 2
+    constexpr int NK2 = (NT + 1) / 2;
+    bf16x8 ktr[3][DT], dsf[2];
+    static_for(std::make_integer_sequence<int, NK2 + 2>{}, [&](auto s_c) {
+      constexpr int st = decltype(s_c)::value;
+      if constexpr (st >= 2) {
+        constexpr int k2 = st - 2;
+        if (k2 * 32 < sk) {
 #pragma unroll
-    for (int d = 0; d < DT; ++d) ktr[0][d] = rfrag_tr(kl, 0, d, ro);
-    static_for(std::make_integer_sequence<int, (NT + 1) / 2>{}, [&](auto k2_c) {
-      constexpr int k2 = decltype(k2_c)::value;
-      if constexpr (k2 + 1 < (NT + 1) / 2) {
-#pragma unroll
-        for (int d = 0; d < DT; ++d) ktr[(k2 + 1) & 1][d] = rfrag_tr(kl, (k2 + 1) * 32, d, ro);
+          for (int d = 0; d < DT; ++d) dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktr[k2 % 3][d], dsf[k2 & 1], dq[d], 0, 0, 0);
+        }
       }
-      if (k2 * 32 < sk) {
+      if constexpr (st < NK2) {
+#pragma unroll
+        for (int d = 0; d < DT; ++d) ktr[st % 3][d] = rfrag_tr(kl, st * 32, d, ro);
+      }
+      if constexpr (st >= 1 && st <= NK2) {
+        constexpr int k2 = st - 1;
         f32x4 ds0, ds1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1028,12 +1058,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           if constexpr (2 * k2 + 1 < NT) ds1[r] = P[2 * k2 + 1][r] * (DP[2 * k2 + 1][r] - delta);
           else ds1[r] = 0.f;
         }
-        const bf16x8 dsf = pack2(ds0, ds1);
-#pragma unroll
-        for (int d = 0; d < DT; ++d) dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktr[k2 & 1][d], dsf, dq[d], 0, 0, 0);
+        dsf[k2 & 1] = pack2(ds0, ds1);
       }
-      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
     });
+    if (tl_first__) PH_TL(5);
     if (qi < f.Sq) {
       bf16* dQ = reinterpret_cast<bf16*>(a.dq) + b * a.dq_bs + (int64_t)qi * a.dq_ts + (int64_t)h * DH;
 #pragma unroll
@@ -1045,7 +1074,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) { qf[ks] = qn[ks]; dof[ks] = don[ks]; }
     lse = lsen;
+    if (tl_first__) PH_TL(6);
+    tl_first__ = 0;
   }
+  PH_TL(8);
+#ifdef PH_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PH_TL(9);
+  PH_TL_FLUSH((int)blockIdx.x, 0, threadIdx.x == 0);
+#endif
 }
 
 // dK / dV: Q, dO and the per-query statistics of the whole head resident (rows = Sq rounded up to 32); a wave walks 16-key sub-tiles
