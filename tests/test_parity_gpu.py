@@ -490,7 +490,8 @@ def _check_grads_against_golden(g, named_grads, tag):
 PROJ_SLACK = 1.8
 
 
-@pytest.mark.parametrize('name', ['base_b8', 'zbase_b4', 'large_vqa_b1', 'large_vqa_b1+big', 'base_b32', 'large_vqa_b4', 'huge_b1', 'zbase_b32', 'large_vqa_b16'])
+@pytest.mark.parametrize('name', ['base_b8', 'zbase_b4', 'large_vqa_b1', 'base_b32', 'large_vqa_b4', 'huge_b1', 'zbase_b32', 'large_vqa_b16'])      # ('large_vqa_b1+big', the forced-dispatch
+# variant of rounds 3-5, is superseded by large_vqa_b4 / large_vqa_b16, where the dispatch picks the 256x128 kernels unforced; `name + '+big'` still works)
 def test_trainer_hipgraph_step_matches_reference_golden(name):
     force_big = name.endswith('+big')           # LARGE shapes (H = 1024, 24 + 24 layers, S = 1220) through the 256x128 ping-pong kernel:
     name = name.split('+')[0]                   # at B = 1 the cost model never picks it, config 5's bs16 does
