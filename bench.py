@@ -259,7 +259,7 @@ def cpu_baseline(seconds_budget=30.0, only_cores=None):
                        note + f' (host has {ncpu} logical cpus)')
 
 
-def dropin_leg(steps=10, warmup=3, batch=32):
+def dropin_leg(steps=10, warmup=3, batch=32, fused=False):
     """What the reference's own loop gets from the drop-in modules (train_caption.py:121-136): `loss = model(experts, caption, prefix=...)`,
     `loss.backward()`, `torch.optim.AdamW.step()` -- each top module one torch.autograd.Function over the HIP layer programs, parameter
     gradients handed to autograd, PyTorch's optimizer on the fp32 masters (bf16 shadows refreshed on the next forward).  No hipGraph."""
@@ -269,7 +269,8 @@ def dropin_leg(steps=10, warmup=3, batch=32):
     dims = pcfg.prismer_base()
     model = PrismerCaption({'experts': pcfg.CAPTION_EXPERTS, 'image_resolution': 224, 'prismer_model': 'prismer_base', 'freeze': 'freeze_vision'}).cuda()
     model.train()
-    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=5e-5, weight_decay=0.05)
+    from prismer_amd.optim import AdamW as FusedAdamW            # (same interface; one launch per parameter store instead of torch's multi-tensor passes)
+    opt = (FusedAdamW if fused else torch.optim.AdamW)([p for p in model.parameters() if p.requires_grad], lr=5e-5, weight_decay=0.05)
     x, ids, mask, _ = make_inputs(dims, batch, 30, 1234, torch.device('cuda'))
     caption = {'input_ids': ids, 'attention_mask': mask}
 
@@ -289,10 +290,12 @@ def dropin_leg(steps=10, warmup=3, batch=32):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     check_loss('dropin', first, loss.item())
+    if fused:
+        assert opt.fused_launches >= 1 and opt.plain_updates == 0, 'the fused optimizer fell back to per-tensor updates'
     return dict(value=round(batch * steps / dt, 2), unit='images/sec', batch=batch, steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 3),
                 hip_graph=False, first_loss=round(float(first), 4), final_loss=round(float(loss.item()), 4),
-                config='Prismer-BASE caption fine-tune through the drop-in nn.Modules: model(experts, caption) -> loss.backward() -> torch.optim.AdamW '
-                       '(reference loop train_caption.py:126-135), eager launches')
+                config='Prismer-BASE caption fine-tune through the drop-in nn.Modules: model(experts, caption) -> loss.backward() -> ' +
+                       ('prismer_amd.optim.AdamW' if fused else 'torch.optim.AdamW') + ' (reference loop train_caption.py:126-135), eager launches')
 
 
 def loader_leg(steps=10, warmup=3, batch=32):
@@ -536,7 +539,8 @@ def main():
                 except Exception as e:                     # a secondary leg must never take the headline line down
                     sec[wl] = dict(error=f'{type(e).__name__}: {e}'[:300])
             # round 4: the two boundaries the library advertises besides the native Trainer, under the same clock
-            for name, leg in (('dropin', dropin_leg), ('loader', loader_leg)):
+            # round 6: 'dropin_fused_adamw' = the same reference loop with prismer_amd.optim.AdamW in place of torch.optim.AdamW
+            for name, leg in (('dropin', dropin_leg), ('dropin_fused_adamw', lambda: dropin_leg(fused=True)), ('loader', loader_leg)):
                 try:
                     sec[name] = leg()
                 except Exception as e:

@@ -13,8 +13,13 @@ BF16 = torch.bfloat16
 F32 = torch.float32
 
 
+_raw_stream, _cur_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """the current HIP stream's handle (what torch.cuda.current_stream().cuda_stream returns, without building the Stream object: the
+    eager drop-in step asks ~2000 times and is bound by host time, not by the GPU)"""
+    return _raw_stream(_cur_device())
 
 
 class Dropout:
@@ -35,7 +40,7 @@ def _workspace(device, which=0):
     """per-(device, stream) fp32 scratch for split-K partial tiles / LayerNorm partials: kernels on one stream are
     serialised, so one buffer per stream is race-free (allocated once, reused by every launch on that stream).
     which = 1: the separate buffer that holds the partial sums of DEFERRED fold passes until gemm_flush_deferred()"""
-    key = (device, torch.cuda.current_stream(device).cuda_stream, which)
+    key = (device, _raw_stream(device.index if device.index is not None else _cur_device()), which)
     ws = _WS.get(key)
     if ws is None:
         ws = torch.empty(WS_BYTES // 4, dtype=F32, device=device)

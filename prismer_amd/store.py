@@ -106,6 +106,8 @@ class ParamStore:
         self.attached = True
         self._freeze_sig = tuple(named[n].requires_grad for n in self.names)
         self.refresh()
+        from . import optim
+        optim.register(self)                 # (prismer_amd.optim.AdamW recognises these parameters and updates the store with one fused launch)
         return self
 
     def check_layout(self):
