@@ -315,15 +315,15 @@ def loader_leg(steps=10, warmup=3, batch=32):
     first = tr.step().item()
     tr.prefetch_batch(*batches[1])
     for i in range(1, warmup):
-        tr.commit_prefetched(); tr.prefetch_batch(*batches[(i + 1) % 3]); tr.step()
+        tr.commit_prefetched(); tr.step(); tr.prefetch_batch(*batches[(i + 1) % 3])
     torch.cuda.synchronize()
     losses = []
     t0 = time.perf_counter()
     for i in range(steps):                                  # batch i+1 travels over PCIe while step i runs (Trainer.prefetch_batch)
         tr.commit_prefetched()
-        tr.prefetch_batch(*batches[(warmup + i + 1) % 3])
         loss = tr.step()
-        losses.append(loss.clone())                         # (device-side copy: no host synchronisation inside the timed loop)
+        losses.append(loss.clone())                         # (device-side copy: the loss is only read after the timed loop)
+        tr.prefetch_batch(*batches[(warmup + i + 1) % 3])   # (waits on the HOST until the device has started the step just enqueued: see Trainer.prefetch_batch)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     for l in losses:

@@ -32,8 +32,8 @@ typedef struct ihipStream_t* hipStream_t;
 
 /* ABI revision: bumped whenever an argument struct or a signature changes (101: ph_conv_gather window fields, ph_gemm_args row map +
  * defer_reduce; 102: round 4; 103: round 5 -- ph_ce_fwd takes a row_loss scratch, no memset nodes anywhere; 104: round 6 -- ph_dense_minmax_partial,
- * ph_resize_remap_nchw_to_nhwc, ph_softmax_gather_bf16, new values of ph_gemm_tuning / ph_attention_tuning).  A host built against another revision must refuse to run: ph_version() != PH_VERSION. */
-#define PH_VERSION 104
+ * ph_resize_remap_nchw_to_nhwc, ph_softmax_gather_bf16, new values of ph_gemm_tuning / ph_attention_tuning; 105: ph_store_words).  A host built against another revision must refuse to run: ph_version() != PH_VERSION. */
+#define PH_VERSION 105
 
 enum { PH_OK = 0, PH_ERR_BAD_ARG = -1, PH_ERR_UNSUPPORTED = -2, PH_ERR_LAUNCH = -3 };
 enum { PH_ACT_NONE = 0, PH_ACT_QUICKGELU = 1, PH_ACT_RELU2 = 2, PH_ACT_GELU = 3, PH_ACT_RELU = 4,
@@ -396,6 +396,12 @@ int ph_gemm_dispatch_counts(int64_t* out, int n, int reset);
  *   PH_WS_CONV_COLSTATS   dims = {N}:       ph_gemm_args.col_stats ([PH_COLSTAT_SLABS][2][N] fp64, zeroed by the caller) */
 enum { PH_WS_GEMM_SPLITK = 0, PH_WS_LAYERNORM_BWD = 1, PH_WS_ATTENTION_BWD = 2, PH_WS_CONV_COLSTATS = 3 };
 int64_t ph_query_workspace(int op, const int64_t* dims, int ndims);
+/* per-step host scalars written by a kernel whose ARGUMENTS carry them (no copy engine, no pinned staging): dst0[0..n0) and dst1[0..n1)
+ * (32-bit words, device memory; dst1 may be NULL with n1 = 0) <- host_words[0..n0+n1), read before the call returns.  Replaces the two
+ * pinned host-to-device copies per step of the learning rate / Adam bias corrections (train_caption.py:127, torch.optim.AdamW's step
+ * count) and the instance-embedding draws (vit.py:145-147).  n0 + n1 <= PH_STORE_WORDS_MAX. */
+#define PH_STORE_WORDS_MAX 320
+int ph_store_words(void* dst0, int n0, void* dst1, int n1, const uint32_t* host_words, hipStream_t stream);
 /* advance the dropout seed (device-side, graph-replay safe): seed[0] = splitmix(seed[0]) */
 int ph_advance_seed(uint64_t* seed, hipStream_t stream);
 /* step glue (round 4: the last stock torch kernels inside the captured step).  x[i] += value for n int64 counters -- BatchNorm's

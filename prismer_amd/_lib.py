@@ -185,6 +185,7 @@ _SIGS = {
     'ph_conv_weight_to_shadow': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ph_conv_grad_from_shadow': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ph_advance_seed': (c_int, [c_void_p, c_void_p]),
+    'ph_store_words': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'ph_add_i64': (c_int, [c_void_p, c_int, c_i64, c_void_p]),
     'ph_fill_zero': (c_int, [c_void_p, c_i64, c_void_p]),
     'ph_copy_bytes': (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
@@ -216,7 +217,7 @@ def _load():
 
 lib, LIB_PATH = _load()
 GEMM_BIG_DEFAULT = (7, 128)    # ph_gemm_tuning(mode, min_tiles) values of the product dispatch (tests / probes restore them after an override)
-ABI_VERSION = 104          # PH_VERSION of include/prismer_hip.h these ctypes structures mirror
+ABI_VERSION = 105          # PH_VERSION of include/prismer_hip.h these ctypes structures mirror
 if lib.ph_version() != ABI_VERSION:
     raise ImportError(f'{LIB_PATH} reports ABI revision {lib.ph_version()}, this binding was written for {ABI_VERSION} '
                       '(stale build? run `python -m prismer_amd.build --force`)')

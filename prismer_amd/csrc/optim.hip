@@ -558,6 +558,29 @@ extern "C" int ph_conv_dgrad_shadow_grouped(const ph_conv_dgrad_item* items, int
   PH_LAUNCH_CHECK("conv_dgrad_shadow_grouped_kernel");
   return PH_OK;
 }
+// ---- per-step host scalars without a copy engine (round 6): the learning rate / Adam bias corrections and the instance-embedding draw
+// table travel in the KERNEL ARGUMENTS (<= 1.25 KB by value) instead of two pinned hipMemcpyAsync.  Those copies ran on the SDMA queue the
+// loader's 56-MB host-to-device prefetch also uses, and the compute stream waited behind it at the start of every step
+// (tools/loader_probe.py: +0.45 ms per step with a loader attached).
+namespace {
+struct StepWords { uint32_t w[PH_STORE_WORDS_MAX]; };
+__global__ void store_words_kernel(uint32_t* __restrict__ dst0, int n0, uint32_t* __restrict__ dst1, int n1, StepWords v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n0) dst0[i] = v.w[i];
+  else if (i < n0 + n1) dst1[i - n0] = v.w[i];
+}
+}  // namespace
+extern "C" int ph_store_words(void* dst0, int n0, void* dst1, int n1, const uint32_t* host_words, hipStream_t stream) {
+  PH_CHECK_ARG(dst0 && host_words && n0 > 0 && n1 >= 0 && (n1 == 0 || dst1) && n0 + n1 <= PH_STORE_WORDS_MAX,
+               "ph_store_words: need dst0, host words and 1 <= n0 + n1 <= %d (got %d + %d)", PH_STORE_WORDS_MAX, n0, n1);
+  ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_store_words");
+  StepWords v;
+  for (int i = 0; i < n0 + n1; ++i) v.w[i] = host_words[i];
+  for (int i = n0 + n1; i < PH_STORE_WORDS_MAX; ++i) v.w[i] = 0u;
+  hipLaunchKernelGGL(store_words_kernel, dim3((n0 + n1 + 255) / 256), dim3(256), 0, stream, (uint32_t*)dst0, n0, (uint32_t*)dst1, n1, v);
+  PH_LAUNCH_CHECK("store_words_kernel");
+  return PH_OK;
+}
 extern "C" int ph_advance_seed(uint64_t* seed, hipStream_t stream) {
   PH_CHECK_ARG(seed, "ph_advance_seed: null");
   ProfScope prof__(PH_FAM_MISC, 0.0, 0.0, stream, "ph_advance_seed");

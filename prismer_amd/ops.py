@@ -3,6 +3,7 @@ HIP stream; every arithmetic step runs in libprismer_hip.so.  No fallbacks: a mi
 """
 import ctypes as C
 import os
+import struct
 
 import torch
 
@@ -888,6 +889,19 @@ def copy_flat(dst, src):
         k = body // dst.element_size()
         dst.reshape(-1)[k:].copy_(src.reshape(-1)[k:])
     return dst
+
+
+STORE_WORDS_MAX = 320
+
+
+def store_words(dst0, vals0, dst1=None, vals1=()):
+    """dst0[:len(vals0)] (fp32 tensor) <- floats, dst1[:len(vals1)] (int32 tensor) <- ints, carried in the arguments of one tiny kernel
+    (no host-to-device copy: see ph_store_words)"""
+    n0, n1 = len(vals0), len(vals1)
+    assert dst0.dtype == F32 and dst0.numel() >= n0 and (n1 == 0 or (dst1.dtype == torch.int32 and dst1.numel() >= n1))
+    words = struct.pack(f'{n0}f{n1}i', *vals0, *vals1)
+    buf = (C.c_uint32 * (n0 + n1)).from_buffer_copy(words)
+    check(lib.ph_store_words(dst0.data_ptr(), n0, ptr(dst1) if n1 else None, n1, buf, _stream()), 'ph_store_words')
 
 
 def advance_seed(seed):

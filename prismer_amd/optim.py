@@ -118,7 +118,7 @@ class AdamW(torch.optim.Optimizer):
                     raise RuntimeError('the parameter store was re-laid out (requires_grad flags changed) after this optimizer took its first step: build a new optimizer')
                 s['step'] += 1
                 t = s['step']
-                s['hyper'].copy_(torch.tensor([lr, 1.0 - b1 ** t, 1.0 - b2 ** t], dtype=torch.float32), non_blocking=True)
+                ops.store_words(s['hyper'], (lr, 1.0 - b1 ** t, 1.0 - b2 ** t))      # (kernel arguments: no host-to-device copy, no stream wait)
                 ops.adamw(st.master, flat, s['m'], s['v'], st.shadow, st.n_train, s['hyper'], b1, b2, eps, wd, 1.0, zero_grad=False)
                 st.refresh_derived()                                             # (the launch wrote the bf16 shadows and bumped no Parameter._version: the store does not see itself as stale)
                 s['step_t'] += 1

@@ -87,11 +87,8 @@ class Trainer:
         self.v = [torch.zeros(max(hi - lo, 1), dtype=F32, device=dev) for lo, hi in own]
         self.piece_state = {}                                  # rs_ag: (store index, a, b) -> (m, v)
         self.hyper = torch.zeros(3, dtype=F32, device=dev)
-        # per-step host values travel through a ring of pinned slots: a slot is rewritten only after the async copy that read
-        # it last has executed (event per slot), so a host that runs ahead of the device (no loss.item() in the loop) can
-        # neither tear the instance table nor hand a step a later step's learning rate
-        self._slots = [dict(hyper=torch.zeros(3, dtype=F32).pin_memory(), table=torch.zeros(256, dtype=torch.int32).pin_memory(),
-                            ev=None) for _ in range(4)]
+        # per-step host values (learning rate, Adam bias corrections, instance draws) travel in the arguments of one tiny kernel
+        # (ops.store_words): stream-ordered like the copies they replace, no pinned staging, no copy engine
         self.table = torch.zeros(256, dtype=torch.int32, device=dev)
         self.seed = self.dec.dropout_seed()
         self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
@@ -595,19 +592,15 @@ class Trainer:
 
     def _host_prologue(self):
         """per-step host work: LR schedule (cosine per ITERATION, train_caption.py:127), Adam bias corrections and the
-        instance-embedding draw table (vit.py:145-147: Python `random`), shipped with two async pinned copies."""
+        instance-embedding draw table (vit.py:145-147: Python `random`), shipped in the arguments of one kernel launch (round 6: the two pinned
+        copies they used to ride queued behind a loader's host-to-device prefetch on the copy engine)."""
         self.it += 1
-        slot = self._slots[self.it % len(self._slots)]
-        if slot['ev'] is not None:
-            slot['ev'].synchronize()
         lr = self.lr_schedule(self.it - 1)
-        slot['hyper'].copy_(torch.tensor([lr, 1.0 - self.betas[0] ** self.it, 1.0 - self.betas[1] ** self.it], dtype=F32))
-        self.hyper.copy_(slot['hyper'], non_blocking=True)
+        hyper = (lr, 1.0 - self.betas[0] ** self.it, 1.0 - self.betas[1] ** self.it)
         if 'obj_detection' in self.enc.experts:
-            slot['table'].copy_(torch.tensor([random.randint(0, 127) for _ in range(256)], dtype=torch.int32))
-            self.table.copy_(slot['table'], non_blocking=True)
-        slot['ev'] = torch.cuda.Event()
-        slot['ev'].record(torch.cuda.current_stream())
+            ops.store_words(self.hyper, hyper, self.table, [random.randint(0, 127) for _ in range(256)])
+        else:
+            ops.store_words(self.hyper, hyper)
 
     # ------------------------------------------------------------------------------------------ public API
     def set_batch(self, experts, input_ids, attention_mask, labels, weights=None):
@@ -677,7 +670,9 @@ class Trainer:
     # ---- input pipeline overlap (round 4): the reference's DataLoader(pin_memory=True) + .to(device, non_blocking=True) hides the
     # host-to-device copy of batch i+1 behind step i (train_caption.py:121-125).  The captured step reads FIXED buffers, so the next batch
     # is staged: prefetch_batch() copies it from (pinned) host memory into a second buffer set on a copy stream, commit_prefetched() moves
-    # it into the static buffers with device-to-device copies (56 MB: tens of microseconds) on the compute stream.
+    # it into the static buffers with device-to-device copies (56 MB: tens of microseconds) on the compute stream.  Loop shape:
+    #     tr.set_batch(first); tr.prefetch_batch(second)
+    #     for nxt in loader:  tr.commit_prefetched(); loss = tr.step(); tr.prefetch_batch(*nxt)
     def prefetch_batch(self, experts, input_ids, attention_mask, labels, weights=None):
         if self.static is None:
             raise RuntimeError('prefetch_batch: bind the first batch with set_batch (it fixes the shapes of the captured program)')
@@ -690,7 +685,12 @@ class Trainer:
             self.copy_stream = torch.cuda.Stream(device=self.device)
             self._staging_ready, self._staging_free = torch.cuda.Event(), torch.cuda.Event()
             self._staging_free.record(torch.cuda.current_stream())
-        self.copy_stream.wait_event(self._staging_free)           # the previous commit has finished reading the staging set
+        # The previous commit must have finished reading the staging set.  The HOST waits for that (an event the compute stream recorded right
+        # after the commit's copies), not the copy stream: a host-to-device copy that carries a device-side dependency on the compute stream
+        # cost the replayed step 0.45 ms wherever in the step it ran, the same copy without the edge nothing (tools/loader_probe.py,
+        # profiles/r6_probe_loader.txt).  Call order that keeps the host from ever idling the device: commit_prefetched() -> step() ->
+        # prefetch_batch(next) -- the wait then returns as soon as the device STARTS the step just enqueued.
+        self._staging_free.synchronize()
 
         def on_device(t):
             return any(on_device(v) for v in t.values()) if isinstance(t, dict) else (t is not None and t.is_cuda)

@@ -24,7 +24,7 @@ def test_library_builds_and_exports_header_symbols():
     for s in syms:
         assert hasattr(_lib.lib, s), f'{s} declared in prismer_hip.h but not exported'
     assert sorted(_lib.EXPORTS) == syms, (set(_lib.EXPORTS) ^ set(syms))
-    assert _lib.lib.ph_version() == _lib.ABI_VERSION == 104
+    assert _lib.lib.ph_version() == _lib.ABI_VERSION == 105
     assert _lib.lib.ph_last_error() is not None
 
 

@@ -964,3 +964,20 @@ def test_softmax_gather(ops):
     assert got.shape == (B, 6) and rel_fro(got, ref) < 1e-5
     assert ops.softmax_gather(last, torch.tensor([V + 3], device='cuda')).abs().max().item() == 0.0
 
+
+
+def test_store_words_carries_host_scalars_in_kernel_arguments(ops):
+    """ph_store_words: the per-step learning rate / bias corrections (fp32) and the 256 instance draws (int32) reach device memory through the
+    arguments of one launch; stream-ordered (a later call overwrites), bounds checked"""
+    import random as _r
+    hyper = torch.full((4,), -1.0, dtype=torch.float32, device='cuda')
+    table = torch.full((260,), -7, dtype=torch.int32, device='cuda')
+    vals = (5e-5 * 0.37, 1.0 - 0.9 ** 17, 1.0 - 0.999 ** 17)
+    draws = [_r.randint(0, 127) for _ in range(256)]
+    ops.store_words(hyper, vals, table, draws)
+    assert torch.equal(hyper.cpu(), torch.tensor(list(vals) + [-1.0], dtype=torch.float32))          # (same double -> fp32 rounding as torch.tensor)
+    assert table[:256].cpu().tolist() == draws and table[256:].cpu().tolist() == [-7] * 4
+    ops.store_words(hyper, (1.0, 2.0, 3.0))
+    assert hyper.cpu().tolist() == [1.0, 2.0, 3.0, -1.0] and table[:256].cpu().tolist() == draws
+    with pytest.raises(RuntimeError):
+        ops.store_words(torch.zeros(400, dtype=torch.float32, device='cuda'), [0.0] * 321)

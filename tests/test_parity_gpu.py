@@ -891,11 +891,15 @@ def test_loader_fed_graph_replay_without_host_sync_matches_set_batch_trajectory(
     assert tr.graphs is not None
     tr.prefetch_batch(*batches[1])
     snaps, losses = [], []
-    for i in range(steps):                                               # no synchronisation in here
+    for i in range(steps):                                               # no device synchronisation in here (prefetch_batch waits for the previous COMMIT only)
         tr.commit_prefetched()
         snaps.append([t.clone() for t in leaves({k: v for k, v in tr.static.items() if k != 'dloss'})])
-        tr.prefetch_batch(*batches[(i + 2) % 3])
-        losses.append(tr.step().clone())
+        if i % 2:                                                        # both call orders are legal (the recommended one is step -> prefetch)
+            tr.prefetch_batch(*batches[(i + 2) % 3])
+            losses.append(tr.step().clone())
+        else:
+            losses.append(tr.step().clone())
+            tr.prefetch_batch(*batches[(i + 2) % 3])
     torch.cuda.synchronize()
     for i, snap in enumerate(snaps):
         b = batches[(i + 1) % 3]
