@@ -560,7 +560,7 @@ class Trainer:
 
     def _schedule(self):
         """[(compute segment, host action right after it)].
-        One rank: forward + decoder backward | encoder backward (+ decoder AdamW as a parallel branch) | encoder AdamW.
+        One rank: the whole step is ONE segment (forward, decoder backward, encoder backward, both AdamW launches, seed advance).
         Data parallel: the backward is cut in reverse layer order -- decoder in `len(dec_cuts) - 1` stages, encoder trunk,
         encoder front; after every segment the finished ranges go to the bf16 all-reduce on the communication stream, so only
         the last one (the stems' 25 M parameters) is exchanged on the critical path; the decoder's AdamW runs on the
@@ -568,8 +568,12 @@ class Trainer:
         s = self.static
         if self.world == 1:
             nl = len(self.dec_prog.layers)
-            return [(lambda: self._seg_forward(self.static, (nl, 0)), None), (self._seg_enc_backward_with_dec_adamw, None),
-                    (self._seg_optimizer_tail, None)]
+
+            def whole_step():                  # ONE captured graph (round 6: three replays per step cost 0.18 ms in launch gaps, tools/stream_edge_probe.py's box)
+                self._seg_forward(self.static, (nl, 0))
+                self._seg_enc_backward_with_dec_adamw()
+                self._seg_optimizer_tail()
+            return [(whole_step, None)]
         cuts = self.dec_cuts
         nst = len(cuts) - 1
         sched = [(lambda: self._seg_forward(self.static, (cuts[0], cuts[1])), lambda: self._issue('dec0'))]

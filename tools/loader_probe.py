@@ -13,6 +13,12 @@ import torch
 import bench
 
 
+def three_segments(tr):
+    """the one-rank schedule of rounds 1-6 (three replays per step), installed before the first step captures"""
+    nl = len(tr.dec_prog.layers)
+    tr._schedule = lambda: [(lambda: tr._seg_forward(tr.static, (nl, 0)), None), (tr._seg_enc_backward_with_dec_adamw, None), (tr._seg_optimizer_tail, None)]
+
+
 def timed(fn, steps, warm=3):
     for _ in range(warm):
         fn()
@@ -27,6 +33,7 @@ def timed(fn, steps, warm=3):
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     tr, dims, _ = bench.build_trainer(32, True, 0, compact_labels=True)
+    three_segments(tr)                             # (one variant below releases the copy after the first of three replays; the shipped one-rank step is ONE graph, 0.18 ms faster)
 
     def pin(t):
         return {k: pin(v) for k, v in t.items()} if isinstance(t, dict) else t.cpu().pin_memory()

@@ -14,6 +14,12 @@ import bench
 from prismer_amd import ops
 
 
+def three_segments(tr):
+    """the one-rank schedule of rounds 1-6 (three replays per step), installed before the first step captures"""
+    nl = len(tr.dec_prog.layers)
+    tr._schedule = lambda: [(lambda: tr._seg_forward(tr.static, (nl, 0)), None), (tr._seg_enc_backward_with_dec_adamw, None), (tr._seg_optimizer_tail, None)]
+
+
 def timed(fn, steps, warm=3):
     for _ in range(warm):
         fn()
@@ -27,7 +33,12 @@ def timed(fn, steps, warm=3):
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    one, _, _ = bench.build_trainer(32, True, 0)            # the Trainer as shipped: the whole one-rank step is ONE graph
+    one.step()
+    print(f'whole step as ONE graph (shipped)                      {timed(one.step, steps):8.3f} ms/step', flush=True)
+    del one
     tr, dims, _ = bench.build_trainer(32, True, 0)
+    three_segments(tr)                                      # the probe needs replay boundaries inside the step: forward + decoder backward | encoder backward | optimizer tail
     tr.step()
     side = torch.cuda.Stream()
     a = torch.empty(16 << 20, dtype=torch.float32, device='cuda')
@@ -54,7 +65,7 @@ def main():
             return f
         tr.graphs = [(graphs[0][0], after(0)), (graphs[1][0], after(1)), graphs[2]]
 
-    print(f'plain step                                             {timed(tr.step, steps):8.3f} ms/step', flush=True)
+    print(f'plain step, three graphs                               {timed(tr.step, steps):8.3f} ms/step', flush=True)
     for name, kw in (('side kernels, no edges', dict(edge=False, kernel=True)),
                      ('edges (event -> side stream waits -> join), no kernels', dict(edge=True, kernel=False)),
                      ('edges + side kernels (the multi-rank pattern)', dict(edge=True, kernel=True)),
