@@ -78,7 +78,7 @@ def make_inputs(dims, batch, T, seed, device, compact_labels=False):
     return x, ids, mask, labels
 
 
-def build_trainer(batch, use_graph, rank, T=30, workload='base_caption', freeze='freeze_vision', compact_labels=False, grad_payload='fp32',
+def build_trainer(batch, use_graph, rank, T=30, workload='base_caption', freeze='freeze_vision', compact_labels=False, grad_payload='fp32', issue='device',
                   shard=False):
     from prismer_amd import config as pcfg
     from prismer_amd.model.prismer_caption import PrismerCaption
@@ -103,7 +103,7 @@ def build_trainer(batch, use_graph, rank, T=30, workload='base_caption', freeze=
         cfg = {'experts': pcfg.CAPTION_EXPERTS, 'image_resolution': 224, 'prismer_model': 'prismer_base', 'freeze': freeze}
         model = PrismerCaption(cfg).cuda()
     tr = Trainer(model, lr=5e-5, weight_decay=0.05, total_steps=10000, task='caption', use_graph=use_graph, grad_payload=grad_payload,
-                 shard_optimizer=shard)
+                 shard_optimizer=shard, exchange_issue=issue)
     x, ids, mask, labels = make_inputs(dims, batch, T, 1234 + rank, torch.device('cuda'), compact_labels)
     weights = None
     if workload == 'large_vqa':
@@ -367,6 +367,9 @@ def main():
     ap.add_argument('--grad-payload', default='auto', choices=['auto', 'fp32', 'bf16'],
                     help='N > 1: gradient exchange payload. fp32 = DDP semantics; bf16 = pre-scaled by 1/world, half the bytes; auto (default) = fp32 unless a '
                          'probe all-reduce at start-up measures < 150 GB/s of bus bandwidth on >= 4 ranks (the decision is printed in grad_exchange)')
+    ap.add_argument('--issue', default='device', choices=['device', 'host'],
+                    help="N > 1: how a finished backward stage reaches the communication stream: 'device' = stream event edge (default); 'host' = the next "
+                         "segment is enqueued, then the host waits for the stage and launches the collectives (no device-side edge: see Trainer.exchange_issue)")
     ap.add_argument('--shard', default='none', choices=['none', 'zero1', 'rs_ag'],
                     help='N > 1: none = replicated AdamW behind an all-reduce; zero1 = sharded AdamW + broadcasts; rs_ag = reduce-scatter + '
                          'sharded AdamW + all-gather (FSDP SHARD_GRAD_OP pattern)')
@@ -417,7 +420,7 @@ def main():
         assert ranks_seen == world, (ranks_seen, world)
 
     tr, dims, n_train = build_trainer(args.batch, not args.no_graph, rank, workload=args.workload, freeze=args.freeze,
-                                      compact_labels=args.compact_labels, grad_payload=args.grad_payload,
+                                      compact_labels=args.compact_labels, grad_payload=args.grad_payload, issue=args.issue,
                                       shard={'none': False, 'zero1': True, 'rs_ag': 'rs_ag'}[args.shard])
     # algorithmic train GFLOP per image (SURVEY 8d / BASELINE.md section 2): (freeze_vision, none)
     gf_img = {'base_caption': (TRAIN_GF_PER_IMG, 307.26), 'z_base_caption': (134.30, 167.59), 'large_vqa': (2987.8, 3724.7)}[args.workload][

@@ -41,7 +41,7 @@ class Trainer:
     def __init__(self, model, lr=5e-5, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8, min_lr=0.0, total_steps=1000,
                  task='caption', use_graph=True, process_group=None, bucket_mb=64, side_stream=False, micro_batches=1, keep_grads=False,
                  max_text_len=None, grad_payload='fp32', transport='torch.distributed', dec_backward_stages=3, lr_schedule=None,
-                 shard_optimizer=False, overwrite_single_writer=True, allow_eager_fallback=False, broadcast_buffers=False):
+                 shard_optimizer=False, overwrite_single_writer=True, allow_eager_fallback=False, broadcast_buffers=False, exchange_issue='device'):
         self.model = model
         self.enc, self.dec = model.expert_encoder, model.text_decoder
         self.init_lr, self.min_lr, self.total_steps = lr, min_lr, total_steps
@@ -58,6 +58,16 @@ class Trainer:
             self.world = torch.distributed.get_world_size(process_group)
         self.it = 0
         self.graphs = None
+        # How a finished stage's gradients reach the communication stream (N > 1, graph replay):
+        #   'device' (default): the communication stream waits for an event of the compute stream (round 1-6 behaviour);
+        #   'host': the NEXT segment is enqueued first, then the host waits for the stage's event and launches the collectives with no
+        #           device-side edge.  tools/stream_edge_probe.py (one GPU, stand-in kernels): an edge from the graph-launching stream to another
+        #           stream costs the replayed step a fixed ~0.45 ms, a host wait with the next segment already enqueued nothing.  Not the default
+        #           because no RCCL run has compared the two yet; identical arithmetic, identical collective order.
+        if exchange_issue not in ('device', 'host'):
+            raise ValueError("exchange_issue must be 'device' or 'host'")
+        self.exchange_issue = exchange_issue
+        self._host_wait_s = 0.0
         self.static = None
         self.staging = None                    # second input buffer set of prefetch_batch / commit_prefetched
         self._staged = False                   # a batch sits in the staging set, not yet committed
@@ -238,6 +248,7 @@ class Trainer:
         if self.exchange is None:
             return None
         d = self.exchange.describe()
+        d['issue'] = self.exchange_issue + (' (stream event edge per stage)' if self.exchange_issue == 'device' else ' (host waits for the stage, next segment already enqueued)')
         if getattr(self, 'payload_decision', None):
             d['payload_decision'] = self.payload_decision
         return d
@@ -279,10 +290,19 @@ class Trainer:
         if self.exchange is None:
             return
         self.trace.append(('issue', stage))
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
+        ev, self._issue_event = self._issue_event, None       # host mode: recorded right behind the stage's replay, before the next segment was enqueued
+        if ev is not None:
+            t0 = time.perf_counter()
+            ev.synchronize()                                   # the stage's gradients are complete: no device-side edge needed
+            self._host_wait_s += time.perf_counter() - t0     # (waiting for COMPUTE: not communication time, kept out of comm_ms_exposed)
+            after = None
+        else:                                                  # device mode, eager steps, the warm-up passes of the capture
+            after = torch.cuda.Event()
+            after.record(torch.cuda.current_stream())
         for si, lo, hi in self.stage_ranges.get(stage, ()):
-            self.exchange.issue(self.stores[si].grad, lo, hi, tag=f'{stage}:{si}', after=ev)
+            self.exchange.issue(self.stores[si].grad, lo, hi, tag=f'{stage}:{si}', after=after)
+
+    _issue_event = None
 
     def _wait_comm(self):
         if self.world > 1:
@@ -831,16 +851,38 @@ class Trainer:
                     st.grad.zero_()
             self._step_open = True
             timed = self.exchange is not None and self.exchange.timing
+            def run(coll, ev=None):
+                self._issue_event = ev
+                if timed:                                       # host time inside the exchange calls: a transport that BLOCKS the host thread (gloo; a
+                    t0, w0 = time.perf_counter(), self._host_wait_s                # mis-configured RCCL) stalls the launches behind it -- invisible to device events
+                    coll()
+                    self._host_comm_s += (time.perf_counter() - t0) - (self._host_wait_s - w0)
+                else:
+                    coll()
+            host_issue = self.exchange_issue == 'host' and self.exchange is not None
+            pending = None
             for i, (g, coll) in enumerate(self.graphs):
                 self.trace.append(('seg', i))
                 g.replay()
+                if not host_issue:
+                    if coll is not None:
+                        run(coll)
+                    continue
+                # host-driven issue: the event of segment i is recorded now, its host action runs after segment i + 1 has been enqueued (the
+                # device never idles while the host wakes up); the LAST host action of the backward (exchange of the front stage + join +
+                # sharded tails) has nothing left to hide behind and runs at once
+                ev = None
                 if coll is not None:
-                    if timed:                                   # host time inside the exchange calls: a transport that BLOCKS the host thread (gloo; a
-                        t0 = time.perf_counter()                # mis-configured RCCL) stalls the launches behind it -- invisible to device events
-                        coll()
-                        self._host_comm_s += time.perf_counter() - t0
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream())    # (directly behind this segment's replay)
+                if pending is not None:
+                    run(*pending)
+                    pending = None
+                if coll is not None:
+                    if i + 1 < len(self.graphs) and self.graphs[i + 1][1] is not None:
+                        pending = (coll, ev)
                     else:
-                        coll()
+                        run(coll, ev)
             if timed:
                 self._host_comm_steps += 1
             self._step_open = False

@@ -17,7 +17,7 @@ def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, use_graph, out, payload='bf16', n_steps=2, shard=False, backend='gloo', own_device=False, transport='torch.distributed', bcast_buffers=False):
+def _worker(rank, world, port, use_graph, out, payload='bf16', n_steps=2, shard=False, backend='gloo', own_device=False, transport='torch.distributed', bcast_buffers=False, issue='device'):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
@@ -46,7 +46,7 @@ def _worker(rank, world, port, use_graph, out, payload='bf16', n_steps=2, shard=
     m = Holder(); m.expert_encoder, m.text_decoder = enc, dec
     tab = case.instance_table(x)
     tr = Trainer(m, lr=1e-3, total_steps=10, use_graph=use_graph, keep_grads=True, grad_payload=payload, dec_backward_stages=2,
-                 shard_optimizer=shard, transport=transport, broadcast_buffers=bcast_buffers)
+                 shard_optimizer=shard, transport=transport, broadcast_buffers=bcast_buffers, exchange_issue=issue)
     assert tr.world == world and tr.dec_cuts == [2, 1, 0]
     tr.set_batch(T.to_dev(x), ids, mask, labels)
     orig = tr._host_prologue
@@ -96,6 +96,31 @@ def test_two_ranks_one_gpu(use_graph):
         cover[int(tag.split(':')[1])] += hi - lo
     assert [cover[0], cover[1]] == a['n_train'], (cover, a['n_train'])
     assert a['desc']['payload'] == 'bf16'
+
+
+@pytest.mark.parametrize('shard', [False, 'rs_ag'])
+def test_host_driven_issue_equals_device_side_edges(shard):
+    """Trainer(exchange_issue='host') (round 6, opt-in): the next segment is enqueued before the host waits for a finished stage and launches its
+    collectives without a stream edge.  Same collectives in the same order => the same trajectory as the default (to the run-to-run noise of the default itself); the host
+    enqueue order shows the one-segment look-ahead (the last stage has nothing to hide behind and is issued at once)."""
+    world = 2
+    res = {}
+    for key, issue in (('device', 'device'), ('device2', 'device'), ('host', 'host')):
+        mgr = mp.Manager(); out = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), True, out, 'fp32', 3, shard, 'gloo', False, 'torch.distributed', False, issue), nprocs=world, join=True)
+        res[key] = (out[0], out[1])
+
+    def dist_(x, y):
+        return max(((pa - pb).norm() / pb.norm()).item() for pa, pb in zip(x['params'], y['params']))
+    for pa, pb in zip(res['host'][0]['params'], res['host'][1]['params']):       # inside one run the ranks agree bit for bit
+        assert torch.equal(pa, pb)
+    # across runs the backward's fp32 atomics make Adam's first steps differ at noise level: the host-driven run must sit inside that spread
+    noise, d = dist_(res['device2'][0], res['device'][0]), dist_(res['host'][0], res['device'][0])
+    assert d <= 3.0 * noise + 1e-6, (d, noise)
+    assert abs(res['host'][0]['loss'] - res['device'][0]['loss']) <= 2e-3 * abs(res['device'][0]['loss'])
+    tr = res['host'][0]['trace']
+    want = [('seg', 0), ('seg', 1), ('issue', 'dec0'), ('seg', 2), ('issue', 'dec1'), ('seg', 3), ('issue', 'trunk'), ('issue', 'front')]
+    assert tr[:len(want)] == want, tr
 
 
 def test_two_ranks_bf16_payload_close_to_fp32():
