@@ -369,17 +369,23 @@ __global__ __launch_bounds__(256) void bn_apply_grouped_kernel(BnGroup g, float 
     }
   }
   __syncthreads();
-  const int cpr = C / 8;
-  const int64_t total = t.M * cpr;
+  // streaming pass (round 6): a thread keeps ONE group of 8 channels (its scale / shift live in registers) and walks the rows; the per-element
+  // LDS reads of the first version were 16 of the 18 memory instructions of an iteration
+  const int tpr = C / 8, rpp = 256 / tpr;
+  const int r_in = threadIdx.x / tpr, cc = threadIdx.x % tpr;
+  if (r_in >= rpp) return;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = lds[cc * 8 + e]; sh[e] = lds[C + cc * 8 + e]; }
   const bf16* y = (const bf16*)t.y;
   bf16* a = (bf16*)t.a;
-  for (int64_t id = (int64_t)lb * 256 + threadIdx.x; id < total; id += (int64_t)nb * 256) {
-    const int c = (int)(id % cpr) * 8;
-    bf16x8 v = *reinterpret_cast<const bf16x8*>(y + id * 8);
+#pragma unroll 4
+  for (int64_t r = (int64_t)lb * rpp + r_in; r < t.M; r += (int64_t)nb * rpp) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(y + r * C + cc * 8);
     bf16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = f2bf(fmaxf(bf2f(v[e]) * lds[c + e] + lds[C + c + e], 0.f));
-    *reinterpret_cast<bf16x8*>(a + id * 8) = o;
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(fmaxf(bf2f(v[e]) * sc[e] + sh[e], 0.f));
+    *reinterpret_cast<bf16x8*>(a + r * C + cc * 8) = o;
   }
 }
 
@@ -403,7 +409,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_grouped_kernel(BnGroup g) {
     }
     const bf16* y = (const bf16*)t.y;
     const bf16* da = (const bf16*)t.a;              // (the `a` slot of the item carries dA in the backward)
-#pragma unroll 4
+#ifndef PH_BN_REDUCE_UNROLL
+#define PH_BN_REDUCE_UNROLL 8          // (round 6 A/B, profiles/r6_ab_batchnorm_passes.txt: 4 -> 8 rows in flight 79.0 -> 74.0 us per launch)
+#endif
+#pragma unroll PH_BN_REDUCE_UNROLL
     for (int64_t r = (int64_t)lb * rpp + r_in; r < t.M; r += (int64_t)nb * rpp) {
       bf16x8 v = *reinterpret_cast<const bf16x8*>(y + r * C + cc * 8);
       bf16x8 d = *reinterpret_cast<const bf16x8*>(da + r * C + cc * 8);
@@ -426,26 +435,40 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_grouped_kernel(BnGroup g) {
   while (i + 1 < g.n && (int)blockIdx.x >= g.blk_start[i + 1]) ++i;
   const ph_bn_item& t = g.it[i];
   const int lb = (int)blockIdx.x - g.blk_start[i], nb = g.blk_start[i + 1] - g.blk_start[i];
-  const int C = t.C, cpr = C / 8;
-  const int64_t total = t.M * cpr;
+  const int C = t.C;
   const float invM = 1.f / (float)t.M;
   const bf16* y = (const bf16*)t.y;
   const bf16* da = (const bf16*)t.a;
   bf16* dy = (bf16*)t.dy;
   const float* bsums = (const float*)t.sums;
-  for (int64_t id = (int64_t)lb * 256 + threadIdx.x; id < total; id += (int64_t)nb * 256) {
-    const int c = (int)(id % cpr) * 8;
-    bf16x8 v = *reinterpret_cast<const bf16x8*>(y + id * 8);
-    bf16x8 d = *reinterpret_cast<const bf16x8*>(da + id * 8);
-    bf16x8 o;
+  // round 6: a thread keeps ONE group of 8 channels and walks the rows, so the per-channel terms are loop invariant and live in registers
+  // (the first version re-loaded 48 statistics per 8 elements).  dy = scale*(g - S1/M - xhat*S2/M) with xhat = (y - mean)*rstd, regrouped as
+  // dy = scale*g + A*y + B,  A = -scale*rstd*S2/M,  B = -scale*S1/M - A*mean       (g = dA where relu(bn(y)) > 0, else 0)
+  const int tpr = C / 8, rpp = 256 / tpr;
+  const int r_in = threadIdx.x / tpr, cc = threadIdx.x % tpr;
+  if (r_in < rpp) {
+    float sc[8], sh[8], ca[8], cb[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float yv = bf2f(v[e]);
-      const float xh = (yv - t.stats[c + e]) * t.stats[C + c + e];
-      const float gg = (yv * t.stats[2 * C + c + e] + t.stats[3 * C + c + e] > 0.f) ? bf2f(d[e]) : 0.f;
-      o[e] = f2bf(t.stats[2 * C + c + e] * (gg - bsums[c + e] * invM - xh * bsums[C + c + e] * invM));   // gamma*rstd = scale
+      const int c = cc * 8 + e;
+      const float mu = t.stats[c], rs = t.stats[C + c];
+      sc[e] = t.stats[2 * C + c]; sh[e] = t.stats[3 * C + c];
+      ca[e] = -sc[e] * rs * bsums[C + c] * invM;
+      cb[e] = -sc[e] * bsums[c] * invM - ca[e] * mu;
     }
-    *reinterpret_cast<bf16x8*>(dy + id * 8) = o;
+#pragma unroll 4
+    for (int64_t r = (int64_t)lb * rpp + r_in; r < t.M; r += (int64_t)nb * rpp) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(y + r * C + cc * 8);
+      const bf16x8 d = *reinterpret_cast<const bf16x8*>(da + r * C + cc * 8);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float yv = bf2f(v[e]);
+        const float gg = (yv * sc[e] + sh[e] > 0.f) ? bf2f(d[e]) : 0.f;
+        o[e] = f2bf(sc[e] * gg + (ca[e] * yv + cb[e]));
+      }
+      *reinterpret_cast<bf16x8*>(dy + r * C + cc * 8) = o;
+    }
   }
   if (lb == 0) {
     for (int c = threadIdx.x; c < C; c += 256) {
@@ -715,7 +738,10 @@ __global__ void zero_floats_kernel(float* __restrict__ p, int n) {
 static void zero_floats(float* p, int n, hipStream_t stream) {
   hipLaunchKernelGGL(zero_floats_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, stream, p, n);
 }
-static int bn_reduce_blocks(int C) { return std::max(64, 49152 / C); }
+#ifndef PH_BN_REDUCE_BUDGET
+#define PH_BN_REDUCE_BUDGET 49152      // blocks per item = budget / C: every block ends in 2C global float atomics (~40 G/s chip-wide); 4 x the blocks: 79 -> 134 us per launch
+#endif
+static int bn_reduce_blocks(int C) { return std::max(64, PH_BN_REDUCE_BUDGET / C); }
 
 extern "C" int ph_bn_stats(const void* y, int M, int C, const float* gamma, const float* beta, float* running_mean,
                            float* running_var, float momentum, float eps, int training, float* mean, float* rstd, float* scale,
@@ -771,7 +797,7 @@ static int bn_group_fill(const ph_bn_item* items, int n, BnGroup& g, int* max_c,
       const int rpp = 256 / (t.C / 8);
       blocks = (int)std::min<int64_t>(ceil_div64(t.M, (int64_t)rpp * 8), bn_reduce_blocks(t.C));
     } else {
-      blocks = (int)std::min<int64_t>(ceil_div64(t.M * (t.C / 8), 256 * 4), 2048);
+      blocks = (int)std::min<int64_t>(ceil_div64(t.M, (int64_t)(256 / (t.C / 8)) * 4), 2048);     // streaming passes: rows strided, 4+ rows per thread
     }
     total += std::max(blocks, 1);
     mc = std::max(mc, t.C);

@@ -598,7 +598,8 @@ def _bn_items(items):
 
 def bn_apply_relu_grouped(items, training, momentum=0.1, eps=1e-5):
     """items: dicts y [M,C] bf16 (conv output), a [M,C] bf16 (out: relu(bn(y))), gamma, beta, running_mean, running_var,
-    stats [4,C] fp32 (out), sums [2,C] fp32 (column sums from the conv GEMM epilogue; unused in eval mode)"""
+    stats [4,C] fp32 (out), sums [PH_COLSTAT_SLABS = 8][2][C] fp64 (column sums / sums of squares from the conv GEMM epilogue,
+    ph_gemm_args.col_stats; unused in eval mode)"""
     for arr, n in _bn_items(items):
         check(lib.ph_bn_apply_relu_grouped(arr, n, momentum, eps, int(training), _stream()), 'ph_bn_apply_relu_grouped')
 

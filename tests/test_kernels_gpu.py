@@ -757,6 +757,45 @@ def test_batchnorm(ops, M, C):
     assert rel_fro(ev[2], g * (rv + 1e-5).rsqrt()) < 1e-5
 
 
+@pytest.mark.parametrize('shapes', [[(5000, 96), (3001, 768)], [(777, 160), (1030, 1280), (641, 2048), (4099, 32)]])
+def test_batchnorm_grouped(ops, shapes):
+    """ph_bn_apply_relu_grouped / ph_bn_relu_bwd_grouped (the stems' same-index layers in one launch; vit.py:88-120 BatchNorm2d + ReLU in train
+    mode and their autograd) against torch: channel counts whose 8-channel groups do not divide the block (96, 160, 768, 1280), one row per
+    block iteration (2048), ragged row counts.  The forward takes its statistics from fp64 column sums as the conv epilogue leaves them."""
+    fwd, bwd, refs = [], [], []
+    for k, (M, C) in enumerate(shapes):
+        y = rnd(M, C, seed=60 + k) * 2 + 0.5
+        g = 1 + 0.1 * rnd(C, dtype=torch.float32, seed=70 + k)
+        b = 0.1 * rnd(C, dtype=torch.float32, seed=80 + k)
+        rm = 0.1 * rnd(C, dtype=torch.float32, seed=90 + k); rv = 1 + 0.2 * rnd(C, dtype=torch.float32, seed=100 + k).abs()
+        rmr, rvr = rm.clone(), rv.clone()
+        sums = torch.zeros(8, 2, C, dtype=torch.float64, device='cuda')
+        sums[k % 8, 0] = y.double().sum(0); sums[(k + 3) % 8, 1] = (y.double() ** 2).sum(0)        # (any split over the slabs)
+        a, stats = torch.empty_like(y), torch.zeros(4, C, dtype=torch.float32, device='cuda')
+        fwd.append(dict(y=y, a=a, gamma=g, beta=b, running_mean=rm, running_var=rv, stats=stats, sums=sums))
+        yf = y.float().requires_grad_(True)
+        gf, bf_ = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        ref = torch.relu(F.batch_norm(yf, rmr, rvr, gf, bf_, True, 0.1, 1e-5))
+        da = rnd(M, C, seed=110 + k)
+        ref.backward(da.float())
+        refs.append((ref, yf, gf, bf_, rmr, rvr))
+        bwd.append(dict(y=y, a=da, dy=torch.empty_like(y), gamma=g, beta=b, stats=stats, sums=torch.zeros(2 * C, dtype=torch.float32, device='cuda'),
+                        dgamma=torch.zeros(C, device='cuda'), dbeta=torch.zeros(C, device='cuda')))
+    ops.bn_apply_relu_grouped(fwd, True)
+    ops.bn_relu_bwd_grouped(bwd)
+    for f, bw, (ref, yf, gf, bf_, rmr, rvr) in zip(fwd, bwd, refs):
+        assert rel_fro(f['a'], ref) < 5e-3, rel_fro(f['a'], ref)                                     # (bf16 output)
+        assert rel_fro(f['running_mean'], rmr) < 1e-4 and rel_fro(f['running_var'], rvr) < 1e-3
+        assert rel_fro(bw['dy'], yf.grad) < 1e-2, rel_fro(bw['dy'], yf.grad)
+        assert rel_fro(bw['dgamma'], gf.grad) < 3e-3 and rel_fro(bw['dbeta'], bf_.grad) < 3e-3
+    # eval mode: running statistics, no update
+    rm0 = fwd[0]['running_mean'].clone()
+    ops.bn_apply_relu_grouped(fwd[:1], False)
+    y, g, b = fwd[0]['y'].float(), fwd[0]['gamma'], fwd[0]['beta']
+    want = torch.relu((y - fwd[0]['running_mean']) * (fwd[0]['running_var'] + 1e-5).rsqrt() * g + b)
+    assert rel_fro(fwd[0]['a'], want) < 5e-3 and torch.equal(fwd[0]['running_mean'], rm0)
+
+
 @pytest.mark.parametrize('B', [2, 19])          # 19: batch slices (gridDim.y = 4) with a ragged last slice
 def test_tokens_finalize(ops, B):
     g_, D, E = 4, 256, 64
