@@ -198,22 +198,35 @@ __global__ __launch_bounds__(256) void im2col_kernel(const bf16* __restrict__ x,
       }
       *reinterpret_cast<u32x4*>(col + m * Kp + k) = v;
     }
-  } else {     // small C (1 or 3): one thread per element
-    int64_t total = (int64_t)B * Ho * Wo * Kp;
+  } else {     // small C (1 or 3): one thread per 8 consecutive k of an output pixel (round 6: was one thread per ELEMENT with four 64-bit
+               // divisions and a 2-byte store each: 37 us per launch for 19 MB of traffic)
+    const int cpr = Kp / 8;
+    const int64_t total = (int64_t)B * Ho * Wo * cpr;
+    const bool f32 = total < (1ll << 31);
     for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
-      int k = (int)(id % Kp);
-      int64_t m = id / Kp;
-      int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho), b = (int)(m / ((int64_t)Wo * Ho));
-      float v = 0.f;
-      if (k < K) {
-        int tap = k / C, c = k % C, ky = tap / ks, kx = tap % ks;
-        int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-          v = bf2f(x[(((int64_t)b * H + iy) * W + ix) * C + c]);
-          if (sc) v = fmaxf(v * sc[c] + sh[c], 0.f);
+      int ch, ox, oy;
+      int64_t m, t, bb;
+      divmod(id, cpr, f32, m, ch);
+      divmod(m, Wo, f32, t, ox);
+      divmod(t, Ho, f32, bb, oy);
+      const bf16* xb = x + (int64_t)bb * H * W * C;
+      const int iy0 = oy * stride - pad, ix0 = ox * stride - pad;
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = ch * 8 + e;
+        float v = 0.f;
+        if (k < K) {
+          const int tap = k / C, c = k - tap * C, ky = tap / ks, kx = tap - ky * ks;
+          const int iy = iy0 + ky, ix = ix0 + kx;
+          if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+            v = bf2f(xb[((int64_t)iy * W + ix) * C + c]);
+            if (sc) v = fmaxf(v * sc[c] + sh[c], 0.f);
+          }
         }
+        o[e] = f2bf(v);
       }
-      col[id] = f2bf(v);
+      *reinterpret_cast<bf16x8*>(col + m * Kp + ch * 8) = o;
     }
   }
 }
@@ -709,7 +722,7 @@ extern "C" int ph_im2col_nhwc(const void* x, void* col, int B, int H, int W, int
     hipLaunchKernelGGL(im2col_kernel<true>, dim3(grid_for((int64_t)B * Ho * Wo * (Kp / 8))), dim3(256), 0, stream, (const bf16*)x,
                        (bf16*)col, B, H, W, C, ksize, stride, Kp, Ho, Wo, bn_scale, bn_shift);
   } else {
-    hipLaunchKernelGGL(im2col_kernel<false>, dim3(grid_for((int64_t)B * Ho * Wo * Kp)), dim3(256), 0, stream, (const bf16*)x,
+    hipLaunchKernelGGL(im2col_kernel<false>, dim3(grid_for((int64_t)B * Ho * Wo * (Kp / 8))), dim3(256), 0, stream, (const bf16*)x,
                        (bf16*)col, B, H, W, C, ksize, stride, Kp, Ho, Wo, bn_scale, bn_shift);
   }
   PH_LAUNCH_CHECK("im2col_kernel");
